@@ -1,0 +1,286 @@
+"""Generate the golden fixtures under tests/golden/ from the reference itself.
+
+Run in the BUILD CONTAINER only (needs /root/reference):   python oracle/gen_golden.py
+The reference is imported unmodified through oracle/ref_harness.py; this script only
+*drives* it (np.random.seed, env.reset/step, Learner/RolloutStorage/JointPPO calls in
+the order of train_fortattack.py:49-116) and records inputs and outputs.  The fixtures
+are data (actions in, observations / rewards / flags / storage tensors out); no
+reference source text is stored.
+
+Batch "identical seeds" convention: env e of a batch with
+base_seed B is the reference run as  np.random.seed(B + e); construct; reset();
+step(actions[t, e]); on done reset() (same RNG stream continues).
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import ref_harness as rh  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+
+
+def scripted_actions(rng, T, E, G, A, p_shoot=0.35, p_up=0.45):
+    """Aggressive scripted-random policy so that all three endings and many deaths occur."""
+    N = G + A
+    a = rng.randint(0, 8, size=(T, E, N))
+    m = rng.rand(T, E, N)
+    a[:, :, :G] = np.where(m[:, :, :G] < p_shoot, 7, a[:, :, :G])
+    a[:, :, G:] = np.where(m[:, :, G:] < p_up, 3, a[:, :, G:])
+    # a few attackers shoot back
+    a[:, :, G:] = np.where(m[:, :, G:] > 0.9, 7, a[:, :, G:])
+    return a.astype(np.int8)
+
+
+def run_env_batch(G, A, max_t, T, E, base_seed, act_seed, full):
+    """Drive E reference envs sequentially (the numpy RNG is global)."""
+    N = G + A
+    actions = scripted_actions(np.random.RandomState(act_seed), T, E, G, A)
+    rec = dict(actions=actions, obs0=np.zeros((E, N, 6)), reward=np.zeros((T, E, N)),
+               done=np.zeros((T, E), np.uint8), alive_before=np.zeros((T, E, N), np.uint8),
+               hit=np.zeros((T, E, N), np.uint8), was_hit=np.zeros((T, E, N), np.uint8),
+               game_result=np.zeros((T, E, 3), np.uint8), obs_sum=np.zeros((T, E)),
+               alive_after=np.zeros((T, E, N), np.uint8))
+    if full:
+        rec["obs"] = np.zeros((T, E, N, 6))  # trainer view: post-reset obs where done
+    term_obs, term_idx = [], []
+    final = dict(prev_dist=np.zeros((E, N)), num_hit=np.zeros((E, N), np.int32),
+                 num_was_hit=np.zeros((E, N), np.int32), time_step=np.zeros(E, np.int32))
+    skip = None
+    for e in range(E):
+        np.random.seed(base_seed + e)
+        env, skip = rh.make_reference_env(G, A, max_t)
+        with rh.quiet():
+            obs = env.reset()
+        rec["obs0"][e] = obs
+        for t in range(T):
+            rec["alive_before"][t, e] = obs[:, 0]
+            with rh.quiet():
+                obs, rew, done, _ = env.step(actions[t, e].astype(np.int64))
+            ag = env.world.agents
+            rec["reward"][t, e] = np.array(rew, dtype=np.float64)
+            rec["done"][t, e] = done
+            rec["alive_after"][t, e] = obs[:, 0]
+            live = [(a.alive or a.justDied) for a in ag]
+            rec["hit"][t, e] = [int(a.hit and l) for a, l in zip(ag, live)]
+            rec["was_hit"][t, e] = [int(a.wasHit and l) for a, l in zip(ag, live)]
+            if done:
+                rec["game_result"][t, e] = env.world.gameResult
+                term_obs.append(obs.copy())
+                term_idx.append((t, e))
+                with rh.quiet():
+                    obs = env.reset()
+            rec["obs_sum"][t, e] = obs.sum()
+            if full:
+                rec["obs"][t, e] = obs
+        ag = env.world.agents
+        final["prev_dist"][e] = [np.nan if a.prevDist is None else a.prevDist for a in ag]
+        final["num_hit"][e] = [a.numHit for a in ag]
+        final["num_was_hit"][e] = [a.numWasHit for a in ag]
+        final["time_step"][e] = env.world.time_step
+    rec["term_obs"] = np.array(term_obs).reshape(-1, N, 6)
+    rec["term_idx"] = np.array(term_idx, np.int32).reshape(-1, 2)
+    rec.update({"final_" + k: v for k, v in final.items()})
+    rec["meta"] = np.array([G, A, max_t, T, E, base_seed, skip], np.int64)
+    return rec
+
+
+def gen_env_fixtures():
+    specs = [  # name, G, A, max_t, T, E, base_seed, act_seed, full
+        ("env_3v3", 3, 3, 60, 192, 4, 0, 11, True),
+        ("env_5v5", 5, 5, 100, 160, 3, 123, 12, True),
+        ("env_2v4", 2, 4, 40, 96, 2, 77, 13, True),
+        ("env_1v1", 1, 1, 30, 64, 2, 5, 14, True),
+        ("env_3v3_long", 3, 3, 100, 400, 32, 4096, 15, False),
+        ("env_5v5_long", 5, 5, 100, 300, 16, 900, 16, False),
+    ]
+    for name, G, A, max_t, T, E, bs, as_, full in specs:
+        rec = run_env_batch(G, A, max_t, T, E, bs, as_, full)
+        gr = rec["game_result"].reshape(-1, 3).sum(0)
+        print("%-14s steps=%d deaths=%d endings[dead,timeout,fort]=%s" % (
+            name, T * E, int((rec["alive_before"] > rec["alive_after"]).sum()), gr.tolist()))
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), **rec)
+
+
+def gen_mt_kat():
+    seeds = np.array([0, 1, 123, 4096, 2 ** 31 - 1, 2 ** 32 - 1], np.uint64)
+    first = np.zeros((len(seeds), 8))
+    after = np.zeros((len(seeds), 8))
+    for i, s in enumerate(seeds):
+        np.random.seed(int(s))
+        first[i] = np.random.random_sample(8)
+        np.random.random_sample(700 - 8)  # crosses two state regenerations (624 words = 312 doubles)
+        after[i] = np.random.random_sample(8)
+    np.random.seed(123)
+    uni = np.array([np.random.uniform(-1, 1, 1)[0], np.random.uniform(-0.8, 0.8 * -0.8, 1)[0],
+                    np.random.uniform(-0.8 * 0.15 / 2, 0.8 * 0.15 / 2, 1)[0],
+                    np.random.uniform(0.8 * 0.8, 0.8, 1)[0]])
+    np.savez(os.path.join(OUT, "mt19937_kat.npz"), seeds=seeds, first=first, after_700=after,
+             uniform_seed123=uni)
+    print("mt19937_kat   ", first[2][:2])
+
+
+def _args(T, device="cpu"):
+    import torch
+    ns = argparse.Namespace(
+        env_name="fortattack-v1", num_agents=3, mask_dist=None, entity_mp=False, identity_size=0,
+        num_processes=1, num_steps=T, num_env_steps=25, no_cuda=True, cuda=False,
+        device=torch.device(device), dist_threshold=0.1, arena_size=1, lr=1e-4, gamma=0.99, tau=0.95,
+        entropy_coef=0.01, value_loss_coef=0.5, max_grad_norm=0.5, ppo_epoch=1, num_mini_batch=4,
+        clip_param=0.2, clipped_value_loss=True, continue_training=False, attacker_load_dir=None,
+        attacker_ckpts=[], load_dir=None)
+    return ns
+
+
+def gen_collector_fixture():
+    """Drive the reference's own Learner/Neo/RolloutStorage/JointPPO through the call
+    sequence of train_fortattack.py:49-116 for a few updates and record everything the
+    collector, GAE and advantage normalisation produce."""
+    import torch
+    rh.import_reference()
+    torch.set_num_threads(1)
+    import learner as ref_learner
+    import rlcore.algo.ppo as ref_ppo
+
+    G, A, T, max_t, n_upd, seed = 3, 3, 64, 25, 3, 2024
+    N = G + A
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    env, skip = rh.make_reference_env(G, A, max_t)
+    args = _args(T)
+    master = ref_learner.setup_master(args, env)
+
+    captured = {}
+    orig_gen = ref_ppo.magent_feed_forward_generator
+
+    def capturing_gen(rollouts_list, opp_rollouts_list, advantages_list, num_mini_batch):
+        captured.setdefault("adv", []).append([a.clone() for a in advantages_list])
+        return orig_gen(rollouts_list, opp_rollouts_list, advantages_list, num_mini_batch)
+
+    ref_ppo.magent_feed_forward_generator = capturing_gen
+
+    rec = dict(actions=np.zeros((n_upd, T, N), np.int8), done=np.zeros((n_upd, T), np.uint8))
+    keys = ["obs", "rewards", "masks", "value_preds", "returns", "action_log_probs", "actions_st"]
+    for k in keys + ["adv", "after_obs", "after_masks"]:
+        rec[k] = []
+    end_pts_all, next_values_all = [], []
+    with rh.quiet():
+        obs = env.reset()
+    rec["obs0"] = obs.copy()
+    for j in range(n_upd):
+        end_pts = []
+        master.initialize_obs(obs)
+        step = 0
+        while step < T:
+            masks = torch.FloatTensor(obs[:, 0])
+            with torch.no_grad():
+                actions_list, _ = master.act(step, masks)
+            agent_actions = np.array(actions_list).reshape(-1)
+            rec["actions"][j, step] = agent_actions
+            with rh.quiet():
+                obs, reward, done, _ = env.step(agent_actions)
+            reward = torch.from_numpy(np.stack(reward)).float()
+            master.update_rollout(obs, reward, masks)
+            rec["done"][j, step] = done
+            step += 1
+            if done:
+                end_pts.append(step)
+                with rh.quiet():
+                    obs = env.reset()
+                masks = torch.FloatTensor(obs[:, 0])
+                master.initialize_new_episode(step, obs, masks)
+        if end_pts[-1] != T:
+            end_pts.append(T)
+        master.wrap_horizon(end_pts)
+        st = [a.rollouts for a in master.all_agents]
+        # value_preds[end_pt] after wrap_horizon == the next_value used for that segment
+        next_values_all.append(np.array([[float(s.value_preds[ep, 0, 0]) for ep in end_pts] for s in st],
+                                        np.float32))
+        end_pts_all.append(end_pts)
+        for k in keys:
+            attr = "actions" if k == "actions_st" else k
+            rec[k].append(np.stack([getattr(s, attr).numpy().copy() for s in st]))
+        captured.pop("adv", None)
+        with rh.quiet():
+            master.update()
+        adv = [None] * N  # guards trained first, then attackers (learner.py:180-184)
+        adv[:G] = [a.numpy() for a in captured["adv"][0]]
+        adv[G:] = [a.numpy() for a in captured["adv"][1]]
+        rec["adv"].append(np.stack(adv))
+        master.after_update()
+        rec["after_obs"].append(np.stack([s.obs.numpy().copy() for s in st]))
+        rec["after_masks"].append(np.stack([s.masks.numpy().copy() for s in st]))
+    ref_ppo.magent_feed_forward_generator = orig_gen
+    for k in list(rec.keys()):
+        if isinstance(rec[k], list):
+            rec[k] = np.stack(rec[k])  # (n_upd, N, ...)
+    max_seg = max(len(e) for e in end_pts_all)
+    ep = np.full((n_upd, max_seg), -1, np.int32)
+    nv = np.zeros((n_upd, N, max_seg), np.float32)
+    for j, e in enumerate(end_pts_all):
+        ep[j, :len(e)] = e
+        nv[j, :, :len(e)] = next_values_all[j]
+    rec["end_pts"], rec["next_values"] = ep, nv
+    rec["meta"] = np.array([G, A, max_t, T, n_upd, seed, skip], np.int64)
+    rec["gamma_tau"] = np.array([args.gamma, args.tau])
+    np.savez_compressed(os.path.join(OUT, "collector_3v3.npz"), **rec)
+    print("collector_3v3  end_pts", end_pts_all)
+
+
+def gen_mpnn_fixture():
+    """Reference MPNN (mpnn.py) at hidden_dim=32: weights + inputs -> value, action
+    log-probs under given actions, entropy.  Small enough (~10k params) to ship."""
+    import torch
+    rh.import_reference()
+    torch.set_num_threads(1)
+    from mpnn import MPNN
+
+    class _Sp(object):
+        shape = (8,)
+
+    torch.manual_seed(7)
+    rec = {}
+    for tag, n_own, n_opp in (("g", 3, 3), ("a", 5, 2)):
+        net = MPNN(action_space=_Sp(), num_agents=n_own, num_opp_agents=n_opp, num_entities=0,
+                   input_size=6, hidden_dim=32, pos_index=2, mask_dist=None, entity_mp=False,
+                   policy_layers=1)
+        B = 5
+        inp = torch.randn(n_own * B, 6)      # agent-major (learner.py:150)
+        opp = torch.randn(n_opp * B, 6)
+        act = torch.randint(0, 8, (n_own * B, 1))
+        with torch.no_grad():
+            value, logp, ent, _ = net.evaluate_actions(inp, None, opp, None, act)
+            x = net._fwd(inp, opp, None)
+            logits = net.dist(net._policy(x)).logits
+        for k, v in net.state_dict().items():
+            rec["%s.sd.%s" % (tag, k)] = v.numpy()
+        rec[tag + ".inp"], rec[tag + ".opp"], rec[tag + ".act"] = inp.numpy(), opp.numpy(), act.numpy()
+        rec[tag + ".value"], rec[tag + ".logp"] = value.numpy(), logp.numpy()
+        rec[tag + ".entropy"], rec[tag + ".logits"] = ent.numpy(), logits.numpy()
+        rec[tag + ".shape"] = np.array([n_own, n_opp, B, 32])
+    # parameter count of the full-size policy (158 153)
+    full = MPNN(action_space=_Sp(), num_agents=3, num_opp_agents=3, num_entities=0, input_size=6,
+                pos_index=2, mask_dist=None, entity_mp=False, policy_layers=1)
+    rec["full_param_count"] = np.array(sum(p.numel() for p in full.parameters()))
+    rec["full_keys"] = np.array(list(full.state_dict().keys()))
+    np.savez_compressed(os.path.join(OUT, "mpnn_h32.npz"), **rec)
+    print("mpnn_h32       params(full)=%d" % int(rec["full_param_count"]))
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    which = sys.argv[1:] or ["mt", "env", "collector", "mpnn"]
+    if "mt" in which:
+        gen_mt_kat()
+    if "env" in which:
+        gen_env_fixtures()
+    if "collector" in which:
+        gen_collector_fixture()
+    if "mpnn" in which:
+        gen_mpnn_fixture()
+    sizes = {f: os.path.getsize(os.path.join(OUT, f)) for f in sorted(os.listdir(OUT)) if f.endswith(".npz")}
+    print(sizes, "total", sum(sizes.values()))
