@@ -1,0 +1,213 @@
+#!/usr/bin/env python
+"""bench.py -- env-steps/s of the FortAttack hot path on MI355X (BASELINE.json metric).
+
+One bench "step" = one pass of the hot path over one batch: a T=128-step rollout of
+E=4096 envs per GPU (FortAttack 3v3, open-loop uniform-random actions already resident in
+the rollout buffers) through the HIP step kernel with its fused collector write
+(obs / rewards / masks / done rows of the RolloutStorage layout), followed by the GAE scan
+and the two-pass advantage statistics + normalisation (the only cross-GPU exchange: an
+all-reduce of N x 3 doubles per pass when --gpus > 1).  Inputs are in HBM before the timed
+region starts.  The MPNN policy forward is NOT part of this workload (BASELINE config 2:
+"random policy, step-kernel only"); bench_rollout_mpnn.py times config 3.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
+        --master-port 29500 bench.py --gpus 8 --steps 20 --warmup 3
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s measured copy
+
+
+def algorithmic_bytes_per_env_step(n_agents):
+    """SURVEY.md 8(d) / BASELINE.md section 5: per agent 2*(6 f64 + 1 B alive) state r+w
+    + 8 B action + 24 B obs + 4 B reward + 4 B mask = 138 B; per env 9 B."""
+    return 138 * n_agents + 9
+
+
+def cpu_baseline(E, G, A, budget_s=16.0):
+    """The CPU oracle (oracle/fa_oracle.c, a C port of the reference's env.step) timed on
+    this box's host cores on a bounded sample of the same workload (uniform-random actions,
+    auto-reset, 3v3).  OpenMP over envs; the thread count is swept (one subprocess each) and
+    the best is reported with its thread count."""
+    import subprocess
+    avail = len(os.sched_getaffinity(0))
+    sweep = sorted({t for t in (1, 4, 8, 16, 32, 64, 128, avail) if t <= avail})
+    per = max(1.0, budget_s / len(sweep))
+    runs = []
+    for t in sweep:
+        env = dict(os.environ, OMP_NUM_THREADS=str(t), OMP_PROC_BIND="false")
+        cmd = [sys.executable, os.path.join(ROOT, "oracle", "cpu_bench.py"), "--envs", str(E if t > 1 else 256),
+               "--guards", str(G), "--attackers", str(A), "--seconds", "%.2f" % per]
+        try:
+            out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=per * 6 + 60)
+            runs.append(json.loads(out.stdout.strip().splitlines()[-1]))
+        except Exception as exc:  # a reported baseline must not take the bench down
+            runs.append({"threads": t, "env_steps_per_s": 0.0, "error": repr(exc)})
+    best = max(runs, key=lambda r: r["env_steps_per_s"])
+    single = next((r for r in runs if r["threads"] == 1), best)
+    return {"value": best["env_steps_per_s"], "unit": "env-steps/s", "cores": best["threads"], "kind": "port",
+            "sample": "oracle/fa_oracle.c (C port of the reference env.step + auto-reset, OpenMP over envs): "
+                      "%d envs x %d steps in %.1f s on %d threads (best of sweep %s over %d available cpus); "
+                      "1 thread: %.0f env-steps/s" % (
+                          best.get("envs", 0), best.get("steps", 0), best.get("seconds", 0.0), best["threads"],
+                          [(r["threads"], int(r["env_steps_per_s"])) for r in runs], avail,
+                          single["env_steps_per_s"]),
+            "single_thread": single["env_steps_per_s"],
+            "reference_python_note": "the reference's own Python env.step, measured in the survey container on "
+                                     "1 Xeon 2.1 GHz thread: 2580 env-steps/s at 3v3 (BASELINE.md section 3); "
+                                     "it cannot run on the GPU box"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--envs", type=int, default=4096, help="envs per GPU")
+    ap.add_argument("--rollout", type=int, default=128, help="env-steps per rollout (T)")
+    ap.add_argument("--guards", type=int, default=3)
+    ap.add_argument("--attackers", type=int, default=3)
+    ap.add_argument("--launch", choices=["fused", "per-step"], default="fused",
+                    help="fused: one launch advances all T steps (open-loop actions); "
+                         "per-step: T launches replayed from one hipGraph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-collector", action="store_true", help="time the step kernel only")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import emergent_multiagent_strategies_amd as fa
+    from emergent_multiagent_strategies_amd.dist import adv_mean_std
+
+    E, G, A, T = args.envs, args.guards, args.attackers, args.rollout
+    N = G + A
+    eng = fa.BatchedFortAttack(E, G, A, 100, base_seed=0, env_offset=rank * E, device=local_rank,
+                               track_counters=False)
+    st = fa.JointRolloutStorage(T, E, N, device=dev)
+    eng.bind_storage(st)
+    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+    st.actions.copy_(torch.randint(0, 8, st.actions.shape, device=dev, generator=gen))
+    st.value_preds.copy_(torch.randn(st.value_preds.shape, device=dev, generator=gen))
+    adv = torch.empty((T, E, N, 1), device=dev)
+    eng.collect_reset()
+
+    graph = None
+    if args.launch == "per-step":
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            for s in range(T):
+                eng.collect_step(s)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            for s in range(T):
+                eng.collect_step(s)
+
+    def env_rollout():
+        if graph is not None:
+            graph.replay()
+        else:
+            eng.collect_rollout(0, T)
+
+    def hot_path():
+        env_rollout()
+        if not args.no_collector:
+            eng.gae(0.99, 0.95)
+            mean, std = adv_mean_std(eng)      # two-pass fp64; all-reduce when world > 1
+            eng.adv_normalize(mean, std, out=adv)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        hot_path()
+    barrier()
+    torch.cuda.synchronize()
+    # HIP events on the launch stream bracket every env rollout launch of the timed region
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        ev[k][0].record()
+        env_rollout()
+        ev[k][1].record()
+        if not args.no_collector:
+            eng.gae(0.99, 0.95)
+            mean, std = adv_mean_std(eng)
+            eng.adv_normalize(mean, std, out=adv)
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    env_steps = world * E * T * args.steps
+    value = env_steps / elapsed
+    launches_per_rollout = T if graph is not None else 1
+    roll_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
+    launch_s = roll_ms * 1e-3 / launches_per_rollout
+    bytes_per_launch = algorithmic_bytes_per_env_step(N) * E * (T // launches_per_rollout)
+    achieved = bytes_per_launch / launch_s / 1e9
+
+    if rank == 0:
+        res = {
+            "metric": "env-steps/sec FortAttack %dv%d, %d parallel envs per GPU" % (G, A, E),
+            "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {
+                "workload": "FortAttack %dv%d, %d envs/GPU, %d-step rollout, open-loop uniform-random actions "
+                            "(BASELINE config 2), %s; %s" % (
+                                G, A, E, T,
+                                "fa_step fused over the rollout in one launch" if graph is None else
+                                "one fa_step launch per env-step replayed from a hipGraph",
+                                "step kernel only" if args.no_collector else
+                                "+ fused RolloutStorage write, GAE scan, 2-pass advantage statistics "
+                                "(all-reduce of N x 3 f64 when n_gpus > 1) and normalisation"),
+                "envs_per_gpu": E, "rollout_steps": T, "num_guards": G, "num_attackers": A,
+                "max_time_steps": 100, "rng": "mt19937 (reference-parity reset stream)",
+                "launch": args.launch, "parallelism": "env shards, %d rank(s)" % world},
+            "roofline": {
+                "bound": "hbm", "kernel": "fa_step_kernel<%d,%d>" % (G if (G, A) in ((3, 3), (5, 5)) else 0,
+                                                                   A if (G, A) in ((3, 3), (5, 5)) else 0),
+                "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                "traffic": None,
+                "algorithmic_bytes_per_env_step": algorithmic_bytes_per_env_step(N),
+                "env_steps_per_launch": E * (T // launches_per_rollout),
+                "avg_launch_us": launch_s * 1e6, "timed_by": "hipEvents on the launch stream, %d launches" % (
+                    args.steps * launches_per_rollout)},
+            "env_rollout_ms": roll_ms,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(E, G, A)
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,107 @@
+"""ctypes view of the C ABI in include/fortattack.h (csrc/libfortattack_hip.so).
+
+There is no CPU fallback: if the HIP library is missing or a call fails, this raises.
+"""
+import ctypes as C
+import os
+
+from . import build as _build
+
+c_p = C.c_void_p
+
+
+class FaError(RuntimeError):
+    pass
+
+
+class WorldConsts(C.Structure):
+    _fields_ = [(n, C.c_double) for n in (
+        "agent_size", "accel", "max_speed", "max_rot", "fort_dim", "door_x", "door_y", "dt", "damping",
+        "contact_force", "contact_margin", "wall_xmin", "wall_xmax", "wall_ymin", "wall_ymax",
+        "shoot_rad", "shoot_win")]
+
+
+class Config(C.Structure):
+    _fields_ = [("num_envs", C.c_int32), ("num_guards", C.c_int32), ("num_attackers", C.c_int32),
+                ("max_time_steps", C.c_int32), ("device_id", C.c_int32), ("rng_mode", C.c_int32),
+                ("base_seed", C.c_uint64), ("env_offset", C.c_int64), ("rng_skip_doubles", C.c_int32),
+                ("track_counters", C.c_int32), ("world", WorldConsts)]
+
+
+class StepIO(C.Structure):
+    _fields_ = [("actions", c_p), ("act_stride_env", C.c_int64), ("act_stride_agent", C.c_int64),
+                ("obs_f32", c_p), ("reward_f32", c_p), ("mask_f32", c_p), ("done", c_p),
+                ("obs_f64", c_p), ("reward_f64", c_p), ("hit", c_p), ("was_hit", c_p),
+                ("auto_reset", C.c_int32), ("num_steps", C.c_int32), ("act_stride_step", C.c_int64)]
+
+
+class Storage(C.Structure):
+    _fields_ = [("num_steps", C.c_int32), ("obs", c_p), ("recurrent_hidden_states", c_p),
+                ("rewards", c_p), ("value_preds", c_p), ("returns", c_p), ("action_log_probs", c_p),
+                ("actions", c_p), ("masks", c_p), ("done", c_p)]
+
+
+class StateHost(C.Structure):
+    _fields_ = [(n, c_p) for n in (
+        "pos_x", "pos_y", "vel_x", "vel_y", "ang", "prev_dist", "alive", "time_step", "num_hit",
+        "num_was_hit", "game_result", "result_count")]
+
+
+FA_RNG_MT19937, FA_RNG_PHILOX = 0, 1
+
+# every symbol include/fortattack.h declares
+EXPORTS = {
+    "fa_config_default": (C.c_int, [C.POINTER(Config)]),
+    "fa_create": (C.c_int, [C.POINTER(Config), C.POINTER(c_p)]),
+    "fa_destroy": (None, [c_p]),
+    "fa_last_error": (C.c_char_p, []),
+    "fa_num_agents": (C.c_int, [c_p]),
+    "fa_num_envs": (C.c_int, [c_p]),
+    "fa_reset": (C.c_int, [c_p, c_p, c_p, c_p, c_p]),
+    "fa_step": (C.c_int, [c_p, C.POINTER(StepIO), c_p]),
+    "fa_bind_storage": (C.c_int, [c_p, C.POINTER(Storage)]),
+    "fa_collect_step": (C.c_int, [c_p, C.c_int32, C.c_int32, c_p]),
+    "fa_collect_rollout": (C.c_int, [c_p, C.c_int32, C.c_int32, C.c_int32, c_p]),
+    "fa_collect_reset": (C.c_int, [c_p, c_p]),
+    "fa_gae": (C.c_int, [c_p, C.c_double, C.c_double, c_p]),
+    "fa_adv_stats": (C.c_int, [c_p, C.c_int32, c_p, c_p, c_p]),
+    "fa_adv_normalize": (C.c_int, [c_p, c_p, c_p, c_p, c_p]),
+    "fa_after_update": (C.c_int, [c_p, c_p]),
+    "fa_get_state": (C.c_int, [c_p, C.POINTER(StateHost)]),
+    "fa_set_state": (C.c_int, [c_p, C.POINTER(StateHost)]),
+    "fa_rng_peek": (C.c_int, [c_p, C.c_int32, C.c_int32, c_p]),
+}
+
+_lib = None
+
+
+def lib_path():
+    return _build.LIB
+
+
+def load():
+    """Load libfortattack_hip.so (must have been built: __graft_entry__.build())."""
+    global _lib
+    if _lib is None:
+        path = lib_path()
+        if not os.path.isfile(path):
+            raise FaError("HIP engine not built: %s is missing (run __graft_entry__.build() or "
+                          "python emergent-multiagent-strategies_amd/build.py)" % path)
+        lib = C.CDLL(path)
+        for name, (res, args) in EXPORTS.items():
+            fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().fa_last_error()
+        raise FaError("%s failed (%d): %s" % (what, rc, msg.decode() if msg else "?"))
+
+
+def default_config():
+    cfg = Config()
+    check(load().fa_config_default(C.byref(cfg)), "fa_config_default")
+    return cfg

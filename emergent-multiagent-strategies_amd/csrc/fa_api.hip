@@ -1,0 +1,479 @@
+// fa_api.hip -- host side of the C ABI declared in include/fortattack.h.
+// Owns the fp64 SoA world state + RNG state in HBM; everything else belongs to the caller.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "fa_device.h"
+#include "fortattack.h"
+
+hipError_t fa_launch_step(const FaStepArgs &a, hipStream_t st);
+hipError_t fa_launch_reset(const FaStepArgs &a, hipStream_t st);
+hipError_t fa_launch_seed(const FaState &s, int E, uint64_t base_seed, int64_t env_offset, int skip_words,
+                          hipStream_t st);
+hipError_t fa_launch_gae(const float *rewards, const float *value_preds, const float *masks, float *returns,
+                         const uint8_t *done, int T, int E, int N, double gamma, double tau, hipStream_t st);
+hipError_t fa_launch_adv_stats(int pass, const float *returns, const float *value_preds, const double *mean,
+                               long long rows, int N, double *partial, int nblocks, double *stats,
+                               hipStream_t st);
+hipError_t fa_launch_adv_norm(const float *returns, const float *value_preds, const double *mean,
+                              const double *std_, long long total, int N, float *out, hipStream_t st);
+
+static thread_local std::string g_err;
+
+static int fail(int code, const std::string &msg) {
+    g_err = msg;
+    return code;
+}
+#define FA_HIP(expr)                                                                          \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess)                                                                 \
+            return fail(FA_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));       \
+    } while (0)
+
+struct fa_env {
+    fa_config cfg;
+    int N;
+    FaDerived c;
+    FaState s;
+    void *slab;
+    size_t slab_bytes;
+    fa_storage st;
+    bool bound;
+    double *adv_partial; // [ADV_BLOCKS][N]
+    int adv_blocks;
+};
+
+namespace {
+struct DeviceGuard {
+    int prev;
+    bool changed;
+    explicit DeviceGuard(int dev) : prev(-1), changed(false) {
+        if (hipGetDevice(&prev) == hipSuccess && prev != dev) changed = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard() {
+        if (changed) (void)hipSetDevice(prev);
+    }
+};
+
+// Python float modulo (core.py:336: u[2] % (2*pi)): result takes the sign of the divisor.
+double py_mod(double a, double b) {
+    double r = std::fmod(a, b);
+    if (r != 0.0 && ((b < 0) != (r < 0))) r += b;
+    return r;
+}
+
+FaDerived derive(const fa_world_consts &w) {
+    const double pi = 3.141592653589793; // np.pi
+    FaDerived d;
+    d.agent_size = w.agent_size;
+    d.accel = w.accel;
+    d.max_speed = w.max_speed;
+    d.fort_dim = w.fort_dim;
+    d.door_x = w.door_x;
+    d.door_y = w.door_y;
+    d.dt = w.dt;
+    d.one_minus_damping = 1 - w.damping;           // core.py:328
+    d.contact_force = w.contact_force;
+    d.contact_margin = w.contact_margin;
+    d.dist_min = w.agent_size + w.agent_size;      // core.py:449
+    d.wall_xmin = w.wall_xmin;
+    d.wall_xmax = w.wall_xmax;
+    d.wall_ymin = w.wall_ymin;
+    d.wall_ymax = w.wall_ymax;
+    d.shoot_rad = w.shoot_rad;
+    d.half_win = w.shoot_win / 2;                  // core.py:376
+    d.rot_pos = py_mod(+w.max_rot, 2 * pi);        // core.py:336
+    d.rot_neg = py_mod(-w.max_rot, 2 * pi);
+    d.ang_guard = 3 * pi / 2;                      // fortattack_env_v1.py:59
+    d.ang_attacker = pi / 2;
+    // fortattack_env_v1.py:66  uniform(xMin,xMax), uniform(yMin, 0.8*yMin): lo + (hi-lo)*u
+    d.att_x_lo = w.wall_xmin;
+    d.att_x_rng = w.wall_xmax - w.wall_xmin;
+    d.att_y_lo = w.wall_ymin;
+    d.att_y_rng = 0.8 * w.wall_ymin - w.wall_ymin;
+    // fortattack_env_v1.py:70  uniform(-0.8*fortDim/2, 0.8*fortDim/2), uniform(0.8*yMax, yMax)
+    d.grd_x_lo = -0.8 * w.fort_dim / 2;
+    d.grd_x_rng = 0.8 * w.fort_dim / 2 - d.grd_x_lo;
+    d.grd_y_lo = 0.8 * w.wall_ymax;
+    d.grd_y_rng = w.wall_ymax - d.grd_y_lo;
+    // exact-zero contact shortcuts: clearance > 1000 * margin => exp(-1000) == +0.0
+    const double clr = 1000.0 * w.contact_margin;
+    d.contact_skip_d2 = (d.dist_min + clr) * (d.dist_min + clr) * (1.0 + 1e-12);
+    d.wall_skip = clr;
+    return d;
+}
+
+size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
+
+FaStepArgs base_args(const fa_env *env) {
+    FaStepArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.s = env->s;
+    a.E = env->cfg.num_envs;
+    a.G = env->cfg.num_guards;
+    a.A = env->cfg.num_attackers;
+    a.max_t = env->cfg.max_time_steps;
+    a.rng_mode = env->cfg.rng_mode;
+    a.track_counters = env->cfg.track_counters;
+    a.seed = env->cfg.base_seed;
+    a.env_offset = env->cfg.env_offset;
+    a.c = env->c;
+    a.nsteps = 1;
+    return a;
+}
+} // namespace
+
+extern "C" {
+
+const char *fa_last_error(void) { return g_err.c_str(); }
+
+int fa_config_default(fa_config *cfg) {
+    if (!cfg) return fail(FA_ERR_INVALID, "fa_config_default: null cfg");
+    std::memset(cfg, 0, sizeof(*cfg));
+    cfg->num_envs = 1;
+    cfg->num_guards = 3;
+    cfg->num_attackers = 3;
+    cfg->max_time_steps = 100; // arguments.py:24 --num-env-steps
+    cfg->device_id = 0;
+    cfg->rng_mode = FA_RNG_MT19937;
+    cfg->base_seed = 0;
+    cfg->env_offset = 0;
+    cfg->rng_skip_doubles = -1;
+    cfg->track_counters = 1;
+    fa_world_consts &w = cfg->world;
+    w.agent_size = 0.05;
+    w.accel = 3;
+    w.max_speed = 3;
+    w.max_rot = 0.17;
+    w.fort_dim = 0.15;
+    w.door_x = 0;
+    w.door_y = 0.8;
+    w.dt = 0.1;
+    w.damping = 0.25;
+    w.contact_force = 1e+2;
+    w.contact_margin = 1e-10;
+    w.wall_xmin = -1;
+    w.wall_xmax = 1;
+    w.wall_ymin = -0.8;
+    w.wall_ymax = 0.8;
+    w.shoot_rad = 0.8;
+    w.shoot_win = 3.141592653589793 / 4;
+    return FA_OK;
+}
+
+int fa_create(const fa_config *cfg, fa_env **out) {
+    if (!cfg || !out) return fail(FA_ERR_INVALID, "fa_create: null argument");
+    const int N = cfg->num_guards + cfg->num_attackers;
+    if (cfg->num_envs < 1) return fail(FA_ERR_INVALID, "fa_create: num_envs must be >= 1");
+    if (cfg->num_guards < 1 || cfg->num_attackers < 1 || N > FA_MAX_AGENTS)
+        return fail(FA_ERR_INVALID, "fa_create: need >=1 guard, >=1 attacker, <=16 agents");
+    if (cfg->max_time_steps < 1) return fail(FA_ERR_INVALID, "fa_create: max_time_steps must be >= 1");
+    if (cfg->rng_mode != FA_RNG_MT19937 && cfg->rng_mode != FA_RNG_PHILOX)
+        return fail(FA_ERR_INVALID, "fa_create: unknown rng_mode");
+    if (!(cfg->world.contact_margin > 0) || !(cfg->world.agent_size > 0))
+        return fail(FA_ERR_INVALID, "fa_create: contact_margin and agent_size must be > 0");
+    int ndev = 0;
+    FA_HIP(hipGetDeviceCount(&ndev));
+    if (cfg->device_id < 0 || cfg->device_id >= ndev) return fail(FA_ERR_INVALID, "fa_create: bad device_id");
+    DeviceGuard guard(cfg->device_id);
+
+    fa_env *env = new fa_env();
+    std::memset(static_cast<void *>(env), 0, sizeof(*env));
+    env->cfg = *cfg;
+    env->N = N;
+    if (env->cfg.rng_skip_doubles < 0) env->cfg.rng_skip_doubles = 2 * N;
+    env->c = derive(cfg->world);
+    env->adv_blocks = 1024;
+
+    const size_t E = (size_t)cfg->num_envs, EN = E * N;
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes); return o; };
+    const size_t o_f64 = carve(6 * EN * sizeof(double));
+    const size_t o_alive = carve(EN);
+    const size_t o_tstep = carve(E * sizeof(int32_t));
+    const size_t o_nh = carve(2 * EN * sizeof(int32_t));
+    const size_t o_gr = carve(E * 3);
+    const size_t o_rc = carve(E * 3 * sizeof(uint32_t));
+    const size_t o_mt = carve(E * FA_MT_N * sizeof(uint32_t));
+    const size_t o_pos = carve(E * sizeof(int32_t));
+    const size_t o_cnt = carve(E * sizeof(uint32_t));
+    const size_t o_adv = carve((size_t)env->adv_blocks * FA_MAX_AGENTS * sizeof(double));
+    env->slab_bytes = off;
+    hipError_t he = hipMalloc(&env->slab, env->slab_bytes);
+    if (he != hipSuccess) {
+        delete env;
+        return fail(FA_ERR_HIP, std::string("hipMalloc: ") + hipGetErrorString(he));
+    }
+    char *b = static_cast<char *>(env->slab);
+    double *f = reinterpret_cast<double *>(b + o_f64);
+    env->s.px = f;
+    env->s.py = f + EN;
+    env->s.vx = f + 2 * EN;
+    env->s.vy = f + 3 * EN;
+    env->s.ang = f + 4 * EN;
+    env->s.prev = f + 5 * EN;
+    env->s.alive = reinterpret_cast<uint8_t *>(b + o_alive);
+    env->s.tstep = reinterpret_cast<int32_t *>(b + o_tstep);
+    env->s.num_hit = reinterpret_cast<int32_t *>(b + o_nh);
+    env->s.num_was_hit = env->s.num_hit + EN;
+    env->s.game_result = reinterpret_cast<uint8_t *>(b + o_gr);
+    env->s.result_count = reinterpret_cast<uint32_t *>(b + o_rc);
+    env->s.mt = reinterpret_cast<uint32_t *>(b + o_mt);
+    env->s.mt_pos = reinterpret_cast<int32_t *>(b + o_pos);
+    env->s.reset_count = reinterpret_cast<uint32_t *>(b + o_cnt);
+    env->adv_partial = reinterpret_cast<double *>(b + o_adv);
+
+    // construction state (core.py:102-104): alive, prevDist None (NaN); positions are
+    // defined by the first reset.
+    he = hipMemset(env->slab, 0, env->slab_bytes);
+    if (he == hipSuccess) he = hipMemset(env->s.alive, 1, EN);
+    if (he == hipSuccess) {
+        std::vector<double> nan(EN, std::nan(""));
+        he = hipMemcpy(env->s.prev, nan.data(), EN * sizeof(double), hipMemcpyHostToDevice);
+    }
+    if (he == hipSuccess)
+        he = fa_launch_seed(env->s, cfg->num_envs, cfg->base_seed, cfg->env_offset,
+                            2 * env->cfg.rng_skip_doubles, nullptr);
+    if (he == hipSuccess) he = hipDeviceSynchronize();
+    if (he != hipSuccess) {
+        (void)hipFree(env->slab);
+        delete env;
+        return fail(FA_ERR_HIP, std::string("fa_create init: ") + hipGetErrorString(he));
+    }
+    *out = env;
+    return FA_OK;
+}
+
+void fa_destroy(fa_env *env) {
+    if (!env) return;
+    DeviceGuard guard(env->cfg.device_id);
+    (void)hipFree(env->slab);
+    delete env;
+}
+
+int fa_num_agents(const fa_env *env) { return env ? env->N : FA_ERR_INVALID; }
+int fa_num_envs(const fa_env *env) { return env ? env->cfg.num_envs : FA_ERR_INVALID; }
+
+int fa_reset(fa_env *env, const uint8_t *env_mask, float *obs_f32, double *obs_f64, void *stream) {
+    if (!env) return fail(FA_ERR_INVALID, "fa_reset: null env");
+    DeviceGuard guard(env->cfg.device_id);
+    FaStepArgs a = base_args(env);
+    a.reset_mask = env_mask;
+    a.obs32 = obs_f32;
+    a.obs64 = obs_f64;
+    FA_HIP(fa_launch_reset(a, static_cast<hipStream_t>(stream)));
+    return FA_OK;
+}
+
+int fa_step(fa_env *env, const fa_step_io *io, void *stream) {
+    if (!env || !io) return fail(FA_ERR_INVALID, "fa_step: null argument");
+    if (!io->actions) return fail(FA_ERR_INVALID, "fa_step: actions is null");
+    DeviceGuard guard(env->cfg.device_id);
+    FaStepArgs a = base_args(env);
+    a.actions = io->actions;
+    a.as_e = io->act_stride_env;
+    a.as_i = io->act_stride_agent;
+    a.as_t = io->act_stride_step;
+    a.nsteps = io->num_steps > 1 ? io->num_steps : 1;
+    a.obs32 = io->obs_f32;
+    a.rew32 = io->reward_f32;
+    a.mask32 = io->mask_f32;
+    a.done = io->done;
+    a.obs64 = io->obs_f64;
+    a.rew64 = io->reward_f64;
+    a.hit = io->hit;
+    a.was_hit = io->was_hit;
+    a.auto_reset = io->auto_reset;
+    FA_HIP(fa_launch_step(a, static_cast<hipStream_t>(stream)));
+    return FA_OK;
+}
+
+int fa_bind_storage(fa_env *env, const fa_storage *st) {
+    if (!env || !st) return fail(FA_ERR_INVALID, "fa_bind_storage: null argument");
+    if (st->num_steps < 1) return fail(FA_ERR_INVALID, "fa_bind_storage: num_steps must be >= 1");
+    if (!st->obs || !st->rewards || !st->value_preds || !st->returns || !st->actions || !st->masks ||
+        !st->done)
+        return fail(FA_ERR_INVALID, "fa_bind_storage: obs/rewards/value_preds/returns/actions/masks/done required");
+    env->st = *st;
+    env->bound = true;
+    return FA_OK;
+}
+
+int fa_collect_step(fa_env *env, int32_t step, int32_t auto_reset, void *stream) {
+    return fa_collect_rollout(env, step, 1, auto_reset, stream);
+}
+
+int fa_collect_rollout(fa_env *env, int32_t step, int32_t num_steps, int32_t auto_reset, void *stream) {
+    if (!env) return fail(FA_ERR_INVALID, "fa_collect_rollout: null env");
+    if (!env->bound) return fail(FA_ERR_STATE, "fa_collect_rollout: no storage bound");
+    const fa_storage &st = env->st;
+    if (step < 0 || num_steps < 1 || step + num_steps > st.num_steps)
+        return fail(FA_ERR_INVALID, "fa_collect_rollout: step range outside the bound storage");
+    DeviceGuard guard(env->cfg.device_id);
+    const size_t EN = (size_t)env->cfg.num_envs * env->N;
+    FaStepArgs a = base_args(env);
+    a.actions = st.actions + (size_t)step * EN;
+    a.as_e = env->N;
+    a.as_i = 1;
+    a.as_t = (int64_t)EN;
+    a.nsteps = num_steps;
+    a.obs32 = st.obs + (size_t)(step + 1) * EN * FA_OBS_DIM;
+    a.rew32 = st.rewards + (size_t)step * EN;
+    a.mask32 = st.masks + (size_t)(step + 1) * EN;
+    a.done = st.done + (size_t)step * env->cfg.num_envs;
+    a.auto_reset = auto_reset;
+    FA_HIP(fa_launch_step(a, static_cast<hipStream_t>(stream)));
+    return FA_OK;
+}
+
+int fa_collect_reset(fa_env *env, void *stream) {
+    if (!env) return fail(FA_ERR_INVALID, "fa_collect_reset: null env");
+    if (!env->bound) return fail(FA_ERR_STATE, "fa_collect_reset: no storage bound");
+    DeviceGuard guard(env->cfg.device_id);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    FaStepArgs a = base_args(env);
+    a.obs32 = env->st.obs;
+    FA_HIP(fa_launch_reset(a, s));
+    // masks[0] = 1 (every agent alive after a reset): float 1.0f fill
+    const size_t EN = (size_t)env->cfg.num_envs * env->N;
+    FA_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(env->st.masks), 0x3f800000, EN, s));
+    return FA_OK;
+}
+
+int fa_gae(fa_env *env, double gamma, double tau, void *stream) {
+    if (!env) return fail(FA_ERR_INVALID, "fa_gae: null env");
+    if (!env->bound) return fail(FA_ERR_STATE, "fa_gae: no storage bound");
+    DeviceGuard guard(env->cfg.device_id);
+    const fa_storage &st = env->st;
+    FA_HIP(fa_launch_gae(st.rewards, st.value_preds, st.masks, st.returns, st.done, st.num_steps,
+                         env->cfg.num_envs, env->N, gamma, tau, static_cast<hipStream_t>(stream)));
+    return FA_OK;
+}
+
+int fa_adv_stats(fa_env *env, int32_t pass, const double *mean, double *stats, void *stream) {
+    if (!env || !stats) return fail(FA_ERR_INVALID, "fa_adv_stats: null argument");
+    if (!env->bound) return fail(FA_ERR_STATE, "fa_adv_stats: no storage bound");
+    if (pass != 0 && pass != 1) return fail(FA_ERR_INVALID, "fa_adv_stats: pass must be 0 or 1");
+    if (pass == 1 && !mean) return fail(FA_ERR_INVALID, "fa_adv_stats: pass 1 needs mean");
+    DeviceGuard guard(env->cfg.device_id);
+    const fa_storage &st = env->st;
+    const long long rows = (long long)st.num_steps * env->cfg.num_envs;
+    long long want = (rows + 255) / 256;
+    const int nblocks = (int)(want < env->adv_blocks ? want : env->adv_blocks);
+    FA_HIP(fa_launch_adv_stats(pass, st.returns, st.value_preds, mean, rows, env->N, env->adv_partial,
+                               nblocks, stats, static_cast<hipStream_t>(stream)));
+    return FA_OK;
+}
+
+int fa_adv_normalize(fa_env *env, const double *mean, const double *std_, float *adv_out, void *stream) {
+    if (!env || !mean || !std_ || !adv_out) return fail(FA_ERR_INVALID, "fa_adv_normalize: null argument");
+    if (!env->bound) return fail(FA_ERR_STATE, "fa_adv_normalize: no storage bound");
+    DeviceGuard guard(env->cfg.device_id);
+    const fa_storage &st = env->st;
+    const long long total = (long long)st.num_steps * env->cfg.num_envs * env->N;
+    FA_HIP(fa_launch_adv_norm(st.returns, st.value_preds, mean, std_, total, env->N, adv_out,
+                              static_cast<hipStream_t>(stream)));
+    return FA_OK;
+}
+
+int fa_after_update(fa_env *env, void *stream) {
+    if (!env) return fail(FA_ERR_INVALID, "fa_after_update: null env");
+    if (!env->bound) return fail(FA_ERR_STATE, "fa_after_update: no storage bound");
+    DeviceGuard guard(env->cfg.device_id);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const fa_storage &st = env->st;
+    const size_t EN = (size_t)env->cfg.num_envs * env->N, T = (size_t)st.num_steps;
+    // storage.py:52-56: obs[0] = obs[-1]; obs[1:] = 0; hidden[0] = hidden[-1]; masks[0] = masks[-1]
+    FA_HIP(hipMemcpyAsync(st.obs, st.obs + T * EN * FA_OBS_DIM, EN * FA_OBS_DIM * sizeof(float),
+                          hipMemcpyDeviceToDevice, s));
+    FA_HIP(hipMemsetAsync(st.obs + EN * FA_OBS_DIM, 0, T * EN * FA_OBS_DIM * sizeof(float), s));
+    if (st.recurrent_hidden_states)
+        FA_HIP(hipMemcpyAsync(st.recurrent_hidden_states, st.recurrent_hidden_states + T * EN,
+                              EN * sizeof(float), hipMemcpyDeviceToDevice, s));
+    FA_HIP(hipMemcpyAsync(st.masks, st.masks + T * EN, EN * sizeof(float), hipMemcpyDeviceToDevice, s));
+    return FA_OK;
+}
+
+int fa_get_state(fa_env *env, const fa_state_host *o) {
+    if (!env || !o) return fail(FA_ERR_INVALID, "fa_get_state: null argument");
+    DeviceGuard guard(env->cfg.device_id);
+    FA_HIP(hipDeviceSynchronize());
+    const size_t E = (size_t)env->cfg.num_envs, EN = E * env->N;
+    const FaState &s = env->s;
+#define FA_D2H(dst, src, bytes) \
+    if (dst) FA_HIP(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost))
+    FA_D2H(o->pos_x, s.px, EN * 8);
+    FA_D2H(o->pos_y, s.py, EN * 8);
+    FA_D2H(o->vel_x, s.vx, EN * 8);
+    FA_D2H(o->vel_y, s.vy, EN * 8);
+    FA_D2H(o->ang, s.ang, EN * 8);
+    FA_D2H(o->prev_dist, s.prev, EN * 8);
+    FA_D2H(o->alive, s.alive, EN);
+    FA_D2H(o->time_step, s.tstep, E * 4);
+    FA_D2H(o->num_hit, s.num_hit, EN * 4);
+    FA_D2H(o->num_was_hit, s.num_was_hit, EN * 4);
+    FA_D2H(o->game_result, s.game_result, E * 3);
+#undef FA_D2H
+    if (o->result_count) {
+        std::vector<uint32_t> rc(E * 3);
+        FA_HIP(hipMemcpy(rc.data(), s.result_count, E * 3 * 4, hipMemcpyDeviceToHost));
+        for (size_t k = 0; k < E * 3; ++k) o->result_count[k] = (int64_t)rc[k];
+    }
+    return FA_OK;
+}
+
+int fa_set_state(fa_env *env, const fa_state_host *in) {
+    if (!env || !in) return fail(FA_ERR_INVALID, "fa_set_state: null argument");
+    DeviceGuard guard(env->cfg.device_id);
+    FA_HIP(hipDeviceSynchronize());
+    const size_t E = (size_t)env->cfg.num_envs, EN = E * env->N;
+    const FaState &s = env->s;
+#define FA_H2D(dst, src, bytes) \
+    if (src) FA_HIP(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice))
+    FA_H2D(s.px, in->pos_x, EN * 8);
+    FA_H2D(s.py, in->pos_y, EN * 8);
+    FA_H2D(s.vx, in->vel_x, EN * 8);
+    FA_H2D(s.vy, in->vel_y, EN * 8);
+    FA_H2D(s.ang, in->ang, EN * 8);
+    FA_H2D(s.prev, in->prev_dist, EN * 8);
+    FA_H2D(s.alive, in->alive, EN);
+    FA_H2D(s.tstep, in->time_step, E * 4);
+#undef FA_H2D
+    return FA_OK;
+}
+
+int fa_rng_peek(fa_env *env, int32_t e, int32_t count, double *out_host) {
+    if (!env || !out_host) return fail(FA_ERR_INVALID, "fa_rng_peek: null argument");
+    if (e < 0 || e >= env->cfg.num_envs || count < 0) return fail(FA_ERR_INVALID, "fa_rng_peek: bad index");
+    if (env->cfg.rng_mode != FA_RNG_MT19937) return fail(FA_ERR_STATE, "fa_rng_peek: MT19937 mode only");
+    DeviceGuard guard(env->cfg.device_id);
+    FA_HIP(hipDeviceSynchronize());
+    std::vector<uint32_t> mt(FA_MT_N);
+    int32_t pos = 0;
+    FA_HIP(hipMemcpy(mt.data(), env->s.mt + (size_t)e * FA_MT_N, FA_MT_N * 4, hipMemcpyDeviceToHost));
+    FA_HIP(hipMemcpy(&pos, env->s.mt_pos + e, 4, hipMemcpyDeviceToHost));
+    auto next = [&]() {
+        const int n1 = pos + 1 >= FA_MT_N ? pos + 1 - FA_MT_N : pos + 1;
+        const int nm = pos + FA_MT_M >= FA_MT_N ? pos + FA_MT_M - FA_MT_N : pos + FA_MT_M;
+        uint32_t y = (mt[pos] & 0x80000000u) | (mt[n1] & 0x7fffffffu);
+        uint32_t nw = mt[nm] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+        mt[pos] = nw;
+        pos = n1;
+        nw ^= (nw >> 11);
+        nw ^= (nw << 7) & 0x9d2c5680u;
+        nw ^= (nw << 15) & 0xefc60000u;
+        nw ^= (nw >> 18);
+        return nw;
+    };
+    for (int k = 0; k < count; ++k) {
+        uint32_t a = next() >> 5, b = next() >> 6;
+        out_host[k] = (a * 67108864.0 + b) / 9007199254740992.0;
+    }
+    return FA_OK;
+}
+
+} // extern "C"

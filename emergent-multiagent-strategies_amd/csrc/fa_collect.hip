@@ -1,0 +1,153 @@
+// fa_collect.hip -- PPO rollout-collector kernels (gfx950): GAE scan, advantage
+// statistics, advantage normalisation.  All tensors are the caller's joint
+// RolloutStorage buffers, (T[+1], E, N) float32, column c = e*N + i contiguous.
+//
+// These are HBM-streaming kernels: GAE reads r, V, m (12 B) and writes ret (4 B) per
+// (t, e, i); the statistics read ret, V (8 B).  One lane per column, consecutive lanes
+// on consecutive columns => every row access is a coalesced span.
+#include "fa_device.h"
+
+// Learner.wrap_horizon (learner.py:191-211) + RolloutStorage.compute_returns
+// (storage.py:59-66) as one backward pass with per-env episode boundaries.
+// `done[t*E + e]` != 0  <=>  the episode of env e ended at rollout step t, i.e. t+1 is one
+// of that env's end_pts; index end_pt < T is never visited by the reference (the next
+// segment starts at end_pt + 1, learner.py:211): its `returns` entry keeps its old value
+// and the accumulator restarts at 0 for the segment below it.
+// float32 throughout, operation order of storage.py:63-66; gamma and gamma*tau are
+// rounded to float32 once (torch scalar * tensor).
+__global__ __launch_bounds__(256) void fa_gae_kernel(const float *__restrict__ rewards,
+                                                     const float *__restrict__ value_preds,
+                                                     const float *__restrict__ masks,
+                                                     float *__restrict__ returns,
+                                                     const uint8_t *__restrict__ done, int T, int E,
+                                                     int N, float g32, float gt32) {
+    const long long EN = (long long)E * N;
+    const long long col = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= EN) return;
+    const int e = (int)(col / N);
+    float gae = 0.0f;
+    float v_next = value_preds[(long long)T * EN + col];
+    float m_next = masks[(long long)T * EN + col];
+#pragma unroll 4
+    for (int t = T - 1; t >= 0; --t) {
+        const float r = rewards[(long long)t * EN + col];
+        const float v = value_preds[(long long)t * EN + col];
+        const float m_t = masks[(long long)t * EN + col];
+        const bool ep_start = t > 0 && done[(long long)(t - 1) * E + e] != 0;
+        const float delta = r + g32 * v_next * m_next - v;
+        const float g = delta + gt32 * m_next * gae;
+        if (ep_start) {
+            gae = 0.0f;
+        } else {
+            gae = g;
+            returns[(long long)t * EN + col] = g + v;
+        }
+        v_next = v;
+        m_next = m_t;
+    }
+}
+
+// rlcore/algo/ppo.py:121-123 statistics.  A = returns[t] - value_preds[t] (float32
+// subtraction as in the reference), accumulated in fp64.  Stage 1: per-workgroup
+// partial sums per agent, fixed order; stage 2: one workgroup folds the partials in a
+// fixed order => bitwise reproducible run to run.
+// partial layout: [block][N][2] = {sum, sum_sq_dev}
+template <int PASS>
+__global__ __launch_bounds__(256) void fa_adv_partial_kernel(const float *__restrict__ returns,
+                                                             const float *__restrict__ value_preds,
+                                                             const double *__restrict__ mean, long long rows,
+                                                             int N, double *__restrict__ partial) {
+    __shared__ double red[4][FA_MAX_AGENTS_DEV];
+    double acc[FA_MAX_AGENTS_DEV];
+#pragma unroll
+    for (int i = 0; i < FA_MAX_AGENTS_DEV; ++i) acc[i] = 0.0;
+    double mu[FA_MAX_AGENTS_DEV];
+#pragma unroll
+    for (int i = 0; i < FA_MAX_AGENTS_DEV; ++i) mu[i] = (PASS == 1 && i < N) ? mean[i] : 0.0;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += stride) {
+        const float *ret = returns + r * N, *vp = value_preds + r * N;
+#pragma unroll
+        for (int i = 0; i < FA_MAX_AGENTS_DEV; ++i) {
+            if (i < N) {
+                const double adv = (double)(ret[i] - vp[i]);
+                if (PASS == 0) acc[i] += adv;
+                else { const double d = adv - mu[i]; acc[i] += d * d; }
+            }
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < FA_MAX_AGENTS_DEV; ++i) {
+        double v = acc[i];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if (lane == 0) red[wave][i] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < N) {
+        const int i = threadIdx.x;
+        partial[((long long)blockIdx.x * N + i)] = ((red[0][i] + red[1][i]) + red[2][i]) + red[3][i];
+    }
+}
+
+// stats[i] = {n, sum, ssd}: PASS 0 fills n and sum (ssd = 0), PASS 1 fills ssd.
+template <int PASS>
+__global__ void fa_adv_final_kernel(const double *__restrict__ partial, int nblocks, int N, double n_rows,
+                                    double *__restrict__ stats) {
+    const int i = threadIdx.x;
+    if (i >= N) return;
+    double s = 0.0;
+    for (int b = 0; b < nblocks; ++b) s += partial[(long long)b * N + i];
+    if (PASS == 0) { stats[i * 3 + 0] = n_rows; stats[i * 3 + 1] = s; stats[i * 3 + 2] = 0.0; }
+    else stats[i * 3 + 2] = s;
+}
+
+// ppo.py:123: (A - mean) / (std + 1e-5), float32 arithmetic with float32 mean/std.
+__global__ __launch_bounds__(256) void fa_adv_norm_kernel(const float *__restrict__ returns,
+                                                          const float *__restrict__ value_preds,
+                                                          const double *__restrict__ mean,
+                                                          const double *__restrict__ std_, long long total,
+                                                          int N, float *__restrict__ out) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x; k < total; k += stride) {
+        const int i = (int)(k % N);
+        const float adv = returns[k] - value_preds[k];
+        out[k] = (adv - (float)mean[i]) / ((float)std_[i] + 1e-5f);
+    }
+}
+
+hipError_t fa_launch_gae(const float *rewards, const float *value_preds, const float *masks, float *returns,
+                         const uint8_t *done, int T, int E, int N, double gamma, double tau, hipStream_t st) {
+    const long long EN = (long long)E * N;
+    const int grid = (int)((EN + 255) / 256);
+    hipLaunchKernelGGL(fa_gae_kernel, dim3(grid), dim3(256), 0, st, rewards, value_preds, masks, returns,
+                       done, T, E, N, (float)gamma, (float)(gamma * tau));
+    return hipGetLastError();
+}
+
+hipError_t fa_launch_adv_stats(int pass, const float *returns, const float *value_preds, const double *mean,
+                               long long rows, int N, double *partial, int nblocks, double *stats,
+                               hipStream_t st) {
+    if (pass == 0) {
+        hipLaunchKernelGGL(fa_adv_partial_kernel<0>, dim3(nblocks), dim3(256), 0, st, returns, value_preds,
+                           mean, rows, N, partial);
+        hipLaunchKernelGGL(fa_adv_final_kernel<0>, dim3(1), dim3(64), 0, st, partial, nblocks, N,
+                           (double)rows, stats);
+    } else {
+        hipLaunchKernelGGL(fa_adv_partial_kernel<1>, dim3(nblocks), dim3(256), 0, st, returns, value_preds,
+                           mean, rows, N, partial);
+        hipLaunchKernelGGL(fa_adv_final_kernel<1>, dim3(1), dim3(64), 0, st, partial, nblocks, N,
+                           (double)rows, stats);
+    }
+    return hipGetLastError();
+}
+
+hipError_t fa_launch_adv_norm(const float *returns, const float *value_preds, const double *mean,
+                              const double *std_, long long total, int N, float *out, hipStream_t st) {
+    long long want = (total + 255) / 256;
+    const int grid = (int)(want < 2048 ? (want < 1 ? 1 : want) : 2048);
+    hipLaunchKernelGGL(fa_adv_norm_kernel, dim3(grid), dim3(256), 0, st, returns, value_preds, mean, std_,
+                       total, N, out);
+    return hipGetLastError();
+}

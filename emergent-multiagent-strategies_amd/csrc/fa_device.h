@@ -1,0 +1,58 @@
+// fa_device.h -- shared device-side declarations of the FortAttack HIP engine (gfx950).
+//
+// Data layout in HBM (E envs, N agents/env, guards first):
+//   world state   fp64 SoA, env-major: field[e*N + i].  A wave64 carries EPW = 64/N whole
+//                 envs (10 at N=6, 6 at N=10), lane = agent, so every field access of a
+//                 wave is one contiguous span of EPW*N elements.
+//   RNG state     MT19937 words, env-major mt[e*624 + k] + a cursor per env.
+//   rollout rows  (E, N, ...) float32 rows of the caller's joint RolloutStorage tensors.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define FA_WAVE 64
+#define FA_MT_N 624
+#define FA_MT_M 397
+#define FA_MAX_AGENTS_DEV 16
+
+// Host-derived constants (evaluated once in double, in the reference's expression order).
+struct FaDerived {
+    double agent_size, accel, max_speed, fort_dim, door_x, door_y, dt, one_minus_damping;
+    double contact_force, contact_margin, dist_min;
+    double wall_xmin, wall_xmax, wall_ymin, wall_ymax;
+    double shoot_rad, half_win;
+    double rot_pos, rot_neg;        // (+max_rot) % 2pi, (-max_rot) % 2pi  (Python modulo, core.py:336)
+    double ang_guard, ang_attacker; // 3pi/2, pi/2                         (fortattack_env_v1.py:59)
+    double att_x_lo, att_x_rng, att_y_lo, att_y_rng; // fortattack_env_v1.py:66
+    double grd_x_lo, grd_x_rng, grd_y_lo, grd_y_rng; // fortattack_env_v1.py:70
+    double contact_skip_d2;         // squared distance beyond which the soft contact is exactly 0
+    double wall_skip;               // wall clearance beyond which the soft contact is exactly 0
+};
+
+struct FaState {
+    double *px, *py, *vx, *vy, *ang, *prev; // (E,N)
+    uint8_t *alive;                          // (E,N)
+    int32_t *tstep;                          // (E)
+    int32_t *num_hit, *num_was_hit;          // (E,N) or null when counters are off
+    uint8_t *game_result;                    // (E,3)
+    uint32_t *result_count;                  // (E,3)
+    uint32_t *mt;                            // (E,624)
+    int32_t *mt_pos;                         // (E)
+    uint32_t *reset_count;                   // (E)   Philox counter
+};
+
+struct FaStepArgs {
+    FaState s;
+    const int64_t *actions;
+    int64_t as_t, as_e, as_i; // element strides: rollout step, env, agent
+    float *obs32, *rew32, *mask32;
+    uint8_t *done;
+    double *obs64, *rew64;
+    uint8_t *hit, *was_hit;
+    const uint8_t *reset_mask; // fa_reset only
+    int32_t E, G, A, max_t;
+    int32_t auto_reset, rng_mode, track_counters, nsteps; // nsteps: env-steps per launch
+    uint64_t seed;
+    int64_t env_offset;
+    FaDerived c;
+};

@@ -1,0 +1,435 @@
+// fa_step.hip -- the FortAttack env.step / reset kernels for CDNA4 (gfx950).
+//
+// One launch advances every env of the handle by one step.  Mapping: lane = agent, a
+// wave64 = EPW = 64/N whole envs, one wave per workgroup (E=4096, N=6 -> 410 workgroups
+// over 256 CUs: the launch is latency bound, so the work is spread as thin as possible).
+// Cross-agent data moves two ways, both inside the wave (no workgroup barrier):
+//   * positions and laser triangles are staged in LDS and read back with per-lane
+//     addresses (broadcast reads inside an env);
+//   * every flag reduction (who shoots, who is alive, who was hit by whom, attackers in
+//     the fort) is a 64-bit wave ballot shifted to the env's lane group + popcount.
+// Float semantics: every fp64 operation is written in the order the reference evaluates
+// it (file:line cited per block); built with -ffp-contract=off so nothing is fused.
+// The exact shortcuts (skipping a contact whose soft penalty is exactly 0.0) are argued
+// where they are taken.
+#include "fa_device.h"
+
+// ---- numpy legacy RandomState (MT19937), incremental form --------------------------
+// Matsumoto-Nishimura genrand regenerates all 624 words at once; word k of the new block
+// depends only on old[k], old[k+1] and (k+397)%624 (old for k<227, new otherwise), so
+// drawing word `pos` = twist it in place, temper, advance.  Identical stream, O(1) work
+// per draw, no 624-word stall inside a step.
+__device__ __forceinline__ uint32_t mt_twist(uint32_t cur, uint32_t nxt, uint32_t far_) {
+    uint32_t y = (cur & 0x80000000u) | (nxt & 0x7fffffffu);
+    return far_ ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+}
+__device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
+    y ^= (y >> 11);
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= (y >> 18);
+    return y;
+}
+__device__ __forceinline__ int mt_wrap(int k) { return k >= FA_MT_N ? k - FA_MT_N : k; }
+
+// genrand_res53 (numpy mt19937_next_double)
+__device__ __forceinline__ double res53(uint32_t w0, uint32_t w1) {
+    uint32_t a = w0 >> 5, b = w1 >> 6;
+    return (a * 67108864.0 + b) / 9007199254740992.0;
+}
+
+// Philox4x32-10 (Salmon et al. 2011), perf-mode reset stream.
+__device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint32_t hi0 = __umulhi(0xD2511F53u, c[0]), lo0 = 0xD2511F53u * c[0];
+        uint32_t hi1 = __umulhi(0xCD9E8D57u, c[2]), lo1 = 0xCD9E8D57u * c[2];
+        uint32_t n0 = hi1 ^ c[1] ^ k0, n2 = hi0 ^ c[3] ^ k1;
+        c[0] = n0; c[1] = lo1; c[2] = n2; c[3] = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+
+// fortattack_env_v1.py:47-75 reset_world, for the lane's agent.  Agent i consumes the
+// 2 doubles (4 words) number 2i, 2i+1 of this reset.  All lanes of the env call together.
+__device__ __forceinline__ void reset_agent(const FaStepArgs &a, int e, int i, int N, bool is_att,
+                                            bool active, double &px, double &py) {
+    uint32_t w[4] = {0, 0, 0, 0};
+    if (active) {
+        if (a.rng_mode == 0) {
+            uint32_t *mt = a.s.mt + (size_t)e * FA_MT_N;
+            const int base = a.s.mt_pos[e] + 4 * i; // < 624 + 64
+            uint32_t cur[5], far_[4];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) cur[k] = mt[mt_wrap(base + k)];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) far_[k] = mt[mt_wrap(mt_wrap(base + k) + FA_MT_M)];
+            // every load above is complete (data dependence) before any lane stores below
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                uint32_t nw = mt_twist(cur[k], cur[k + 1], far_[k]);
+                mt[mt_wrap(base + k)] = nw;
+                w[k] = mt_temper(nw);
+            }
+        } else {
+            const uint64_t genv = (uint64_t)(a.env_offset + e);
+            uint32_t c[4] = {(uint32_t)genv, (uint32_t)(genv >> 32), a.s.reset_count[e], (uint32_t)i};
+            philox4x32_10(c, (uint32_t)a.seed, (uint32_t)(a.seed >> 32));
+            w[0] = c[0]; w[1] = c[1]; w[2] = c[2]; w[3] = c[3];
+        }
+    }
+    const double u1 = res53(w[0], w[1]), u2 = res53(w[2], w[3]);
+    if (is_att) { // :66
+        px = a.c.att_x_lo + a.c.att_x_rng * u1;
+        py = a.c.att_y_lo + a.c.att_y_rng * u2;
+    } else {      // :70
+        px = a.c.grd_x_lo + a.c.grd_x_rng * u1;
+        py = a.c.grd_y_lo + a.c.grd_y_rng * u2;
+    }
+}
+
+// after every lane of the env has drawn: advance the env's cursor (one lane per env)
+__device__ __forceinline__ void reset_advance(const FaStepArgs &a, int e, int N) {
+    if (a.rng_mode == 0) a.s.mt_pos[e] = mt_wrap(a.s.mt_pos[e] + 4 * N);
+    else a.s.reset_count[e] += 1u;
+}
+
+// np.logaddexp(0, t) * k, numpy npy_logaddexp with x = 0 (core.py:452, :469).
+//   t >= 40  : t + log1p(exp(-t)) == t exactly (exp(-t) <= 4.3e-18 < ulp(40)/2)
+//   t < -746 : exp underflows to +0, log1p(0) = 0
+// only the band in between needs libm.
+__device__ __forceinline__ double softplus_pen(double t, double k) {
+    double v;
+    if (t >= 40.0) v = t;
+    else if (t < -746.0) v = 0.0;
+    else if (t == 0.0) v = 0.0 + 0.693147180559945309417232121458176568;
+    else if (t < 0.0) v = 0.0 + log1p(exp(t));
+    else v = t + log1p(exp(-t));
+    return v * k;
+}
+
+// core.py:384-390 laser_hit: lam = A^-1 (px,py,1), hit iff all lam >= 0 (Cramer's rule;
+// the reference's SVD pseudo-inverse is the exact inverse of this never-singular matrix).
+__device__ __forceinline__ bool laser_hit(double x1, double y1, double x2, double y2, double x3,
+                                          double y3, double px, double py) {
+    double w1 = (x2 - px) * (y3 - py) - (x3 - px) * (y2 - py);
+    double w2 = (x3 - px) * (y1 - py) - (x1 - px) * (y3 - py);
+    double w3 = (x1 - px) * (y2 - py) - (x2 - px) * (y1 - py);
+    double det = (w1 + w2) + w3;
+    if (det > 0) return w1 >= 0 && w2 >= 0 && w3 >= 0;
+    if (det < 0) return w1 <= 0 && w2 <= 0 && w3 <= 0;
+    return false;
+}
+
+template <int TG, int TA, bool RESET_ONLY>
+__global__ __launch_bounds__(FA_WAVE) void fa_step_kernel(FaStepArgs a) {
+    const int G = TG ? TG : a.G, A = TA ? TA : a.A;
+    const int N = G + A;
+    const int EPW = FA_WAVE / N;          // envs per wave
+    const int lane = threadIdx.x;         // one wave per workgroup
+    const int slot = lane / N;            // env slot inside the wave
+    const int i = lane - slot * N;        // agent index
+    const int gbase = slot * N;           // first lane of this env's group
+    const int e = blockIdx.x * EPW + slot;
+    const bool valid = (slot < EPW) && (e < a.E);
+    const bool is_att = i >= G;
+    const size_t idx = (size_t)e * N + i;
+    const size_t EN = (size_t)a.E * N;
+    const unsigned long long grp_mask = (1ull << N) - 1ull;
+    const FaDerived &c = a.c;
+
+    __shared__ double s_px[FA_WAVE], s_py[FA_WAVE], s_tri[6][FA_WAVE];
+
+    // ---- load state once per launch (coalesced: lane-contiguous) --------------------
+    double px = 0, py = 0, vx = 0, vy = 0, ang = 0, prev = 0;
+    bool alive = false;
+    int t = 0, nh = 0, nwh = 0;
+    if (valid) {
+        px = a.s.px[idx]; py = a.s.py[idx]; vx = a.s.vx[idx]; vy = a.s.vy[idx];
+        ang = a.s.ang[idx]; prev = a.s.prev[idx];
+        alive = a.s.alive[idx] != 0;
+        t = a.s.tstep[e];
+        if (a.track_counters) { nh = a.s.num_hit[idx]; nwh = a.s.num_was_hit[idx]; }
+    }
+    bool dirty = false; // state changed => write it back
+
+    const int nsteps = RESET_ONLY ? 1 : a.nsteps;
+    for (int s = 0; s < nsteps; ++s) {
+        bool do_reset;
+        if (RESET_ONLY) {
+            do_reset = valid && (a.reset_mask == nullptr || a.reset_mask[e] != 0);
+        } else {
+            const bool alive0 = alive;
+            // ---- fortattack.py:253-263,:289 _set_action (all agents, dead ones too) ----
+            const int act = valid ? (int)a.actions[(int64_t)s * a.as_t + (int64_t)e * a.as_e + (int64_t)i * a.as_i] : 0;
+            double u0 = 0.0, u1 = 0.0, rot = 0.0;
+            if (act == 1) u0 = +1.0;
+            if (act == 2) u0 = -1.0;
+            if (act == 3) u1 = +1.0;
+            if (act == 4) u1 = -1.0;
+            if (act == 5) rot = c.rot_pos;
+            if (act == 6) rot = c.rot_neg;
+            const bool shoot = act == 7;
+            u0 *= c.accel;
+            u1 *= c.accel;
+
+            // ---- stage positions + laser triangles in LDS (core.py:373-382) ------------
+            s_px[lane] = px;
+            s_py[lane] = py;
+            const bool shooter = valid && alive0 && shoot;
+            if (shooter) {
+                double sn, cs;
+                sincos(ang, &sn, &cs);
+                const double x1 = px + c.agent_size * cs, y1 = py + c.agent_size * sn;
+                sincos(ang + c.half_win, &sn, &cs);
+                const double x2 = x1 + c.shoot_rad * cs, y2 = y1 + c.shoot_rad * sn;
+                sincos(ang - c.half_win, &sn, &cs);
+                const double x3 = x1 + c.shoot_rad * cs, y3 = y1 + c.shoot_rad * sn;
+                s_tri[0][lane] = x1; s_tri[1][lane] = y1; s_tri[2][lane] = x2;
+                s_tri[3][lane] = y2; s_tri[4][lane] = x3; s_tri[5][lane] = y3;
+            }
+            const unsigned long long shooters_b = __ballot(shooter);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+            // ---- core.py:254-302 apply_laser_effect ------------------------------------
+            // iteration k: every lane tests the triangle of its k-th opponent; the ballot
+            // of the results gives shooter k of either team its hit list.
+            bool was_hit = false;
+            int hit_cnt = 0, was_hit_cnt = 0;
+            if (shooters_b != 0ull) {
+                const int n_opp = is_att ? G : A, opp0 = is_att ? 0 : G;
+                const int team_idx = is_att ? i - G : i;
+                const unsigned long long opp_mask =
+                    is_att ? ((1ull << G) - 1ull) : (((1ull << A) - 1ull) << G);
+                const int KMAX = G > A ? G : A;
+                for (int k = 0; k < KMAX; ++k) {
+                    const int j = gbase + opp0 + k;
+                    bool h = false;
+                    if (valid && alive0 && k < n_opp && ((shooters_b >> j) & 1ull))
+                        h = laser_hit(s_tri[0][j], s_tri[1][j], s_tri[2][j], s_tri[3][j], s_tri[4][j],
+                                      s_tri[5][j], px, py);
+                    const unsigned long long hb = __ballot(h);
+                    if (k == team_idx) hit_cnt = __popcll((hb >> gbase) & opp_mask);
+                    was_hit = was_hit || h;
+                    was_hit_cnt += h ? 1 : 0;
+                }
+            }
+            const bool hit = shooter && hit_cnt > 0;
+            const bool alive1 = alive0 && !was_hit;       // :293-302 one shot kills
+            const bool just_died = alive0 && was_hit;
+            const unsigned long long grp_alive1 = (__ballot(valid && alive1) >> gbase) & grp_mask;
+            const int n_alive_att = __popcll(grp_alive1 >> G);
+
+            // ---- forces + integration for agents alive after the laser ----------------
+            if (valid && alive1) {
+                double Fx = u0 + 0.0, Fy = u1 + 0.0;      // core.py:221-228
+                // core.py:231-243 + :440-456.  Reference order: pairs (a,b), a<b, lexicographic;
+                // for agent i that is partner j ascending, with f_i = +f for j>i and
+                // -(f(j,i)) for j<i, which is bitwise the same number as f computed from
+                // i's side (negation commutes exactly with *, / and the sqrt argument).
+                for (int j = 0; j < N; ++j) {
+                    if (j == i || !((grp_alive1 >> j) & 1ull)) continue;
+                    const double dx = px - s_px[gbase + j], dy = py - s_py[gbase + j];
+                    const double d2 = dx * dx + dy * dy;
+                    // exact skip: farther than dist_min + 1000*margin => t < -1000 =>
+                    // exp(t) == +0 => penetration == +0.0 => force == +-0.0, and F (never
+                    // -0.0) is unchanged by adding it.
+                    if (d2 > c.contact_skip_d2) continue;
+                    const double dist = sqrt(d2);
+                    const double pen = softplus_pen(-(dist - c.dist_min) / c.contact_margin, c.contact_margin);
+                    Fx = c.contact_force * dx / dist * pen + Fx;
+                    Fy = c.contact_force * dy / dist * pen + Fy;
+                }
+                // core.py:246-252 + :459-472 walls
+                {
+                    const double k = c.contact_margin, size = c.agent_size;
+                    const double d0 = px - size - c.wall_xmin, d1 = c.wall_xmax - px - size;
+                    const double d2 = py - size - c.wall_ymin, d3 = c.wall_ymax - py - size;
+                    // exact skip: all four clearances > 1000*margin => all penalties +0.0
+                    if (!(d0 > c.wall_skip && d1 > c.wall_skip && d2 > c.wall_skip && d3 > c.wall_skip)) {
+                        const double fx1 = c.contact_force * softplus_pen(-d0 / k, k);
+                        const double fx2 = c.contact_force * softplus_pen(-d1 / k, k);
+                        const double fy1 = c.contact_force * softplus_pen(-d2 / k, k);
+                        const double fy2 = c.contact_force * softplus_pen(-d3 / k, k);
+                        Fx = (fx1 - fx2) + Fx;
+                        Fy = (fy1 - fy2) + Fy;
+                    }
+                }
+                // core.py:324-338 integrate_state (mass == 1.0: F/1.0 is exact)
+                vx = vx * c.one_minus_damping;
+                vy = vy * c.one_minus_damping;
+                vx += Fx * c.dt;
+                vy += Fy * c.dt;
+                const double speed = sqrt(vx * vx + vy * vy);
+                if (speed > c.max_speed) {
+                    vx = vx / speed * c.max_speed;
+                    vy = vy / speed * c.max_speed;
+                }
+                ang += rot;
+                px += vx * c.dt;
+                py += vy * c.dt;
+            }
+
+            // ---- rewards (fortattack_env_v1.py:87-188), after World.step ---------------
+            const double ddx = px - c.door_x, ddy = py - c.door_y;
+            const double dist_door = sqrt(ddx * ddx + ddy * ddy);
+            const unsigned long long in_fort_b =
+                __ballot(valid && is_att && alive1 && dist_door < c.fort_dim);
+            const bool any_in_fort = ((in_fort_b >> gbase) & grp_mask) != 0ull;
+            const bool rewarded = valid && (alive1 || just_died);
+            const bool has_prev = !(prev != prev); // NaN encodes prevDist None
+            double rew = 0.0;
+            if (rewarded) {
+                if (is_att) { // :94-128
+                    double r0 = 0, r1 = 0, r2 = 0, r3 = 0, r4 = 0, r5 = 0;
+                    if (has_prev) r0 = 2 * (prev - dist_door);
+                    if (dist_door < c.fort_dim) r1 = 10;
+                    if (shoot) r2 = -1;
+                    if (hit) r3 = +3;
+                    if (was_hit) r4 = -3;
+                    if (n_alive_att == 0) r5 = -10;
+                    rew = r0 + r1 + r2 + r3 + r4 + r5;
+                } else {      // :130-188
+                    double r0 = 0, r3 = 0, r4 = 0, r5 = 0, r6 = 0, r7 = 0;
+                    if (has_prev) {
+                        if (dist_door > 0.3 && prev <= 0.3) r0 = -1;
+                        else if (dist_door <= 0.3 && prev > 0.3) r0 = 1;
+                    }
+                    if (n_alive_att != 0 && any_in_fort) r3 = -10; // min over alive attackers < th
+                    if (shoot) r4 = -0.1;
+                    if (hit) r5 = 3;
+                    if (was_hit) r6 = -3;
+                    if (n_alive_att == 0) r7 = 10;
+                    rew = r0 + 0.0 + 0.0 + r3 + r4 + r5 + r6 + r7 + 0.0;
+                }
+                prev = dist_door;
+            }
+
+            // ---- fortattack.py:202-225 _get_done, :171 time_step += 1 ------------------
+            const bool timeout = t == a.max_t - 1;
+            const bool done = any_in_fort || n_alive_att == 0 || timeout;
+            if (valid && i == 0) {
+                if (done) {
+                    const int which = any_in_fort ? 2 : (n_alive_att == 0 ? 0 : 1);
+                    uint8_t *gr = a.s.game_result + (size_t)e * 3;
+                    gr[0] = which == 0; gr[1] = which == 1; gr[2] = which == 2;
+                    a.s.result_count[(size_t)e * 3 + which] += 1u;
+                }
+                if (a.done) a.done[(size_t)s * a.E + e] = done ? 1 : 0;
+            }
+            t += 1;
+            do_reset = valid && done && a.auto_reset != 0;
+            dirty = dirty || alive0;
+            alive = alive1;
+            nh += hit_cnt;
+            nwh += was_hit_cnt; // one per shooter that hit (core.py:283)
+
+            // step-level outputs (the reset below must not touch them)
+            if (valid) {
+                const size_t o = (size_t)s * EN + idx;
+                if (a.rew32) a.rew32[o] = (float)rew;
+                if (a.rew64) a.rew64[o] = rew;
+                // trainer mask (train_fortattack.py:53,87): alive BEFORE the step; an env that is
+                // reset here gets the post-reset mask 1 (initialize_new_episode, rlagent.py:31)
+                if (a.mask32) a.mask32[o] = (alive0 || do_reset) ? 1.0f : 0.0f;
+                if (a.hit) a.hit[o] = hit ? 1 : 0;
+                if (a.was_hit) a.was_hit[o] = was_hit ? 1 : 0;
+            }
+        }
+
+        // ---- fortattack_env_v1.py:47-75 reset_world --------------------------------------
+        // (prevDist and the action are NOT reset: SURVEY quirk Q1)
+        if (__ballot(do_reset) != 0ull) {
+            double npx = px, npy = py;
+            reset_agent(a, e, i, N, is_att, do_reset, npx, npy);
+            if (do_reset) {
+                px = npx; py = npy; vx = 0.0; vy = 0.0;
+                ang = is_att ? c.ang_attacker : c.ang_guard;
+                alive = true;
+                t = 0;
+                nh = 0; nwh = 0;
+                dirty = true;
+                if (i == 0) {
+                    reset_advance(a, e, N);
+                    if (RESET_ONLY) { uint8_t *gr = a.s.game_result + (size_t)e * 3; gr[0] = gr[1] = gr[2] = 0; }
+                }
+            }
+        }
+
+        // ---- observation row (fortattack_env_v1.py:238) ------------------------------------
+        if (valid && (!RESET_ONLY || do_reset)) {
+            const double al = alive ? 1.0 : 0.0;
+            const size_t o6 = ((size_t)s * EN + idx) * 6;
+            if (a.obs32) {
+                float2 *o = reinterpret_cast<float2 *>(a.obs32 + o6);
+                o[0] = make_float2((float)al, (float)px);
+                o[1] = make_float2((float)py, (float)ang);
+                o[2] = make_float2((float)vx, (float)vy);
+            }
+            if (a.obs64) {
+                double2 *o = reinterpret_cast<double2 *>(a.obs64 + o6);
+                o[0] = make_double2(al, px);
+                o[1] = make_double2(py, ang);
+                o[2] = make_double2(vx, vy);
+            }
+        }
+        // next iteration restages LDS: keep its writes behind this iteration's reads
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+
+    // ---- write back state once per launch ----------------------------------------------------
+    if (valid && dirty) {
+        a.s.px[idx] = px; a.s.py[idx] = py; a.s.vx[idx] = vx; a.s.vy[idx] = vy;
+        a.s.ang[idx] = ang; a.s.prev[idx] = prev;
+        a.s.alive[idx] = alive ? 1 : 0;
+        if (a.track_counters) { a.s.num_hit[idx] = nh; a.s.num_was_hit[idx] = nwh; }
+    }
+    if (valid && i == 0 && (!RESET_ONLY || dirty)) a.s.tstep[e] = t;
+}
+
+// ---- np.random.seed(int): init_genrand, then discard the construction draws ----------
+__global__ void fa_seed_kernel(FaState s, int E, uint64_t base_seed, int64_t env_offset, int skip_words) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    uint32_t *mt = s.mt + (size_t)e * FA_MT_N;
+    uint32_t x = (uint32_t)(base_seed + (uint64_t)(env_offset + e));
+    mt[0] = x;
+    for (int k = 1; k < FA_MT_N; ++k) {
+        x = 1812433253u * (x ^ (x >> 30)) + (uint32_t)k;
+        mt[k] = x;
+    }
+    int pos = 0;
+    for (int w = 0; w < skip_words; ++w) {
+        mt[pos] = mt_twist(mt[pos], mt[mt_wrap(pos + 1)], mt[mt_wrap(pos + FA_MT_M)]);
+        pos = mt_wrap(pos + 1);
+    }
+    s.mt_pos[e] = pos;
+    s.reset_count[e] = 0u;
+}
+
+// ---- launchers --------------------------------------------------------------------------
+template <bool RESET_ONLY>
+static hipError_t launch_step_t(const FaStepArgs &a, hipStream_t st) {
+    const int N = a.G + a.A;
+    const int epw = FA_WAVE / N;
+    const int grid = (a.E + epw - 1) / epw;
+    if (a.G == 3 && a.A == 3)
+        hipLaunchKernelGGL((fa_step_kernel<3, 3, RESET_ONLY>), dim3(grid), dim3(FA_WAVE), 0, st, a);
+    else if (a.G == 5 && a.A == 5)
+        hipLaunchKernelGGL((fa_step_kernel<5, 5, RESET_ONLY>), dim3(grid), dim3(FA_WAVE), 0, st, a);
+    else
+        hipLaunchKernelGGL((fa_step_kernel<0, 0, RESET_ONLY>), dim3(grid), dim3(FA_WAVE), 0, st, a);
+    return hipGetLastError();
+}
+
+hipError_t fa_launch_step(const FaStepArgs &a, hipStream_t st) { return launch_step_t<false>(a, st); }
+hipError_t fa_launch_reset(const FaStepArgs &a, hipStream_t st) { return launch_step_t<true>(a, st); }
+hipError_t fa_launch_seed(const FaState &s, int E, uint64_t base_seed, int64_t env_offset,
+                          int skip_words, hipStream_t st) {
+    hipLaunchKernelGGL(fa_seed_kernel, dim3((E + 255) / 256), dim3(256), 0, st, s, E, base_seed,
+                       env_offset, skip_words);
+    return hipGetLastError();
+}

@@ -1,0 +1,46 @@
+"""Multi-GPU layer: env shards + the one exchange the hot path has.
+
+Envs are independent, so rank r simply owns envs [r*E, (r+1)*E) (``env_offset`` of
+BatchedFortAttack) and nothing is exchanged during a rollout.  The only cross-rank
+quantity is the per-agent advantage mean / unbiased std of JointPPO.update
+(rlcore/algo/ppo.py:121-123), which the reference computes over one process's T*P samples
+and which must now cover every rank's samples: a two-pass reduction, each pass one
+all-reduce (RCCL over xGMI, backend "nccl") of N x 3 resp. N doubles -- latency bound,
+144 B at 3v3.  Two passes (mean first, then squared deviations) keep the result equal to
+the single-process two-pass value to fp64 rounding.
+"""
+import torch
+import torch.distributed as dist
+
+
+def _all_reduce_sum_(t, group=None):
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t
+
+
+def two_pass_mean_std(pass0, pass1, group=None):
+    """pass0() -> (N,3) float64 {n, sum, *}; pass1(mean (N,)) -> (N,) float64 sum of squared
+    deviations from `mean`.  Returns global (mean, unbiased std, n), all (N,) float64, on
+    the tensors' device; no host synchronisation."""
+    s0 = _all_reduce_sum_(pass0().clone(), group)
+    n = s0[:, 0]
+    mean = (s0[:, 1] / n).contiguous()
+    ssd = _all_reduce_sum_(pass1(mean).contiguous().clone(), group)
+    std = torch.sqrt(ssd / (n - 1)).contiguous()
+    return mean, std, n
+
+
+def adv_mean_std(eng, group=None):
+    """Global per-agent advantage mean / std for the storage bound to `eng` (fa_adv_stats)."""
+    mean, std, _ = two_pass_mean_std(lambda: eng.adv_stats(0),
+                                     lambda m: eng.adv_stats(1, mean=m)[:, 2], group)
+    return mean, std
+
+
+def shard_range(num_envs_total, rank, world):
+    """Env index range of `rank` when `num_envs_total` envs are split evenly."""
+    if num_envs_total % world:
+        raise ValueError("num_envs_total must be divisible by the world size")
+    per = num_envs_total // world
+    return rank * per, per

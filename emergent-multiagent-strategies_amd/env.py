@@ -1,0 +1,332 @@
+"""FortAttack on the MI355X: batched engine + the reference's single-env surface.
+
+* ``BatchedFortAttack``  -- E independent worlds resident in HBM, one HIP launch per
+  env-step, torch tensors in/out (device pointers go straight to the C ABI).
+* ``FortAttackGlobalEnv`` / ``make_fortattack_env`` -- the reference's Python boundary
+  (gym_fortattack/fortattack.py:17-27, :31-225) over the same engine with E = 1, so a
+  copy of train_fortattack.py's loop runs unchanged.
+
+Everything here calls the HIP library; there is no CPU path.
+"""
+import ctypes as C
+import types
+
+import numpy as np
+import torch
+
+from . import _lib
+from .spaces import Box, Discrete, MASpace
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class BatchedFortAttack(object):
+    """E FortAttack worlds on one GPU (fa_env handle of include/fortattack.h).
+
+    Env e reproduces the reference run under ``np.random.seed(base_seed + env_offset + e)``
+    (``rng="mt19937"``); ``skip_doubles`` = random_sample() draws the reference consumed
+    before its first ``env.reset()`` (default 2N: FortAttackEnvV1.__init__ calls
+    reset_world once, fortattack_env_v1.py:45).
+    """
+
+    def __init__(self, num_envs, num_guards=3, num_attackers=3, max_time_steps=100, base_seed=0,
+                 env_offset=0, skip_doubles=None, rng="mt19937", device=0, track_counters=True):
+        lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise _lib.FaError("BatchedFortAttack needs a ROCm GPU (torch.cuda.is_available() is False)")
+        self.device = torch.device("cuda", device if isinstance(device, int) else torch.device(device).index or 0)
+        cfg = _lib.default_config()
+        cfg.num_envs, cfg.num_guards, cfg.num_attackers = int(num_envs), int(num_guards), int(num_attackers)
+        cfg.max_time_steps = int(max_time_steps)
+        cfg.device_id = self.device.index
+        cfg.rng_mode = {"mt19937": _lib.FA_RNG_MT19937, "philox": _lib.FA_RNG_PHILOX}[rng]
+        cfg.base_seed, cfg.env_offset = int(base_seed), int(env_offset)
+        cfg.rng_skip_doubles = -1 if skip_doubles is None else int(skip_doubles)
+        cfg.track_counters = int(bool(track_counters))
+        self.cfg = cfg
+        self.E, self.G, self.A = cfg.num_envs, cfg.num_guards, cfg.num_attackers
+        self.N = self.G + self.A
+        self.max_time_steps = cfg.max_time_steps
+        h = C.c_void_p()
+        _lib.check(lib.fa_create(C.byref(cfg), C.byref(h)), "fa_create")
+        self._h, self._lib = h, lib
+        self.storage = None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.fa_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- env API -------------------------------------------------------------------
+    def _new(self, shape, dtype):
+        return torch.empty(shape, dtype=dtype, device=self.device)
+
+    def reset(self, env_mask=None, obs_f32=None, obs_f64=None):
+        """fa_reset.  env_mask: uint8/bool (E) device tensor or None (all envs)."""
+        if env_mask is not None:
+            env_mask = env_mask.to(self.device, torch.uint8).contiguous()
+        if obs_f32 is None and obs_f64 is None:
+            obs_f32 = self._new((self.E, self.N, 6), torch.float32)
+        _lib.check(self._lib.fa_reset(self._h, _ptr(env_mask), _ptr(obs_f32), _ptr(obs_f64), _stream()),
+                   "fa_reset")
+        return obs_f32 if obs_f32 is not None else obs_f64
+
+    def step(self, actions, auto_reset=True, out=None, want=("obs_f32", "reward_f32", "mask_f32", "done")):
+        """fa_step.  actions: int64 device tensor (E, N) (any strides).  Returns dict."""
+        assert actions.dtype == torch.int64 and actions.is_cuda and tuple(actions.shape) == (self.E, self.N)
+        shapes = dict(obs_f32=((self.E, self.N, 6), torch.float32), reward_f32=((self.E, self.N), torch.float32),
+                      mask_f32=((self.E, self.N), torch.float32), done=((self.E,), torch.uint8),
+                      obs_f64=((self.E, self.N, 6), torch.float64), reward_f64=((self.E, self.N), torch.float64),
+                      hit=((self.E, self.N), torch.uint8), was_hit=((self.E, self.N), torch.uint8))
+        out = dict(out or {})
+        for k in want:
+            if k not in out:
+                out[k] = self._new(*shapes[k])
+        io = _lib.StepIO()
+        io.actions = _ptr(actions)
+        io.act_stride_env, io.act_stride_agent = actions.stride(0), actions.stride(1)
+        for k in shapes:
+            t = out.get(k)
+            if t is not None:
+                assert t.is_contiguous() and t.dtype == shapes[k][1] and tuple(t.shape) == shapes[k][0], k
+            setattr(io, k, _ptr(t))
+        io.auto_reset = int(bool(auto_reset))
+        _lib.check(self._lib.fa_step(self._h, C.byref(io), _stream()), "fa_step")
+        return out
+
+    # -- collector -------------------------------------------------------------------
+    def bind_storage(self, storage):
+        """Attach a JointRolloutStorage (storage.py) -- fa_bind_storage."""
+        st = _lib.Storage()
+        st.num_steps = storage.num_steps
+        for k in ("obs", "recurrent_hidden_states", "rewards", "value_preds", "returns",
+                  "action_log_probs", "actions", "masks", "done"):
+            t = getattr(storage, k)
+            assert t.is_contiguous() and t.device == self.device, k
+            setattr(st, k, _ptr(t))
+        _lib.check(self._lib.fa_bind_storage(self._h, C.byref(st)), "fa_bind_storage")
+        self.storage = storage
+
+    def collect_reset(self):
+        _lib.check(self._lib.fa_collect_reset(self._h, _stream()), "fa_collect_reset")
+
+    def collect_step(self, step, auto_reset=True):
+        _lib.check(self._lib.fa_collect_step(self._h, int(step), int(bool(auto_reset)), _stream()),
+                   "fa_collect_step")
+
+    def collect_rollout(self, step_begin, num_steps, auto_reset=True):
+        """Open-loop rollout of `num_steps` env-steps in ONE launch (actions already in storage)."""
+        _lib.check(self._lib.fa_collect_rollout(self._h, int(step_begin), int(num_steps),
+                                                int(bool(auto_reset)), _stream()), "fa_collect_rollout")
+
+    def gae(self, gamma=0.99, tau=0.95):
+        _lib.check(self._lib.fa_gae(self._h, float(gamma), float(tau), _stream()), "fa_gae")
+
+    def adv_stats(self, pass_, mean=None, out=None):
+        """fa_adv_stats.  pass 0 fills out[i] = {n, sum(A), 0}; pass 1 (needs `mean`) writes only
+        out[i][2] = sum((A-mean)^2) -- hand it pass 0's buffer to get the full triple."""
+        if out is None:
+            out = torch.zeros((self.N, 3), dtype=torch.float64, device=self.device)
+        _lib.check(self._lib.fa_adv_stats(self._h, int(pass_), _ptr(mean), _ptr(out), _stream()), "fa_adv_stats")
+        return out
+
+    def adv_normalize(self, mean, std, out=None):
+        if out is None:
+            out = self._new((self.storage.num_steps, self.E, self.N, 1), torch.float32)
+        _lib.check(self._lib.fa_adv_normalize(self._h, _ptr(mean), _ptr(std), _ptr(out), _stream()),
+                   "fa_adv_normalize")
+        return out
+
+    def after_update(self):
+        _lib.check(self._lib.fa_after_update(self._h, _stream()), "fa_after_update")
+
+    # -- state snapshot ----------------------------------------------------------------
+    _F64 = ("pos_x", "pos_y", "vel_x", "vel_y", "ang", "prev_dist")
+
+    def get_state(self):
+        E, N = self.E, self.N
+        s = {k: np.empty((E, N), np.float64) for k in self._F64}
+        s.update(alive=np.empty((E, N), np.uint8), time_step=np.empty(E, np.int32),
+                 num_hit=np.empty((E, N), np.int32), num_was_hit=np.empty((E, N), np.int32),
+                 game_result=np.empty((E, 3), np.uint8), result_count=np.empty((E, 3), np.int64))
+        sh = _lib.StateHost()
+        for k, v in s.items():
+            setattr(sh, k, v.ctypes.data_as(C.c_void_p))
+        _lib.check(self._lib.fa_get_state(self._h, C.byref(sh)), "fa_get_state")
+        return s
+
+    def set_state(self, s):
+        keep = []
+        sh = _lib.StateHost()
+        for k in self._F64 + ("alive", "time_step"):
+            if k in s:
+                dt = np.float64 if k in self._F64 else (np.uint8 if k == "alive" else np.int32)
+                a = np.ascontiguousarray(s[k], dt)
+                assert a.shape == ((self.E,) if k == "time_step" else (self.E, self.N)), k
+                keep.append(a)
+                setattr(sh, k, a.ctypes.data_as(C.c_void_p))
+        _lib.check(self._lib.fa_set_state(self._h, C.byref(sh)), "fa_set_state")
+
+    def rng_peek(self, e, count):
+        out = np.empty(count, np.float64)
+        _lib.check(self._lib.fa_rng_peek(self._h, int(e), int(count), out.ctypes.data_as(C.c_void_p)),
+                   "fa_rng_peek")
+        return out
+
+
+# =====================================================================================
+# The reference's single-env surface
+# =====================================================================================
+class _AgentView(object):
+    """Read-only stand-in for gym_fortattack.core.Agent as seen through env.world."""
+
+    def __init__(self, env, i, attacker):
+        self._env, self._i, self.attacker = env, i, attacker
+        self.name = "agent %d" % (i + 1)  # fortattack_env_v1.py:28
+        self.action_callback = None
+        self.movable, self.silent, self.collide = True, True, True
+        self.size, self.accel, self.max_speed, self.max_rot = 0.05, 3, 3, 0.17
+        self.shootRad, self.shootWin = 0.8, np.pi / 4
+
+    @property
+    def alive(self):
+        return bool(self._env._state()["alive"][0, self._i])
+
+    @property
+    def numHit(self):
+        return int(self._env._state()["num_hit"][0, self._i])
+
+    @property
+    def numWasHit(self):
+        return int(self._env._state()["num_was_hit"][0, self._i])
+
+    @property
+    def state(self):
+        s = self._env._state()
+        i = self._i
+        return types.SimpleNamespace(p_pos=np.array([s["pos_x"][0, i], s["pos_y"][0, i]]),
+                                     p_vel=np.array([s["vel_x"][0, i], s["vel_y"][0, i]]),
+                                     p_ang=float(s["ang"][0, i]))
+
+
+class _WorldView(object):
+    """The attributes of World / the scenario that callers read."""
+
+    def __init__(self, env):
+        self._env = env
+        self.agents = [_AgentView(env, i, i >= env._eng.G) for i in range(env._eng.N)]
+        self.numGuards, self.numAttackers = env._eng.G, env._eng.A
+        self.numAgents = env._eng.N
+        self.max_time_steps = env._eng.max_time_steps
+        self.fortDim, self.doorLoc = 0.15, np.array([0, 0.8])
+        self.wall_pos = [-1, 1, -0.8, 0.8]
+        self.dim_p, self.dim_c = 3, 0
+
+    @property
+    def policy_agents(self):
+        return self.agents
+
+    @property
+    def numAliveGuards(self):
+        return int(self._env._state()["alive"][0, :self.numGuards].sum())
+
+    @property
+    def numAliveAttackers(self):
+        return int(self._env._state()["alive"][0, self.numGuards:].sum())
+
+    @property
+    def time_step(self):
+        return int(self._env._state()["time_step"][0])
+
+    @property
+    def gameResult(self):
+        return self._env._state()["game_result"][0].astype(np.int64)
+
+
+class FortAttackGlobalEnv(object):
+    """gym_fortattack/fortattack.py:31 FortAttackGlobalEnv, one env on the GPU engine.
+
+    ``reset() -> (N,6) float64``; ``step(action_n) -> (obs (N,6) f64, reward_n list,
+    done bool, {'n': [{}]*N})``.  The reference draws reset positions from numpy's
+    *global* RNG; here the stream is owned by the env: ``seed`` plays the role of the
+    ``np.random.seed(seed)`` call made before construction (train_fortattack.py:200).
+    Nothing is printed at episode end (the reference prints, fortattack.py:208,214,220).
+    """
+    metadata = {"render.modes": ["human", "rgb_array"]}
+
+    def __init__(self, num_steps, num_guards=5, num_attackers=5, seed=0, skip_doubles=None, device=0):
+        self._eng = BatchedFortAttack(1, num_guards, num_attackers, num_steps, base_seed=seed,
+                                      skip_doubles=skip_doubles, device=device)
+        e = self._eng
+        self.n = e.N                                              # fortattack.py:47
+        self.agent_num = e.N
+        self.ob_rms = None                                        # fortattack.py:42
+        self.discrete_action_space = True
+        self.discrete_action_input = True
+        self.shared_reward = False
+        self.action_space = [Discrete(8) for _ in range(e.N)]     # fortattack.py:73,94
+        self.observation_space = [Box(-np.inf, np.inf, (6,), np.float32) for _ in range(e.N)]  # :98
+        self.action_spaces = MASpace(tuple(Box(0., 1., (8,)) for _ in range(e.N)))              # :107
+        self.observation_spaces = MASpace(tuple(Box(-np.inf, np.inf, (6,)) for _ in range(e.N)))
+        self.action_range = [0., 1.]
+        self._cache = None
+        self._act = torch.zeros((1, e.N), dtype=torch.int64, device=e.device)
+        self._obs64 = torch.empty((1, e.N, 6), dtype=torch.float64, device=e.device)
+        self._rew64 = torch.empty((1, e.N), dtype=torch.float64, device=e.device)
+        self._done = torch.empty((1,), dtype=torch.uint8, device=e.device)
+        self.world = _WorldView(self)
+        self.agents = self.world.policy_agents
+
+    def _state(self):
+        if self._cache is None:
+            self._cache = self._eng.get_state()
+        return self._cache
+
+    def seed(self, seed=None):  # gym.Env default: a no-op in the reference too (eval.py:26)
+        return []
+
+    def reset(self):
+        self._cache = None
+        self._eng.reset(obs_f64=self._obs64)
+        return self._obs64[0].cpu().numpy()
+
+    def step(self, action_n):
+        a = np.asarray(action_n).reshape(-1)
+        if a.shape[0] != self.n:
+            raise AssertionError("expected %d actions, got %d" % (self.n, a.shape[0]))
+        self._cache = None
+        self._act.copy_(torch.from_numpy(a.astype(np.int64)).view(1, -1))
+        self._eng.step(self._act, auto_reset=False, want=(),
+                       out=dict(obs_f64=self._obs64, reward_f64=self._rew64, done=self._done))
+        obs = self._obs64[0].cpu().numpy()
+        reward_n = list(self._rew64[0].cpu().numpy())
+        done = bool(self._done.item())
+        return obs, reward_n, done, {"n": [{} for _ in range(self.n)]}
+
+    def render(self, *args, **kwargs):  # GUI: out of scope
+        return []
+
+    def terminate(self):
+        pass
+
+    def close(self):
+        self._eng.close()
+
+
+def make_fortattack_env(num_steps, benchmark=False, num_guards=5, num_attackers=5, seed=0,
+                        skip_doubles=None, device=0):
+    """gym_fortattack/fortattack.py:17-27.  Defaults = the reference's 5v5 scenario."""
+    return FortAttackGlobalEnv(num_steps, num_guards, num_attackers, seed=seed,
+                               skip_doubles=skip_doubles, device=device)

@@ -1,0 +1,201 @@
+/*
+ * fortattack.h -- C ABI of the MI355X-native FortAttack rollout engine.
+ *
+ * The reference (Ankur-Deka/Emergent-Multiagent-Strategies) has no FFI / plugin
+ * interface: its boundary is a duck-typed Python API.  This header is
+ * the boundary a binding for that API sits on: every entry point names the reference
+ * interface it replaces (file:line relative to the reference root).  INTEGRATION.md
+ * shows the ctypes stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - return 0 (FA_OK) on success, negative on error; text via fa_last_error()
+ *     (thread local).
+ *   - the CALLER owns every buffer passed in (torch tensors, hipMalloc'd memory); the
+ *     library owns only the per-handle fp64 SoA world state and RNG state.
+ *   - all pointers in fa_step_io / fa_storage are DEVICE pointers on the handle's
+ *     device; fa_state_host pointers are HOST pointers.
+ *   - every call that takes `stream` (a hipStream_t, passed as void*) is asynchronous
+ *     and stream ordered: no hidden synchronisation, no allocation after fa_create.
+ *   - one handle per device; a handle is not thread safe (the reference is single
+ *     threaded, train_fortattack.py:199); distinct handles are independent.
+ *   - nothing is printed (the reference prints on every episode end,
+ *     fortattack.py:208,214,220).
+ *
+ * Layouts (E = num_envs on this handle, N = num_guards + num_attackers, guards first
+ * as in fortattack_env_v1.py:26-31):
+ *   state        fp64 SoA, element (e, i) at [e*N + i]          (env-major: a wave
+ *                touches one contiguous span per field)
+ *   obs          (E, N, 6) = [alive, px, py, ang, vx, vy]        fortattack_env_v1.py:238
+ *   storage      joint tensors (T[+1], E, N, ...).  Agent i's reference-shaped
+ *                RolloutStorage tensor (T[+1], P=E, ...) is the strided view [:, :, i]
+ *                (rlcore/storage.py:10-21).
+ */
+#ifndef FORTATTACK_H
+#define FORTATTACK_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FA_MAX_AGENTS 16
+#define FA_OBS_DIM 6
+#define FA_NUM_ACTIONS 8
+
+enum { FA_OK = 0, FA_ERR_INVALID = -1, FA_ERR_HIP = -2, FA_ERR_STATE = -3 };
+enum { FA_RNG_MT19937 = 0, /* numpy legacy RandomState stream: parity with the reference */
+       FA_RNG_PHILOX = 1 }; /* counter based, stateless: perf mode */
+
+typedef struct fa_env fa_env; /* opaque */
+
+/* World constants: literals of gym_fortattack/core.py:32,100-101,117-128 and
+ * gym_fortattack/envs/fortattack_env_v1.py:16-17,33-35.  fa_config_default fills them. */
+typedef struct fa_world_consts {
+    double agent_size;     /* 0.05   core.py:32 */
+    double accel;          /* 3      fortattack_env_v1.py:33 */
+    double max_speed;      /* 3      fortattack_env_v1.py:34 */
+    double max_rot;        /* 0.17   fortattack_env_v1.py:35 */
+    double fort_dim;       /* 0.15   fortattack_env_v1.py:16 */
+    double door_x, door_y; /* 0, 0.8 fortattack_env_v1.py:17 */
+    double dt;             /* 0.1    core.py:121 */
+    double damping;        /* 0.25   core.py:123 */
+    double contact_force;  /* 100    core.py:125 */
+    double contact_margin; /* 1e-10  core.py:126 */
+    double wall_xmin, wall_xmax, wall_ymin, wall_ymax; /* -1 1 -0.8 0.8  core.py:128 */
+    double shoot_rad;      /* 0.8    core.py:100 */
+    double shoot_win;      /* pi/4   core.py:101 */
+} fa_world_consts;
+
+typedef struct fa_config {
+    int32_t num_envs;       /* E: env instances on this handle */
+    int32_t num_guards;     /* reference hard-codes 5 (fortattack_env_v1.py:18) */
+    int32_t num_attackers;  /* reference hard-codes 5 (fortattack_env_v1.py:19) */
+    int32_t max_time_steps; /* world.max_time_steps, fortattack.py:21 */
+    int32_t device_id;
+    int32_t rng_mode;       /* FA_RNG_* */
+    uint64_t base_seed;     /* env e == reference under np.random.seed(base_seed + env_offset + e) */
+    int64_t env_offset;     /* global index of this handle's env 0 (multi-GPU sharding) */
+    int32_t rng_skip_doubles; /* random_sample() draws consumed before the first reset
+                                 (scenario __init__ -> reset_world, fortattack_env_v1.py:45);
+                                 negative = 2*N */
+    int32_t track_counters; /* maintain Agent.numHit / numWasHit (core.py:93-94) */
+    fa_world_consts world;
+} fa_config;
+
+/* One env.step over all E envs.  Any output pointer may be NULL. */
+typedef struct fa_step_io {
+    const int64_t *actions;    /* element (e,i) at actions[e*act_stride_env + i*act_stride_agent];
+                                  values 0..7 (fortattack.py:253-263) */
+    int64_t act_stride_env, act_stride_agent;
+    float *obs_f32;            /* (E,N,6)  as stored by learner.py:240 (.float())          */
+    float *reward_f32;         /* (E,N)    train_fortattack.py:73                            */
+    float *mask_f32;           /* (E,N)    obs[:,0] BEFORE the step, train_fortattack.py:53;
+                                  1 for every agent of an env auto-reset by this step      */
+    uint8_t *done;             /* (E)      fortattack.py:166                                 */
+    double *obs_f64;           /* (E,N,6)  what env.step returns, fortattack.py:172          */
+    double *reward_f64;        /* (E,N)    fortattack.py:173                                 */
+    uint8_t *hit, *was_hit;    /* (E,N)    Agent.hit / wasHit of this step (core.py:95-96)   */
+    int32_t auto_reset;        /* !=0: envs that finish are reset in the same launch and obs_*
+                                  hold the post-reset observation -- the trainer's
+                                  `if done: obs = env.reset()` (train_fortattack.py:97-104,
+                                  rlagent.py:28-31); mask for the next step is then 1 */
+    int32_t num_steps;         /* env-steps advanced by this ONE launch (0 or 1 = one step).
+                                  With K > 1 the actions of step k are read at
+                                  actions + k*act_stride_step and every output is a stack of K
+                                  rows ((K,E,N,6), (K,E,N), (K,E)): an open-loop rollout whose
+                                  world state never leaves the registers between steps.
+                                  Requires auto_reset != 0 when episodes may end. */
+    int64_t act_stride_step;
+} fa_step_io;
+
+/* Joint rollout buffers (device).  Shapes use T = num_steps. */
+typedef struct fa_storage {
+    int32_t num_steps;
+    float *obs;                     /* (T+1, E, N, 6)  storage.py:11 */
+    float *recurrent_hidden_states; /* (T+1, E, N)     storage.py:12 (size 1, unused by MPNN) */
+    float *rewards;                 /* (T,   E, N)     storage.py:13 */
+    float *value_preds;             /* (T+1, E, N)     storage.py:14 */
+    float *returns;                 /* (T+1, E, N)     storage.py:15 */
+    float *action_log_probs;        /* (T,   E, N)     storage.py:16 */
+    int64_t *actions;               /* (T,   E, N)     storage.py:17-18 */
+    float *masks;                   /* (T+1, E, N)     storage.py:19 (init 1) */
+    uint8_t *done;                  /* (T,   E)        episode ended at step t: the per-env
+                                       end_pts list of train_fortattack.py:98 as flags */
+} fa_storage;
+
+/* Host-side fp64 snapshot of the world state (tests, checkpoint).  Any pointer may be
+ * NULL.  prev_dist: NaN encodes prevDist == None (core.py:104). */
+typedef struct fa_state_host {
+    double *pos_x, *pos_y, *vel_x, *vel_y, *ang, *prev_dist; /* (E,N) */
+    uint8_t *alive;                                           /* (E,N) */
+    int32_t *time_step;                                       /* (E)   world.time_step */
+    int32_t *num_hit, *num_was_hit;                           /* (E,N) */
+    uint8_t *game_result;                                     /* (E,3) world.gameResult of the
+                                                                 last finished episode */
+    int64_t *result_count;                                    /* (E,3) finished episodes by
+                                                                 ending since fa_create */
+} fa_state_host;
+
+/* ---- lifecycle ---------------------------------------------------------------- */
+int fa_config_default(fa_config *cfg);            /* reference literals; 3v3, E=1 */
+/* replaces make_fortattack_env (fortattack.py:17-27) + gym.make('fortattack-v1')
+ * (fortattack_env_v1.py:10-45) for E independent worlds; seeds the per-env RNG and
+ * consumes the construction draws. */
+int fa_create(const fa_config *cfg, fa_env **out);
+void fa_destroy(fa_env *env);
+const char *fa_last_error(void);
+int fa_num_agents(const fa_env *env);
+int fa_num_envs(const fa_env *env);
+
+/* ---- env API ------------------------------------------------------------------- */
+/* replaces FortAttackGlobalEnv.reset (fortattack.py:175-186) -> reset_world
+ * (fortattack_env_v1.py:47-75).  env_mask: device (E) bytes, NULL = every env. */
+int fa_reset(fa_env *env, const uint8_t *env_mask, float *obs_f32, double *obs_f64, void *stream);
+/* replaces FortAttackGlobalEnv.step (fortattack.py:127-173): _set_action (:235-302),
+ * World.step (core.py:191-218), observation / reward callbacks
+ * (fortattack_env_v1.py:87-238), _get_done (fortattack.py:202-225). */
+int fa_step(fa_env *env, const fa_step_io *io, void *stream);
+
+/* ---- collector ------------------------------------------------------------------ */
+/* Attach caller-owned rollout buffers (RolloutStorage.__init__/to, storage.py:10-31). */
+int fa_bind_storage(fa_env *env, const fa_storage *st);
+/* env.step + RolloutStorage.insert of the env-produced fields for rollout index `step`
+ * (storage.py:33-43 via rlagent.py:33-34, learner.py:239-243): reads
+ * actions[step], writes obs[step+1], rewards[step], masks[step+1], done[step]; with
+ * auto_reset also Neo.initialize_new_episode (rlagent.py:28-31).  The policy-produced
+ * fields (actions, action_log_probs, value_preds) are written by the caller. */
+int fa_collect_step(fa_env *env, int32_t step, int32_t auto_reset, void *stream);
+/* The same for rollout indices [step_begin, step_begin + num_steps) in ONE launch, for
+ * open-loop policies (scripted / random actions already in storage.actions): the host
+ * loop of train_fortattack.py:51-105 without the per-step policy call. */
+int fa_collect_rollout(fa_env *env, int32_t step_begin, int32_t num_steps, int32_t auto_reset, void *stream);
+/* FortAttackGlobalEnv.reset + Neo.initialize_obs (rlagent.py:23-26): reset every env and
+ * write the observation to obs[0], masks[0] = 1. */
+int fa_collect_reset(fa_env *env, void *stream);
+/* Learner.wrap_horizon (learner.py:191-211) + RolloutStorage.compute_returns
+ * (storage.py:59-66, GAE branch) for all (env, agent) with per-env episode boundaries.
+ * value_preds[T] must hold V(obs[T]).  Reproduces quirk Q7 (returns[end_pt] not
+ * recomputed) exactly. */
+int fa_gae(fa_env *env, double gamma, double tau, void *stream);
+/* Advantage statistics of JointPPO.update (rlcore/algo/ppo.py:121-123), per agent, in
+ * fp64: pass 0 writes stats[i] = {n, sum(A), 0}; pass 1 reads mean[i] and writes
+ * only stats[i][2] = sum((A-mean)^2) (stats[i][0..1] are left as they are).  A = returns[:-1] - value_preds[:-1].
+ * stats: device (N,3) doubles; mean: device (N) doubles.  The only quantities that
+ * cross GPUs (all-reduce sum of `stats`). */
+int fa_adv_stats(fa_env *env, int32_t pass, const double *mean, double *stats, void *stream);
+/* ppo.py:123: adv_out (T,E,N) = (A - mean[i]) / (std[i] + 1e-5), float32. */
+int fa_adv_normalize(fa_env *env, const double *mean, const double *std, float *adv_out, void *stream);
+/* RolloutStorage.after_update (storage.py:51-56). */
+int fa_after_update(fa_env *env, void *stream);
+
+/* ---- state access (synchronous; tests / checkpoint) ------------------------------ */
+int fa_get_state(fa_env *env, const fa_state_host *out);
+int fa_set_state(fa_env *env, const fa_state_host *in); /* pos/vel/ang/prev_dist/alive/time_step */
+/* next `count` random_sample() doubles env e would draw (does not advance the stream) */
+int fa_rng_peek(fa_env *env, int32_t e, int32_t count, double *out_host);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FORTATTACK_H */

@@ -1,0 +1,164 @@
+"""GPU parity of the rollout collector: fused storage writes of fa_collect_step, fa_gae,
+fa_adv_stats / fa_adv_normalize, fa_after_update -- against the golden capture of the
+reference's own Learner / RolloutStorage / JointPPO (tests/golden/collector_3v3.npz) and
+against the numpy collector oracle on batched random data.
+
+float32 storage tensors: bit exact.  Normalised advantages: 2e-6 (torch's float32
+mean/std reduction order is not restated; the kernels accumulate in fp64).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def fa():
+    import emergent_multiagent_strategies_amd as m
+    assert torch.cuda.is_available()
+    m._lib.load()
+    return m
+
+
+def _t(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def test_collector_golden(fa, golden_dir):
+    g = np.load(os.path.join(golden_dir, "collector_3v3.npz"))
+    G, A, max_t, T, n_upd, seed, skip = [int(v) for v in g["meta"]]
+    N = G + A
+    gamma, tau = [float(v) for v in g["gamma_tau"]]
+    eng = fa.BatchedFortAttack(1, G, A, max_t, base_seed=seed, skip_doubles=skip)
+    st = fa.JointRolloutStorage(T, 1, N, device="cuda")
+    eng.bind_storage(st)
+    views = st.agent_views()
+    assert views[2].obs.shape == (T + 1, 1, 6) and views[2].actions.shape == (T, 1, 1)
+    eng.collect_reset()                                    # env.reset + initialize_obs
+    assert np.array_equal(st.obs[0, 0].cpu().numpy(), g["obs0"].astype(np.float32))
+    for j in range(n_upd):
+        # policy-side fields come from the capture (the reference's MPNN sampled them)
+        st.actions[:, 0, :, 0] = _t(g["actions"][j].astype(np.int64))
+        st.action_log_probs[:, 0, :, :] = _t(g["action_log_probs"][j][:, :, 0].transpose(1, 0, 2))
+        vp = _t(g["value_preds"][j][:, :, 0].transpose(1, 0, 2))       # (T+1, N, 1)
+        st.value_preds[:T, 0] = vp[:T]
+        for s in range(T):
+            eng.collect_step(s, auto_reset=True)
+        assert np.array_equal(st.done[:, 0].cpu().numpy(), g["done"][j])
+        end_pts = [int(v) for v in g["end_pts"][j] if v >= 0]
+        st.value_preds[T, 0] = _t(g["next_values"][j][:, len(end_pts) - 1])[:, None]
+        eng.gae(gamma, tau)
+        for i in range(N):
+            v = views[i]
+            for k in ("obs", "rewards", "masks", "returns", "value_preds"):
+                assert np.array_equal(getattr(v, k).cpu().numpy(), g[k][j, i]), (k, j, i)
+        # advantage statistics + normalisation (ppo.py:121-124)
+        s0 = eng.adv_stats(0)
+        mean = (s0[:, 1] / s0[:, 0]).contiguous()
+        s1 = eng.adv_stats(1, mean=mean, out=s0.clone())
+        std = torch.sqrt(s1[:, 2] / (s1[:, 0] - 1)).contiguous()
+        adv = eng.adv_normalize(mean, std)
+        for i in range(N):
+            assert np.abs(adv[:, :, i].cpu().numpy() - g["adv"][j, i]).max() < 2e-6
+        eng.after_update()
+        for i in range(N):
+            assert np.array_equal(views[i].obs.cpu().numpy(), g["after_obs"][j, i])
+            assert np.array_equal(views[i].masks.cpu().numpy(), g["after_masks"][j, i])
+
+
+@pytest.mark.parametrize("E,G,A,T", [(300, 3, 3, 64), (64, 5, 5, 128)])
+def test_gae_and_stats_vs_numpy_oracle(fa, E, G, A, T):
+    import collector_oracle as co
+    N = G + A
+    rng = np.random.RandomState(E)
+    eng = fa.BatchedFortAttack(E, G, A, 50)
+    st = fa.JointRolloutStorage(T, E, N, device="cuda")
+    eng.bind_storage(st)
+    rewards = rng.randn(T, E, N, 1).astype(np.float32)
+    values = rng.randn(T + 1, E, N, 1).astype(np.float32)
+    masks = (rng.rand(T + 1, E, N, 1) > 0.2).astype(np.float32)
+    stale = rng.randn(T + 1, E, N, 1).astype(np.float32)   # previous update's returns (quirk Q7)
+    done = (rng.rand(T, E) < 0.05).astype(np.uint8)
+    for k, v in (("rewards", rewards), ("value_preds", values), ("masks", masks), ("returns", stale),
+                 ("done", done)):
+        getattr(st, k).copy_(_t(v))
+    eng.gae(0.99, 0.95)
+    ep_start = np.zeros((T, E), bool)
+    ep_start[1:] = done[:-1] != 0
+    want = stale.copy()
+    for i in range(N):
+        co.gae_single_pass(rewards[:, :, i], values[:, :, i], masks[:, :, i], want[:, :, i], ep_start, 0.99, 0.95)
+    got = st.returns.cpu().numpy()
+    assert np.array_equal(got, want)
+    assert np.array_equal(got[T], stale[T])                 # row T untouched
+    s0 = eng.adv_stats(0)
+    mean = (s0[:, 1] / s0[:, 0]).contiguous()
+    s1 = eng.adv_stats(1, mean=mean, out=s0.clone()).cpu().numpy()
+    for i in range(N):
+        n, sm, ssd = co.adv_moments(want[:, :, i], values[:, :, i])
+        assert s1[i, 0] == n and abs(s1[i, 1] - sm) <= 1e-9 * max(1, abs(sm)) and abs(s1[i, 2] - ssd) <= 1e-9 * ssd
+    std = torch.sqrt(torch.from_numpy(s1[:, 2] / (s1[:, 0] - 1))).cuda().contiguous()
+    adv = eng.adv_normalize(mean, std).cpu().numpy()
+    for i in range(N):
+        assert np.abs(adv[:, :, i] - co.normalized_advantages(want[:, :, i], values[:, :, i])).max() < 2e-6
+    # run-to-run determinism of the two-stage reduction
+    assert torch.equal(eng.adv_stats(0), s0)
+
+
+def test_collect_step_matches_plain_step(fa):
+    """The storage-writing launch and the plain fa_step launch are the same kernel."""
+    E, G, A, T = 200, 3, 3, 40
+    N = G + A
+    a_eng = fa.BatchedFortAttack(E, G, A, 15, base_seed=5)
+    b_eng = fa.BatchedFortAttack(E, G, A, 15, base_seed=5)
+    st = fa.JointRolloutStorage(T, E, N, device="cuda")
+    a_eng.bind_storage(st)
+    a_eng.collect_reset()
+    ob = b_eng.reset()
+    assert torch.equal(st.obs[0], ob) and bool((st.masks[0] == 1).all())
+    gen = torch.Generator(device="cuda").manual_seed(1)
+    for s in range(T):
+        act = torch.randint(0, 8, (E, N), device="cuda", generator=gen)
+        st.actions[s, :, :, 0] = act
+        a_eng.collect_step(s)
+        o = b_eng.step(act)
+        assert torch.equal(st.obs[s + 1], o["obs_f32"])
+        assert torch.equal(st.rewards[s, :, :, 0], o["reward_f32"])
+        assert torch.equal(st.masks[s + 1, :, :, 0], o["mask_f32"])
+        assert torch.equal(st.done[s], o["done"])
+    # lagged masks (quirk Q2): masks[s+1] == obs[s][..., 0]; 1 where the env was reset at step s
+    want = torch.where(st.done[:, :, None] != 0, torch.ones_like(st.masks[1:, :, :, 0]), st.obs[:-1, :, :, 0])
+    assert torch.equal(st.masks[1:, :, :, 0], want)
+
+
+@pytest.mark.parametrize("G,A,E,T,chunk", [(3, 3, 500, 64, 64), (5, 5, 100, 48, 16), (3, 3, 4096, 128, 128)])
+def test_fused_rollout_equals_per_step_launches(fa, G, A, E, T, chunk):
+    """fa_collect_rollout (K env-steps in one launch, state in registers) is bit-identical
+    to K fa_collect_step launches -- storage rows, world state and RNG cursor."""
+    N = G + A
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    acts = torch.randint(0, 8, (T, E, N, 1), device="cuda", generator=gen)
+    res = []
+    for fused in (False, True):
+        eng = fa.BatchedFortAttack(E, G, A, 25, base_seed=99)
+        st = fa.JointRolloutStorage(T, E, N, device="cuda")
+        eng.bind_storage(st)
+        eng.collect_reset()
+        st.actions.copy_(acts)
+        if fused:
+            for s0 in range(0, T, chunk):
+                eng.collect_rollout(s0, chunk)
+        else:
+            for s in range(T):
+                eng.collect_step(s)
+        res.append((st, eng.get_state(), eng.rng_peek(E - 1, 4)))
+    (sa, xa, ra), (sb, xb, rb) = res
+    for k in ("obs", "rewards", "masks", "done"):
+        assert torch.equal(getattr(sa, k), getattr(sb, k)), k
+    for k in xa:
+        assert np.array_equal(xa[k], xb[k], equal_nan=True), k
+    assert np.array_equal(ra, rb)
+    assert int(sa.done.sum()) > 0
