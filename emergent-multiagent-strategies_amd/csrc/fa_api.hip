@@ -86,6 +86,14 @@ FaDerived derive(const fa_world_consts &w) {
     d.wall_ymax = w.wall_ymax;
     d.shoot_rad = w.shoot_rad;
     d.half_win = w.shoot_win / 2;                  // core.py:376
+    d.cos_hw = std::cos(d.half_win);
+    d.sin_hw = std::sin(d.half_win);
+    {   // largest double x with sqrt(x) <= max_speed (host sqrt is correctly rounded)
+        double x = w.max_speed * w.max_speed;
+        while (std::sqrt(x) > w.max_speed) x = std::nextafter(x, 0.0);
+        while (std::sqrt(std::nextafter(x, INFINITY)) <= w.max_speed) x = std::nextafter(x, INFINITY);
+        d.speed2_max = x;
+    }
     d.rot_pos = py_mod(+w.max_rot, 2 * pi);        // core.py:336
     d.rot_neg = py_mod(-w.max_rot, 2 * pi);
     d.ang_guard = 3 * pi / 2;                      // fortattack_env_v1.py:59

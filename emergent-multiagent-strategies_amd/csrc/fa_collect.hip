@@ -15,12 +15,13 @@
 // and the accumulator restarts at 0 for the segment below it.
 // float32 throughout, operation order of storage.py:63-66; gamma and gamma*tau are
 // rounded to float32 once (torch scalar * tensor).
-__global__ __launch_bounds__(256) void fa_gae_kernel(const float *__restrict__ rewards,
-                                                     const float *__restrict__ value_preds,
-                                                     const float *__restrict__ masks,
-                                                     float *__restrict__ returns,
-                                                     const uint8_t *__restrict__ done, int T, int E,
-                                                     int N, float g32, float gt32) {
+#define FA_GAE_CHUNK 32
+__global__ __launch_bounds__(64) void fa_gae_kernel(const float *__restrict__ rewards,
+                                                    const float *__restrict__ value_preds,
+                                                    const float *__restrict__ masks,
+                                                    float *__restrict__ returns,
+                                                    const uint8_t *__restrict__ done, int T, int E,
+                                                    int N, float g32, float gt32) {
     const long long EN = (long long)E * N;
     const long long col = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (col >= EN) return;
@@ -28,22 +29,37 @@ __global__ __launch_bounds__(256) void fa_gae_kernel(const float *__restrict__ r
     float gae = 0.0f;
     float v_next = value_preds[(long long)T * EN + col];
     float m_next = masks[(long long)T * EN + col];
-#pragma unroll 4
-    for (int t = T - 1; t >= 0; --t) {
-        const float r = rewards[(long long)t * EN + col];
-        const float v = value_preds[(long long)t * EN + col];
-        const float m_t = masks[(long long)t * EN + col];
-        const bool ep_start = t > 0 && done[(long long)(t - 1) * E + e] != 0;
-        const float delta = r + g32 * v_next * m_next - v;
-        const float g = delta + gt32 * m_next * gae;
-        if (ep_start) {
-            gae = 0.0f;
-        } else {
-            gae = g;
-            returns[(long long)t * EN + col] = g + v;
+    // the scan is a 2-op dependent chain per step; the loads do not depend on it, so a
+    // chunk's 4 x 8 loads are issued together and the chain runs out of registers.
+    for (int t0 = T - 1; t0 >= 0; t0 -= FA_GAE_CHUNK) {
+        float r[FA_GAE_CHUNK], v[FA_GAE_CHUNK], m[FA_GAE_CHUNK];
+        bool skip[FA_GAE_CHUNK];
+#pragma unroll
+        for (int k = 0; k < FA_GAE_CHUNK; ++k) {
+            const int t = t0 - k;
+            const bool in = t >= 0;
+            const long long o = (long long)(in ? t : 0) * EN + col;
+            r[k] = rewards[o];
+            v[k] = value_preds[o];
+            m[k] = masks[o];
+            skip[k] = in && t > 0 && done[(long long)(t - 1) * E + e] != 0;
         }
-        v_next = v;
-        m_next = m_t;
+#pragma unroll
+        for (int k = 0; k < FA_GAE_CHUNK; ++k) {
+            const int t = t0 - k;
+            if (t >= 0) {
+                const float delta = r[k] + g32 * v_next * m_next - v[k];
+                const float g = delta + gt32 * m_next * gae;
+                if (skip[k]) {
+                    gae = 0.0f;
+                } else {
+                    gae = g;
+                    returns[(long long)t * EN + col] = g + v[k];
+                }
+                v_next = v[k];
+                m_next = m[k];
+            }
+        }
     }
 }
 
@@ -91,16 +107,21 @@ __global__ __launch_bounds__(256) void fa_adv_partial_kernel(const float *__rest
     }
 }
 
-// stats[i] = {n, sum, ssd}: PASS 0 fills n and sum (ssd = 0), PASS 1 fills ssd.
+// stats[i] = {n, sum, 0} (PASS 0) / stats[i][2] = ssd (PASS 1).  One wave per agent: lane l
+// folds partials l, l+64, ... in order, then a fixed shuffle tree => reproducible.
 template <int PASS>
 __global__ void fa_adv_final_kernel(const double *__restrict__ partial, int nblocks, int N, double n_rows,
                                     double *__restrict__ stats) {
-    const int i = threadIdx.x;
+    const int i = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (i >= N) return;
     double s = 0.0;
-    for (int b = 0; b < nblocks; ++b) s += partial[(long long)b * N + i];
-    if (PASS == 0) { stats[i * 3 + 0] = n_rows; stats[i * 3 + 1] = s; stats[i * 3 + 2] = 0.0; }
-    else stats[i * 3 + 2] = s;
+    for (int b = lane; b < nblocks; b += 64) s += partial[(long long)b * N + i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if (lane == 0) {
+        if (PASS == 0) { stats[i * 3 + 0] = n_rows; stats[i * 3 + 1] = s; stats[i * 3 + 2] = 0.0; }
+        else stats[i * 3 + 2] = s;
+    }
 }
 
 // ppo.py:123: (A - mean) / (std + 1e-5), float32 arithmetic with float32 mean/std.
@@ -120,8 +141,8 @@ __global__ __launch_bounds__(256) void fa_adv_norm_kernel(const float *__restric
 hipError_t fa_launch_gae(const float *rewards, const float *value_preds, const float *masks, float *returns,
                          const uint8_t *done, int T, int E, int N, double gamma, double tau, hipStream_t st) {
     const long long EN = (long long)E * N;
-    const int grid = (int)((EN + 255) / 256);
-    hipLaunchKernelGGL(fa_gae_kernel, dim3(grid), dim3(256), 0, st, rewards, value_preds, masks, returns,
+    const int grid = (int)((EN + 63) / 64);
+    hipLaunchKernelGGL(fa_gae_kernel, dim3(grid), dim3(64), 0, st, rewards, value_preds, masks, returns,
                        done, T, E, N, (float)gamma, (float)(gamma * tau));
     return hipGetLastError();
 }
@@ -132,12 +153,12 @@ hipError_t fa_launch_adv_stats(int pass, const float *returns, const float *valu
     if (pass == 0) {
         hipLaunchKernelGGL(fa_adv_partial_kernel<0>, dim3(nblocks), dim3(256), 0, st, returns, value_preds,
                            mean, rows, N, partial);
-        hipLaunchKernelGGL(fa_adv_final_kernel<0>, dim3(1), dim3(64), 0, st, partial, nblocks, N,
+        hipLaunchKernelGGL(fa_adv_final_kernel<0>, dim3(1), dim3(64 * N), 0, st, partial, nblocks, N,
                            (double)rows, stats);
     } else {
         hipLaunchKernelGGL(fa_adv_partial_kernel<1>, dim3(nblocks), dim3(256), 0, st, returns, value_preds,
                            mean, rows, N, partial);
-        hipLaunchKernelGGL(fa_adv_final_kernel<1>, dim3(1), dim3(64), 0, st, partial, nblocks, N,
+        hipLaunchKernelGGL(fa_adv_final_kernel<1>, dim3(1), dim3(64 * N), 0, st, partial, nblocks, N,
                            (double)rows, stats);
     }
     return hipGetLastError();

@@ -121,7 +121,10 @@ __device__ __forceinline__ bool laser_hit(double x1, double y1, double x2, doubl
     return false;
 }
 
-template <int TG, int TA, bool RESET_ONLY>
+// COLLECT: the four trainer rows (obs32, rew32, mask32, done) are all present and nothing
+// else is: their stores are then unconditional, which lets the compiler wait for the
+// prefetched action with vmcnt(#stores) instead of draining the store queue every step.
+template <int TG, int TA, bool RESET_ONLY, bool COLLECT>
 __global__ __launch_bounds__(FA_WAVE) void fa_step_kernel(FaStepArgs a) {
     const int G = TG ? TG : a.G, A = TA ? TA : a.A;
     const int N = G + A;
@@ -131,7 +134,8 @@ __global__ __launch_bounds__(FA_WAVE) void fa_step_kernel(FaStepArgs a) {
     const int i = lane - slot * N;        // agent index
     const int gbase = slot * N;           // first lane of this env's group
     const int e = blockIdx.x * EPW + slot;
-    const bool valid = (slot < EPW) && (e < a.E);
+    if (!((slot < EPW) && (e < a.E))) return; // padding lanes leave: ballots count live lanes only
+    const bool valid = true;
     const bool is_att = i >= G;
     const size_t idx = (size_t)e * N + i;
     const size_t EN = (size_t)a.E * N;
@@ -154,6 +158,11 @@ __global__ __launch_bounds__(FA_WAVE) void fa_step_kernel(FaStepArgs a) {
     bool dirty = false; // state changed => write it back
 
     const int nsteps = RESET_ONLY ? 1 : a.nsteps;
+    // the action of step s+1 is requested at the top of step s: gfx9 vector memory returns in
+    // order, so a load issued after step s's stores would wait for all of them to drain.
+    const int64_t *act_ptr = RESET_ONLY ? nullptr : a.actions + (int64_t)e * a.as_e + (int64_t)i * a.as_i;
+    int act_cur = RESET_ONLY ? 0 : (int)act_ptr[0];
+    asm volatile("" ::"v"(act_cur)); // first action arrives before the loop, not at its head
     for (int s = 0; s < nsteps; ++s) {
         bool do_reset;
         if (RESET_ONLY) {
@@ -161,7 +170,8 @@ __global__ __launch_bounds__(FA_WAVE) void fa_step_kernel(FaStepArgs a) {
         } else {
             const bool alive0 = alive;
             // ---- fortattack.py:253-263,:289 _set_action (all agents, dead ones too) ----
-            const int act = valid ? (int)a.actions[(int64_t)s * a.as_t + (int64_t)e * a.as_e + (int64_t)i * a.as_i] : 0;
+            const int act = act_cur;
+            if (valid && s + 1 < nsteps) act_cur = (int)act_ptr[(int64_t)(s + 1) * a.as_t];
             double u0 = 0.0, u1 = 0.0, rot = 0.0;
             if (act == 1) u0 = +1.0;
             if (act == 2) u0 = -1.0;
@@ -178,13 +188,17 @@ __global__ __launch_bounds__(FA_WAVE) void fa_step_kernel(FaStepArgs a) {
             s_py[lane] = py;
             const bool shooter = valid && alive0 && shoot;
             if (shooter) {
+                // one sincos; cos/sin(ang +- shootWin/2) by the angle-addition identities with
+                // host-evaluated cos/sin(shootWin/2).  Differs from evaluating cos(ang +- w/2)
+                // directly only in the last ulp, which can move a hit decision only for a target
+                // within ~1e-16 of a triangle edge (same class as libm-vs-libm differences).
                 double sn, cs;
                 sincos(ang, &sn, &cs);
                 const double x1 = px + c.agent_size * cs, y1 = py + c.agent_size * sn;
-                sincos(ang + c.half_win, &sn, &cs);
-                const double x2 = x1 + c.shoot_rad * cs, y2 = y1 + c.shoot_rad * sn;
-                sincos(ang - c.half_win, &sn, &cs);
-                const double x3 = x1 + c.shoot_rad * cs, y3 = y1 + c.shoot_rad * sn;
+                const double cp = cs * c.cos_hw - sn * c.sin_hw, sp = sn * c.cos_hw + cs * c.sin_hw;
+                const double cm = cs * c.cos_hw + sn * c.sin_hw, sm = sn * c.cos_hw - cs * c.sin_hw;
+                const double x2 = x1 + c.shoot_rad * cp, y2 = y1 + c.shoot_rad * sp;
+                const double x3 = x1 + c.shoot_rad * cm, y3 = y1 + c.shoot_rad * sm;
                 s_tri[0][lane] = x1; s_tri[1][lane] = y1; s_tri[2][lane] = x2;
                 s_tri[3][lane] = y2; s_tri[4][lane] = x3; s_tri[5][lane] = y3;
             }
@@ -249,10 +263,13 @@ __global__ __launch_bounds__(FA_WAVE) void fa_step_kernel(FaStepArgs a) {
                     const double d2 = py - size - c.wall_ymin, d3 = c.wall_ymax - py - size;
                     // exact skip: all four clearances > 1000*margin => all penalties +0.0
                     if (!(d0 > c.wall_skip && d1 > c.wall_skip && d2 > c.wall_skip && d3 > c.wall_skip)) {
-                        const double fx1 = c.contact_force * softplus_pen(-d0 / k, k);
-                        const double fx2 = c.contact_force * softplus_pen(-d1 / k, k);
-                        const double fy1 = c.contact_force * softplus_pen(-d2 / k, k);
-                        const double fy2 = c.contact_force * softplus_pen(-d3 / k, k);
+                        // four independent divisions issued back to back (ILP), then the
+                        // three-branch softplus on each
+                        const double t0 = -d0 / k, t1 = -d1 / k, t2 = -d2 / k, t3 = -d3 / k;
+                        const double fx1 = c.contact_force * softplus_pen(t0, k);
+                        const double fx2 = c.contact_force * softplus_pen(t1, k);
+                        const double fy1 = c.contact_force * softplus_pen(t2, k);
+                        const double fy2 = c.contact_force * softplus_pen(t3, k);
                         Fx = (fx1 - fx2) + Fx;
                         Fy = (fy1 - fy2) + Fy;
                     }
@@ -262,8 +279,12 @@ __global__ __launch_bounds__(FA_WAVE) void fa_step_kernel(FaStepArgs a) {
                 vy = vy * c.one_minus_damping;
                 vx += Fx * c.dt;
                 vy += Fy * c.dt;
-                const double speed = sqrt(vx * vx + vy * vy);
-                if (speed > c.max_speed) {
+                // `sqrt(v.v) > max_speed` decided without the sqrt: speed2_max is the largest
+                // double whose correctly rounded sqrt is <= max_speed (found on the host), so
+                // the comparison below is the reference's comparison, exactly.
+                const double speed2 = vx * vx + vy * vy;
+                if (speed2 > c.speed2_max) {
+                    const double speed = sqrt(speed2);
                     vx = vx / speed * c.max_speed;
                     vy = vy / speed * c.max_speed;
                 }
@@ -315,9 +336,9 @@ __global__ __launch_bounds__(FA_WAVE) void fa_step_kernel(FaStepArgs a) {
                     const int which = any_in_fort ? 2 : (n_alive_att == 0 ? 0 : 1);
                     uint8_t *gr = a.s.game_result + (size_t)e * 3;
                     gr[0] = which == 0; gr[1] = which == 1; gr[2] = which == 2;
-                    a.s.result_count[(size_t)e * 3 + which] += 1u;
+                    atomicAdd(a.s.result_count + (size_t)e * 3 + which, 1u); // no-return atomic: no wait
                 }
-                if (a.done) a.done[(size_t)s * a.E + e] = done ? 1 : 0;
+                if (COLLECT || a.done) a.done[(size_t)s * a.E + e] = done ? 1 : 0;
             }
             t += 1;
             do_reset = valid && done && a.auto_reset != 0;
@@ -327,15 +348,21 @@ __global__ __launch_bounds__(FA_WAVE) void fa_step_kernel(FaStepArgs a) {
             nwh += was_hit_cnt; // one per shooter that hit (core.py:283)
 
             // step-level outputs (the reset below must not touch them)
-            if (valid) {
+            {
                 const size_t o = (size_t)s * EN + idx;
-                if (a.rew32) a.rew32[o] = (float)rew;
-                if (a.rew64) a.rew64[o] = rew;
                 // trainer mask (train_fortattack.py:53,87): alive BEFORE the step; an env that is
                 // reset here gets the post-reset mask 1 (initialize_new_episode, rlagent.py:31)
-                if (a.mask32) a.mask32[o] = (alive0 || do_reset) ? 1.0f : 0.0f;
-                if (a.hit) a.hit[o] = hit ? 1 : 0;
-                if (a.was_hit) a.was_hit[o] = was_hit ? 1 : 0;
+                const float mk = (alive0 || do_reset) ? 1.0f : 0.0f;
+                if (COLLECT) {
+                    a.rew32[o] = (float)rew;
+                    a.mask32[o] = mk;
+                } else {
+                    if (a.rew32) a.rew32[o] = (float)rew;
+                    if (a.rew64) a.rew64[o] = rew;
+                    if (a.mask32) a.mask32[o] = mk;
+                    if (a.hit) a.hit[o] = hit ? 1 : 0;
+                    if (a.was_hit) a.was_hit[o] = was_hit ? 1 : 0;
+                }
             }
         }
 
@@ -362,13 +389,13 @@ __global__ __launch_bounds__(FA_WAVE) void fa_step_kernel(FaStepArgs a) {
         if (valid && (!RESET_ONLY || do_reset)) {
             const double al = alive ? 1.0 : 0.0;
             const size_t o6 = ((size_t)s * EN + idx) * 6;
-            if (a.obs32) {
+            if (COLLECT || a.obs32) {
                 float2 *o = reinterpret_cast<float2 *>(a.obs32 + o6);
                 o[0] = make_float2((float)al, (float)px);
                 o[1] = make_float2((float)py, (float)ang);
                 o[2] = make_float2((float)vx, (float)vy);
             }
-            if (a.obs64) {
+            if (!COLLECT && a.obs64) {
                 double2 *o = reinterpret_cast<double2 *>(a.obs64 + o6);
                 o[0] = make_double2(al, px);
                 o[1] = make_double2(py, ang);
@@ -411,22 +438,25 @@ __global__ void fa_seed_kernel(FaState s, int E, uint64_t base_seed, int64_t env
 }
 
 // ---- launchers --------------------------------------------------------------------------
-template <bool RESET_ONLY>
+template <bool RESET_ONLY, bool COLLECT>
 static hipError_t launch_step_t(const FaStepArgs &a, hipStream_t st) {
     const int N = a.G + a.A;
     const int epw = FA_WAVE / N;
     const int grid = (a.E + epw - 1) / epw;
     if (a.G == 3 && a.A == 3)
-        hipLaunchKernelGGL((fa_step_kernel<3, 3, RESET_ONLY>), dim3(grid), dim3(FA_WAVE), 0, st, a);
+        hipLaunchKernelGGL((fa_step_kernel<3, 3, RESET_ONLY, COLLECT>), dim3(grid), dim3(FA_WAVE), 0, st, a);
     else if (a.G == 5 && a.A == 5)
-        hipLaunchKernelGGL((fa_step_kernel<5, 5, RESET_ONLY>), dim3(grid), dim3(FA_WAVE), 0, st, a);
+        hipLaunchKernelGGL((fa_step_kernel<5, 5, RESET_ONLY, COLLECT>), dim3(grid), dim3(FA_WAVE), 0, st, a);
     else
-        hipLaunchKernelGGL((fa_step_kernel<0, 0, RESET_ONLY>), dim3(grid), dim3(FA_WAVE), 0, st, a);
+        hipLaunchKernelGGL((fa_step_kernel<0, 0, RESET_ONLY, COLLECT>), dim3(grid), dim3(FA_WAVE), 0, st, a);
     return hipGetLastError();
 }
 
-hipError_t fa_launch_step(const FaStepArgs &a, hipStream_t st) { return launch_step_t<false>(a, st); }
-hipError_t fa_launch_reset(const FaStepArgs &a, hipStream_t st) { return launch_step_t<true>(a, st); }
+hipError_t fa_launch_step(const FaStepArgs &a, hipStream_t st) {
+    const bool collect = a.obs32 && a.rew32 && a.mask32 && a.done && !a.obs64 && !a.rew64 && !a.hit && !a.was_hit;
+    return collect ? launch_step_t<false, true>(a, st) : launch_step_t<false, false>(a, st);
+}
+hipError_t fa_launch_reset(const FaStepArgs &a, hipStream_t st) { return launch_step_t<true, false>(a, st); }
 hipError_t fa_launch_seed(const FaState &s, int E, uint64_t base_seed, int64_t env_offset,
                           int skip_words, hipStream_t st) {
     hipLaunchKernelGGL(fa_seed_kernel, dim3((E + 255) / 256), dim3(256), 0, st, s, E, base_seed,
