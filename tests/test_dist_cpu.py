@@ -1,0 +1,83 @@
+"""CPU, world_size 2 (gloo): the multi-GPU path of the hot path -- env shards plus the
+two-pass all-reduce of the advantage statistics (rlcore/algo/ppo.py:121-123)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import collector_oracle as co
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, returns, values, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from emergent_multiagent_strategies_amd.dist import shard_range, two_pass_mean_std
+    T, E, N = returns.shape[0] - 1, returns.shape[1], returns.shape[2]
+    lo, per = shard_range(E, rank, world)
+    ret = torch.from_numpy(returns[:, lo:lo + per])
+    val = torch.from_numpy(values[:, lo:lo + per])
+    adv = (ret[:-1] - val[:-1]).double()                       # (T, per, N, 1)
+
+    def pass0():                                               # what fa_adv_stats(0) returns per rank
+        s = torch.zeros(N, 3, dtype=torch.float64)
+        s[:, 0] = T * per
+        s[:, 1] = adv.sum(dim=(0, 1, 3))
+        return s
+
+    def pass1(mean):                                           # fa_adv_stats(1)[:, 2]
+        return ((adv - mean.view(1, 1, N, 1)) ** 2).sum(dim=(0, 1, 3))
+
+    mean, std, n = two_pass_mean_std(pass0, pass1)
+    q.put((rank, mean.numpy(), std.numpy(), n.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_advantage_statistics_equal_single_process():
+    T, E, N, world = 16, 12, 6, 2
+    rng = np.random.RandomState(0)
+    returns = rng.randn(T + 1, E, N, 1).astype(np.float32)
+    values = rng.randn(T + 1, E, N, 1).astype(np.float32)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, returns, values, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for i in range(N):
+        n, sm, ssd = co.adv_moments(returns[:, :, i], values[:, :, i])
+        a64 = (returns[:-1, :, i] - values[:-1, :, i]).astype(np.float64)
+        for rank, mean, std, nn in got:
+            assert nn[i] == n
+            assert abs(mean[i] - a64.mean()) < 1e-12
+            assert abs(std[i] - a64.std(ddof=1)) < 1e-12          # unbiased, like torch .std()
+    assert np.array_equal(got[0][1], got[1][1]) and np.array_equal(got[0][2], got[1][2])  # identical on all ranks
+
+
+def test_shard_range():
+    from emergent_multiagent_strategies_amd.dist import shard_range
+    assert [shard_range(32768, r, 8) for r in (0, 7)] == [(0, 4096), (28672, 4096)]
+    with pytest.raises(ValueError):
+        shard_range(10, 0, 3)
+
+
+def test_single_process_is_a_no_op_reduce():
+    from emergent_multiagent_strategies_amd.dist import two_pass_mean_std
+    x = torch.randn(100, 3, dtype=torch.float64)
+    s0 = torch.stack([torch.full((3,), 100.0, dtype=torch.float64), x.sum(0), torch.zeros(3, dtype=torch.float64)], 1)
+    mean, std, n = two_pass_mean_std(lambda: s0, lambda m: ((x - m) ** 2).sum(0))
+    assert torch.allclose(mean, x.mean(0)) and torch.allclose(std, x.std(0))
