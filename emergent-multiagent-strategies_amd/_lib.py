@@ -76,7 +76,8 @@ _lib = None
 
 
 def lib_path():
-    return _build.LIB
+    # FA_LIB_OVERRIDE: load an alternative build of the same C ABI (kernel experiments)
+    return os.environ.get("FA_LIB_OVERRIDE") or _build.LIB
 
 
 def load():

@@ -14,6 +14,7 @@
 #define FA_MT_N 624
 #define FA_MT_M 397
 #define FA_MAX_AGENTS_DEV 16
+#define FA_ACT_BATCH 16 // env-steps of actions staged in LDS per batch (power of two)
 
 // Host-derived constants (evaluated once in double, in the reference's expression order).
 struct FaDerived {

@@ -98,13 +98,18 @@ __device__ __forceinline__ void reset_advance(const FaStepArgs &a, int e, int N)
 //   t >= 40  : t + log1p(exp(-t)) == t exactly (exp(-t) <= 4.3e-18 < ulp(40)/2)
 //   t < -746 : exp underflows to +0, log1p(0) = 0
 // only the band in between needs libm.
+// the libm band, kept out of line: it runs for ~1e-5 of contacts but would otherwise be
+// inlined (exp + log1p, twice) at every one of the ~10 call sites
+__device__ __attribute__((noinline)) double softplus_band(double t) {
+    if (t == 0.0) return 0.0 + 0.693147180559945309417232121458176568; // NPY_LOGE2
+    if (t < 0.0) return 0.0 + log1p(exp(t));
+    return t + log1p(exp(-t));
+}
 __device__ __forceinline__ double softplus_pen(double t, double k) {
     double v;
     if (t >= 40.0) v = t;
     else if (t < -746.0) v = 0.0;
-    else if (t == 0.0) v = 0.0 + 0.693147180559945309417232121458176568;
-    else if (t < 0.0) v = 0.0 + log1p(exp(t));
-    else v = t + log1p(exp(-t));
+    else v = softplus_band(t);
     return v * k;
 }
 
@@ -143,6 +148,7 @@ __global__ __launch_bounds__(FA_WAVE) void fa_step_kernel(FaStepArgs a) {
     const FaDerived &c = a.c;
 
     __shared__ double s_px[FA_WAVE], s_py[FA_WAVE], s_tri[6][FA_WAVE];
+    __shared__ int s_act[FA_ACT_BATCH][FA_WAVE];
 
     // ---- load state once per launch (coalesced: lane-contiguous) --------------------
     double px = 0, py = 0, vx = 0, vy = 0, ang = 0, prev = 0;
@@ -158,20 +164,29 @@ __global__ __launch_bounds__(FA_WAVE) void fa_step_kernel(FaStepArgs a) {
     bool dirty = false; // state changed => write it back
 
     const int nsteps = RESET_ONLY ? 1 : a.nsteps;
-    // the action of step s+1 is requested at the top of step s: gfx9 vector memory returns in
-    // order, so a load issued after step s's stores would wait for all of them to drain.
     const int64_t *act_ptr = RESET_ONLY ? nullptr : a.actions + (int64_t)e * a.as_e + (int64_t)i * a.as_i;
-    int act_cur = RESET_ONLY ? 0 : (int)act_ptr[0];
-    asm volatile("" ::"v"(act_cur)); // first action arrives before the loop, not at its head
+    // Actions reach the step through LDS in batches of FA_ACT_BATCH steps: gfx9 vector memory
+    // returns in order, so a per-step action load would make every step wait (s_waitcnt vmcnt)
+    // for the acknowledgement of its predecessor's stores.  One batch = 16 loads in flight,
+    // one wait per 16 steps; inside a batch the step only touches LDS (lgkmcnt).
     for (int s = 0; s < nsteps; ++s) {
+        if (!RESET_ONLY && (s & (FA_ACT_BATCH - 1)) == 0) {
+            int av[FA_ACT_BATCH];
+#pragma unroll
+            for (int k = 0; k < FA_ACT_BATCH; ++k)
+                av[k] = (s + k < nsteps) ? (int)act_ptr[(int64_t)(s + k) * a.as_t] : 0; // uniform
+#pragma unroll
+            for (int k = 0; k < FA_ACT_BATCH; ++k) s_act[k][lane] = av[k];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
         bool do_reset;
         if (RESET_ONLY) {
             do_reset = valid && (a.reset_mask == nullptr || a.reset_mask[e] != 0);
         } else {
             const bool alive0 = alive;
             // ---- fortattack.py:253-263,:289 _set_action (all agents, dead ones too) ----
-            const int act = act_cur;
-            if (valid && s + 1 < nsteps) act_cur = (int)act_ptr[(int64_t)(s + 1) * a.as_t];
+            const int act = s_act[s & (FA_ACT_BATCH - 1)][lane];
             double u0 = 0.0, u1 = 0.0, rot = 0.0;
             if (act == 1) u0 = +1.0;
             if (act == 2) u0 = -1.0;
@@ -217,17 +232,45 @@ __global__ __launch_bounds__(FA_WAVE) void fa_step_kernel(FaStepArgs a) {
                 const int team_idx = is_att ? i - G : i;
                 const unsigned long long opp_mask =
                     is_att ? ((1ull << G) - 1ull) : (((1ull << A) - 1ull) << G);
-                const int KMAX = G > A ? G : A;
-                for (int k = 0; k < KMAX; ++k) {
-                    const int j = gbase + opp0 + k;
-                    bool h = false;
-                    if (valid && alive0 && k < n_opp && ((shooters_b >> j) & 1ull))
-                        h = laser_hit(s_tri[0][j], s_tri[1][j], s_tri[2][j], s_tri[3][j], s_tri[4][j],
-                                      s_tri[5][j], px, py);
-                    const unsigned long long hb = __ballot(h);
-                    if (k == team_idx) hit_cnt = __popcll((hb >> gbase) & opp_mask);
-                    was_hit = was_hit || h;
-                    was_hit_cnt += h ? 1 : 0;
+                constexpr int KT = TG > TA ? TG : TA;
+                if constexpr (KT != 0) {
+                    // compile-time team sizes: all opponent triangles are fetched from LDS in one
+                    // batch and the KT hit tests are independent instruction streams (ILP; this
+                    // wave is alone on its SIMD, so dependent fp64 latency is otherwise exposed)
+                    double tr[KT][6];
+                    bool hk[KT];
+#pragma unroll
+                    for (int k = 0; k < KT; ++k) {
+                        const int j = gbase + opp0 + (k < n_opp ? k : 0);
+#pragma unroll
+                        for (int q = 0; q < 6; ++q) tr[k][q] = s_tri[q][j];
+                    }
+#pragma unroll
+                    for (int k = 0; k < KT; ++k) {
+                        const int j = gbase + opp0 + k;
+                        const bool cand = alive0 && k < n_opp && ((shooters_b >> j) & 1ull);
+                        hk[k] = cand && laser_hit(tr[k][0], tr[k][1], tr[k][2], tr[k][3], tr[k][4], tr[k][5], px, py);
+                    }
+#pragma unroll
+                    for (int k = 0; k < KT; ++k) {
+                        const unsigned long long hb = __ballot(hk[k]);
+                        if (k == team_idx) hit_cnt = __popcll((hb >> gbase) & opp_mask);
+                        was_hit = was_hit || hk[k];
+                        was_hit_cnt += hk[k] ? 1 : 0;
+                    }
+                } else {
+                    const int KMAX = G > A ? G : A;
+                    for (int k = 0; k < KMAX; ++k) {
+                        const int j = gbase + opp0 + k;
+                        bool h = false;
+                        if (alive0 && k < n_opp && ((shooters_b >> j) & 1ull))
+                            h = laser_hit(s_tri[0][j], s_tri[1][j], s_tri[2][j], s_tri[3][j], s_tri[4][j],
+                                          s_tri[5][j], px, py);
+                        const unsigned long long hb = __ballot(h);
+                        if (k == team_idx) hit_cnt = __popcll((hb >> gbase) & opp_mask);
+                        was_hit = was_hit || h;
+                        was_hit_cnt += h ? 1 : 0;
+                    }
                 }
             }
             const bool hit = shooter && hit_cnt > 0;
@@ -243,33 +286,57 @@ __global__ __launch_bounds__(FA_WAVE) void fa_step_kernel(FaStepArgs a) {
                 // for agent i that is partner j ascending, with f_i = +f for j>i and
                 // -(f(j,i)) for j<i, which is bitwise the same number as f computed from
                 // i's side (negation commutes exactly with *, / and the sqrt argument).
-                for (int j = 0; j < N; ++j) {
-                    if (j == i || !((grp_alive1 >> j) & 1ull)) continue;
-                    const double dx = px - s_px[gbase + j], dy = py - s_py[gbase + j];
-                    const double d2 = dx * dx + dy * dy;
-                    // exact skip: farther than dist_min + 1000*margin => t < -1000 =>
-                    // exp(t) == +0 => penetration == +0.0 => force == +-0.0, and F (never
-                    // -0.0) is unchanged by adding it.
-                    if (d2 > c.contact_skip_d2) continue;
-                    const double dist = sqrt(d2);
-                    const double pen = softplus_pen(-(dist - c.dist_min) / c.contact_margin, c.contact_margin);
-                    Fx = c.contact_force * dx / dist * pen + Fx;
-                    Fy = c.contact_force * dy / dist * pen + Fy;
+                constexpr int NT = (TG != 0) ? TG + TA : 0;
+                if constexpr (NT != 0) {
+                    // all partner positions in one LDS batch; the cheap reject for every partner
+                    // is independent work; only partners actually in range take the slow path
+                    double dxs[NT], dys[NT], d2s[NT];
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) {
+                        dxs[j] = px - s_px[gbase + j];
+                        dys[j] = py - s_py[gbase + j];
+                        d2s[j] = dxs[j] * dxs[j] + dys[j] * dys[j];
+                    }
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) {
+                        // exact skip: farther than dist_min + 1000*margin => t < -1000 =>
+                        // exp(t) == +0 => penetration == +0.0 => force == +-0.0, and F (never
+                        // -0.0) is unchanged by adding it.
+                        if (j == i || !((grp_alive1 >> j) & 1ull) || d2s[j] > c.contact_skip_d2) continue;
+                        const double dist = sqrt(d2s[j]);
+                        const double pen = softplus_pen(-(dist - c.dist_min) / c.contact_margin, c.contact_margin);
+                        Fx = c.contact_force * dxs[j] / dist * pen + Fx;
+                        Fy = c.contact_force * dys[j] / dist * pen + Fy;
+                    }
+                } else {
+                    for (int j = 0; j < N; ++j) {
+                        if (j == i || !((grp_alive1 >> j) & 1ull)) continue;
+                        const double dx = px - s_px[gbase + j], dy = py - s_py[gbase + j];
+                        const double d2 = dx * dx + dy * dy;
+                        if (d2 > c.contact_skip_d2) continue; // exact skip, see above
+                        const double dist = sqrt(d2);
+                        const double pen = softplus_pen(-(dist - c.dist_min) / c.contact_margin, c.contact_margin);
+                        Fx = c.contact_force * dx / dist * pen + Fx;
+                        Fy = c.contact_force * dy / dist * pen + Fy;
+                    }
                 }
                 // core.py:246-252 + :459-472 walls
                 {
                     const double k = c.contact_margin, size = c.agent_size;
                     const double d0 = px - size - c.wall_xmin, d1 = c.wall_xmax - px - size;
                     const double d2 = py - size - c.wall_ymin, d3 = c.wall_ymax - py - size;
-                    // exact skip: all four clearances > 1000*margin => all penalties +0.0
-                    if (!(d0 > c.wall_skip && d1 > c.wall_skip && d2 > c.wall_skip && d3 > c.wall_skip)) {
-                        // four independent divisions issued back to back (ILP), then the
-                        // three-branch softplus on each
-                        const double t0 = -d0 / k, t1 = -d1 / k, t2 = -d2 / k, t3 = -d3 / k;
-                        const double fx1 = c.contact_force * softplus_pen(t0, k);
-                        const double fx2 = c.contact_force * softplus_pen(t1, k);
-                        const double fy1 = c.contact_force * softplus_pen(t2, k);
-                        const double fy2 = c.contact_force * softplus_pen(t3, k);
+                    // exact skips: a wall whose clearance is > 1000*margin contributes a penalty of
+                    // exactly +0.0 (its division is not needed); if all four do, nothing changes.
+                    const bool w0 = !(d0 > c.wall_skip), w1 = !(d1 > c.wall_skip);
+                    const bool w2 = !(d2 > c.wall_skip), w3 = !(d3 > c.wall_skip);
+                    if (w0 || w1 || w2 || w3) {
+                        double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0;
+                        if (w0) p0 = softplus_pen(-d0 / k, k);
+                        if (w1) p1 = softplus_pen(-d1 / k, k);
+                        if (w2) p2 = softplus_pen(-d2 / k, k);
+                        if (w3) p3 = softplus_pen(-d3 / k, k);
+                        const double fx1 = c.contact_force * p0, fx2 = c.contact_force * p1;
+                        const double fy1 = c.contact_force * p2, fy2 = c.contact_force * p3;
                         Fx = (fx1 - fx2) + Fx;
                         Fy = (fy1 - fy2) + Fy;
                     }
