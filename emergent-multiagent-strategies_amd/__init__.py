@@ -8,6 +8,8 @@ from ._lib import FaError  # noqa: F401
 from .spaces import Box, Discrete, MASpace  # noqa: F401
 from .storage import JointRolloutStorage, RolloutStorage  # noqa: F401
 from .env import BatchedFortAttack, FortAttackGlobalEnv, make_fortattack_env  # noqa: F401
+from .mpnn import MPNN  # noqa: F401
+from .learner import BatchedLearner  # noqa: F401
 
 __all__ = ["BatchedFortAttack", "FortAttackGlobalEnv", "make_fortattack_env", "JointRolloutStorage",
-           "RolloutStorage", "FaError", "Box", "Discrete", "MASpace"]
+           "RolloutStorage", "FaError", "Box", "Discrete", "MASpace", "MPNN", "BatchedLearner"]

@@ -1,0 +1,229 @@
+"""Batched counterpart of the reference's host loop: Learner / Neo / JointPPO over E envs.
+
+What the reference does per env-step in Python -- cat the per-agent observations
+(learner.py:150-152), one MPNN forward per team (:160), chunk the outputs back per agent
+(:164-170, with a ``.cpu().numpy()`` per agent), ``env.step``, seven ``copy_`` per agent into
+its RolloutStorage (storage.py:33-43) -- is here: two MPNN forwards on one contiguous
+``obs[s]`` row each, their outputs written straight into the ``value_preds[s] / actions[s] /
+action_log_probs[s]`` rows, and one ``fa_collect_step`` launch that reads ``actions[s]`` and
+writes ``obs[s+1] / rewards[s] / masks[s+1] / done[s]``.  Nothing leaves the GPU during a
+rollout; the per-step sequence can be replayed from a hipGraph.
+
+  BatchedLearner.collect()      train_fortattack.py:49-110 (rollout + wrap_horizon)
+  BatchedLearner.update()       learner.py:175-188 -> JointPPO.update (ppo.py:116-204)
+  BatchedLearner.after_update() learner.py:234-236 -> storage.py:51-56
+Multi-GPU: env shards per rank; the advantage statistics are all-reduced (dist.py) and the
+gradients of both policies are averaged with one flat all-reduce per optimizer step.
+"""
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+from torch._utils import _flatten_dense_tensors, _unflatten_dense_tensors
+
+from .dist import adv_mean_std
+from .mpnn import MPNN
+from .storage import JointRolloutStorage
+
+
+def ppo_losses(pol, own, opp, actions, value_preds, returns, old_logp, adv, clip_param, clipped_value_loss=True):
+    """The three alive-masked losses of JointPPO.update for one minibatch (ppo.py:146-187).
+    own (B,n,6), opp (B,m,6); the rest (B,n,1).  Works on any device, no host sync: the
+    reference's `if mask.mean() != 0: x /= mask.mean()` becomes a division by
+    where(mean != 0, mean, 1) (x is 0 whenever the mean is 0)."""
+    mask = own[:, :, 0:1]                                      # alive flag = obs[:,0] (ppo.py:224)
+    values, logp, ent = pol.evaluate_actions(own, opp, actions)
+    mm = mask.mean()
+    denom = torch.where(mm != 0, mm, torch.ones_like(mm))
+    dist_entropy = (ent.unsqueeze(-1) * mask).mean() / denom
+    ratio = mask * torch.exp(logp - old_logp)
+    surr1 = ratio * adv
+    surr2 = torch.clamp(ratio, 1.0 - clip_param, 1.0 + clip_param) * adv
+    action_loss = (mask * -torch.min(surr1, surr2)).mean() / denom
+    if clipped_value_loss:
+        vclip = value_preds + (values - value_preds).clamp(-clip_param, clip_param)
+        vl = 0.5 * torch.max((values - returns).pow(2), (vclip - returns).pow(2))
+    else:
+        vl = 0.5 * (returns - values).pow(2)
+    value_loss = (vl * mask).mean() / denom
+    return value_loss, action_loss, dist_entropy
+
+
+class BatchedLearner(object):
+    def __init__(self, eng, num_steps=128, hidden_dim=128, lr=1e-4, clip_param=0.2, ppo_epoch=4,
+                 num_mini_batch=32, value_loss_coef=0.5, entropy_coef=0.01, max_grad_norm=0.5,
+                 gamma=0.99, tau=0.95, clipped_value_loss=True, use_graph=False, group=None):
+        # defaults: arguments.py:22-45
+        self.eng, self.T, self.G, self.A, self.N, self.E = eng, num_steps, eng.G, eng.A, eng.N, eng.E
+        self.device = eng.device
+        self.gamma, self.tau = gamma, tau
+        self.clip_param, self.ppo_epoch, self.num_mini_batch = clip_param, ppo_epoch, num_mini_batch
+        self.value_loss_coef, self.entropy_coef = value_loss_coef, entropy_coef
+        self.max_grad_norm, self.clipped_value_loss = max_grad_norm, clipped_value_loss
+        self.group = group
+        # learner.py:60-68: guards first (policy1), then attackers (policy2); shared per team
+        self.policies = [MPNN(num_agents=self.G, num_opp_agents=self.A, hidden_dim=hidden_dim, num_actions=8),
+                         MPNN(num_agents=self.A, num_opp_agents=self.G, hidden_dim=hidden_dim, num_actions=8)]
+        for p in self.policies:
+            p.to(self.device)
+        self.optimizers = [torch.optim.Adam(p.parameters(), lr=lr) for p in self.policies]  # ppo.py:114
+        self.storage = JointRolloutStorage(num_steps, self.E, self.N, device=self.device)
+        eng.bind_storage(self.storage)
+        self.team_slices = [slice(0, self.G), slice(self.G, self.N)]
+        self.adv = torch.empty((num_steps, self.E, self.N, 1), device=self.device)
+        self.use_graph = use_graph
+        self._graphs = None
+        self.episode_rewards = torch.zeros((self.E, self.N), device=self.device)
+
+    # ---- model I/O (train_fortattack.py:123-128, learner.py:245-249) ----------------------
+    def state_dicts(self):
+        """[N state_dicts]: entries 0..G-1 the guard policy, G..N-1 the attacker policy."""
+        return [self.policies[0].state_dict()] * self.G + [self.policies[1].state_dict()] * self.A
+
+    def load_models(self, policies_list):
+        self.policies[0].load_state_dict(policies_list[0])
+        self.policies[1].load_state_dict(policies_list[-1])
+
+    def save(self, path):
+        torch.save({"models": self.state_dicts(), "ob_rms": (None, None)}, path)
+
+    def load(self, path):
+        self.load_models(torch.load(path, map_location=self.device, weights_only=False)["models"])
+
+    # ---- rollout -------------------------------------------------------------------------
+    def reset(self):
+        """env.reset() + initialize_obs (train_fortattack.py:29,49).  With use_graph the
+        per-step hipGraphs are captured here first: capture needs a few real warm-up steps,
+        and before the first reset the world holds nothing worth keeping."""
+        if self.use_graph and self._graphs is None:
+            if self.eng.max_time_steps < 8:
+                raise ValueError("use_graph needs max_time_steps >= 8 (warm-up steps must not end an episode)")
+            self._graphs = self._capture()
+        self.eng.collect_reset()
+
+    @torch.no_grad()
+    def _act_into_storage(self, s):
+        st = self.storage
+        obs = st.obs[s]
+        for pol, own_sl, opp_sl in ((self.policies[0], self.team_slices[0], self.team_slices[1]),
+                                    (self.policies[1], self.team_slices[1], self.team_slices[0])):
+            value, action, logp = pol.act(obs[:, own_sl], obs[:, opp_sl])
+            st.value_preds[s, :, own_sl] = value
+            st.actions[s, :, own_sl] = action
+            st.action_log_probs[s, :, own_sl] = logp
+
+    def step(self, s):
+        """One env-step of the rollout: act (learner.py:143-172) + env.step + insert."""
+        self._act_into_storage(s)
+        self.eng.collect_step(s, auto_reset=True)
+
+    def _warm_state(self):
+        """A harmless world for the capture warm-up steps: teams on opposite walls facing
+        away from each other (no laser can hit, nobody is near the door, no timeout), so no
+        episode ends and the reset RNG stream is not touched."""
+        import numpy as np
+        E, N, G = self.E, self.N, self.G
+        x = np.concatenate([np.linspace(-0.9, 0.9, G), np.linspace(-0.9, 0.9, self.A)])
+        y = np.concatenate([np.full(G, 0.6), np.full(self.A, -0.6)])
+        ang = np.concatenate([np.full(G, np.pi / 2), np.full(self.A, 3 * np.pi / 2)])
+        tile = lambda v: np.tile(v[None, :], (E, 1))
+        self.eng.set_state(dict(pos_x=tile(x), pos_y=tile(y), vel_x=np.zeros((E, N)), vel_y=np.zeros((E, N)),
+                                ang=tile(ang), prev_dist=np.full((E, N), np.nan),
+                                alive=np.ones((E, N), np.uint8), time_step=np.zeros(E, np.int32)))
+        obs = np.stack([np.ones((E, N)), tile(x), tile(y), tile(ang), np.zeros((E, N)), np.zeros((E, N))], -1)
+        self.storage.obs[:2] = torch.from_numpy(obs.astype(np.float32)).to(self.device)
+
+    def _capture(self):
+        """One hipGraph per rollout index (every launch argument is then a fixed pointer)."""
+        import numpy as np
+        self._warm_state()
+        side = torch.cuda.Stream(self.device)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for s in (0, 1, 0):  # warm up allocator / rocBLAS handles on a side stream
+                self.step(s)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graphs = []
+        pool = None
+        for s in range(self.T):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=pool):
+                self.step(s)
+            pool = g.pool()
+            graphs.append(g)
+        # the warm-up steps set prevDist; it survives resets in the reference (quirk Q1), so put
+        # back "None" -- everything else is rewritten by the reset that follows
+        self.eng.set_state(dict(prev_dist=np.full((self.E, self.N), np.nan)))
+        return graphs
+
+    def collect(self):
+        """A T-step rollout from the current obs[0] + GAE (train_fortattack.py:51-110).
+        Call reset() before the first rollout and after_update() between rollouts."""
+        st = self.storage
+        if self.use_graph and self._graphs is None:
+            raise RuntimeError("call reset() before collect()")
+        for s in range(self.T):
+            if self._graphs is not None:
+                self._graphs[s].replay()
+            else:
+                self.step(s)
+        with torch.no_grad():                      # wrap_horizon: V(obs[T]) (learner.py:196-202)
+            obs = st.obs[self.T]
+            for pol, own_sl, opp_sl in ((self.policies[0], self.team_slices[0], self.team_slices[1]),
+                                        (self.policies[1], self.team_slices[1], self.team_slices[0])):
+                st.value_preds[self.T, :, own_sl] = pol.get_value(obs[:, own_sl], obs[:, opp_sl])
+        self.eng.gae(self.gamma, self.tau)
+        # train_fortattack.py:88: episode_rewards += reward * masks (alive before the step)
+        self.episode_rewards = (st.rewards * st.masks[1:]).sum(0)[..., 0]
+
+    # ---- PPO update (ppo.py:116-204) ------------------------------------------------------------
+    def _allreduce_grads(self, params):
+        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1):
+            return
+        grads = [p.grad for p in params if p.grad is not None]
+        flat = _flatten_dense_tensors(grads)
+        dist.all_reduce(flat, group=self.group)
+        flat.div_(dist.get_world_size(self.group))
+        for g, f in zip(grads, _unflatten_dense_tensors(flat, grads)):
+            g.copy_(f)
+
+    def update(self, train_guards_only=False):
+        """-> float tensor (n_trained_teams, 3) = mean (value_loss, action_loss, entropy)."""
+        st, T, E = self.storage, self.T, self.E
+        mean, std = adv_mean_std(self.eng, self.group)          # ppo.py:121-123 over ALL ranks
+        self.eng.adv_normalize(mean, std, out=self.adv)          # ppo.py:123
+        flat = lambda t: t.view(T * E, *t.shape[2:])
+        obs_f, act_f = flat(st.obs[:-1]), flat(st.actions)
+        vp_f, ret_f = flat(st.value_preds[:-1]), flat(st.returns[:-1])
+        olp_f, adv_f = flat(st.action_log_probs), flat(self.adv)
+        batch = T * E
+        mb = int(batch / self.num_mini_batch)                    # ppo.py:210
+        out = []
+        teams = [0] if train_guards_only else [0, 1]             # learner.py:177
+        for ti in teams:
+            pol, opt = self.policies[ti], self.optimizers[ti]
+            own_sl, opp_sl = self.team_slices[ti], self.team_slices[1 - ti]
+            params = [p for p in pol.parameters()]
+            acc = torch.zeros(3, device=self.device)
+            n_upd = 0
+            for _ in range(self.ppo_epoch):
+                perm = torch.randperm(batch, device=self.device)  # SubsetRandomSampler (ppo.py:213)
+                for k in range(0, batch, mb):                     # BatchSampler, drop_last=False
+                    idx = perm[k:k + mb]
+                    obs_b = obs_f[idx]
+                    own, opp = obs_b[:, own_sl], obs_b[:, opp_sl]
+                    value_loss, action_loss, dist_entropy = ppo_losses(
+                        pol, own, opp, act_f[idx][:, own_sl], vp_f[idx][:, own_sl], ret_f[idx][:, own_sl],
+                        olp_f[idx][:, own_sl], adv_f[idx][:, own_sl], self.clip_param, self.clipped_value_loss)
+                    opt.zero_grad(set_to_none=True)
+                    (value_loss * self.value_loss_coef + action_loss - dist_entropy * self.entropy_coef).backward()
+                    self._allreduce_grads(params)
+                    nn.utils.clip_grad_norm_(params, self.max_grad_norm)
+                    opt.step()
+                    acc += torch.stack([value_loss.detach(), action_loss.detach(), dist_entropy.detach()])
+                    n_upd += 1
+            out.append(acc / n_upd)
+        return torch.stack(out)
+
+    def after_update(self):
+        self.eng.after_update()

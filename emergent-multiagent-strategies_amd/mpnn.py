@@ -1,0 +1,163 @@
+"""MPNN actor-critic (the reference's mpnn.py) for batched rollouts on ROCm.
+
+Stays in PyTorch per the north star (its GEMMs go to rocBLAS/hipBLASLt, i.e. MFMA); what
+changes relative to the reference module is what made it unusable inside a device-resident
+loop, not the math:
+  * input is env-major ``(B, n, 6)`` / ``(B, m, 6)`` -- exactly one row ``obs[s][:, team]`` of
+    the joint rollout buffer, no cat/chunk per agent (learner.py:150-170) and no
+    view/transpose round trip (mpnn.py:132-134, :161);
+  * no ``.cpu().numpy()`` export of the attention matrices inside the forward
+    (mpnn.py:140, :166: two host syncs per call) -- they are returned as tensors on request;
+  * the ``-inf`` diagonal of the team self-attention is a constant buffer, not a Python loop
+    over agents (mpnn.py:297-298).
+The parameter names, shapes and *initialisation order* are the reference's, so a reference
+``state_dict`` loads as is and the same ``torch.manual_seed`` yields the
+same weights.  ``oppUpdate`` is created but unused, exactly as in the reference (mpnn.py:44-45).
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+def _weights_init(m):  # mpnn.py:9-14
+    name = m.__class__.__name__
+    if name.find("Conv") != -1 or name.find("Linear") != -1:
+        nn.init.orthogonal_(m.weight.data)
+        if m.bias is not None:
+            m.bias.data.fill_(0)
+
+
+class _AttnParams(nn.Module):
+    """Parameter container of MultiHeadAttention / MultiHeadOppAttention (mpnn.py:208-249,
+    :335-370): W_query, W_key, W_val (heads, in, key) and W_out (heads, key, embed),
+    uniform(+-1/sqrt(last dim)) in that order."""
+
+    def __init__(self, n_heads, input_dim, embed_dim):
+        super().__init__()
+        key_dim = embed_dim // n_heads
+        self.n_heads, self.input_dim, self.embed_dim, self.key_dim = n_heads, input_dim, embed_dim, key_dim
+        self.norm_factor = 1 / math.sqrt(key_dim)
+        self.W_query = nn.Parameter(torch.Tensor(n_heads, input_dim, key_dim))
+        self.W_key = nn.Parameter(torch.Tensor(n_heads, input_dim, key_dim))
+        self.W_val = nn.Parameter(torch.Tensor(n_heads, input_dim, key_dim))
+        self.W_out = nn.Parameter(torch.Tensor(n_heads, key_dim, embed_dim))
+        for p in self.parameters():
+            stdv = 1.0 / math.sqrt(p.size(-1))
+            p.data.uniform_(-stdv, stdv)
+
+
+class _Categorical(nn.Module):
+    """rlcore/distributions.py:19-31 (the linear head; orthogonal gain 0.01 first, then
+    overwritten by MPNN.apply(weights_init), quirk Q13)."""
+
+    def __init__(self, num_inputs, num_outputs):
+        super().__init__()
+        self.linear = nn.Linear(num_inputs, num_outputs)
+        nn.init.orthogonal_(self.linear.weight.data, gain=0.01)
+        nn.init.constant_(self.linear.bias.data, 0)
+
+    def forward(self, x):
+        return self.linear(x)
+
+
+class MPNN(nn.Module):
+    def __init__(self, action_space=None, num_agents=3, num_opp_agents=3, num_entities=0, input_size=6,
+                 hidden_dim=128, embed_dim=None, pos_index=2, norm_in=False, nonlin=nn.ReLU, n_heads=1,
+                 mask_dist=None, entity_mp=False, policy_layers=1, num_actions=None):
+        super().__init__()
+        if n_heads != 1 or entity_mp or norm_in or policy_layers != 1:
+            raise NotImplementedError("FortAttack uses n_heads=1, entity_mp=False, norm_in=False, "
+                                      "policy_layers=1 (learner.py:62-68)")
+        self.h_dim = hidden_dim
+        self.num_agents, self.num_opp_agents = num_agents, num_opp_agents
+        self.K = 3  # message passing rounds (mpnn.py:27)
+        self.embed_dim = hidden_dim if embed_dim is None else embed_dim
+        self.input_size = input_size
+        half = int(hidden_dim / 2)
+        # construction order == reference (mpnn.py:37-74): RNG draws line up
+        self.encoder = nn.Sequential(nn.Linear(input_size, half), nonlin(inplace=True))
+        self.oppEncoder = nn.Sequential(nn.Linear(input_size, half), nonlin(inplace=True))
+        self.oppAttn = _AttnParams(n_heads, half, int(self.embed_dim / 2))
+        self.oppUpdate = nn.Sequential(nn.Linear(half + int(self.embed_dim / 2), half), nonlin(inplace=True))
+        self.messages = _AttnParams(n_heads, hidden_dim, self.embed_dim)
+        self.update = nn.Sequential(nn.Linear(hidden_dim + self.embed_dim, hidden_dim), nonlin(inplace=True))
+        self.value_head = nn.Sequential(nn.Linear(hidden_dim, hidden_dim), nonlin(inplace=True),
+                                        nn.Linear(hidden_dim, 1))
+        self.policy_head = nn.Sequential(nn.Linear(hidden_dim, hidden_dim), nonlin(inplace=True))
+        if num_actions is None:
+            num_actions = action_space.shape[0]  # mpnn.py:73
+        self.dist = _Categorical(hidden_dim, num_actions)
+        self.is_recurrent = False
+        self.apply(_weights_init)  # mpnn.py:84
+        diag = torch.zeros(num_agents, num_agents)
+        diag.fill_diagonal_(-math.inf)
+        self.register_buffer("_diag", diag, persistent=False)
+
+    # ---- trunk (mpnn.py:117-172 _fwd) ---------------------------------------------------
+    def trunk(self, own, opp, return_attn=False):
+        """own (B, n, 6), opp (B, m, 6) -> h (B, n, h_dim)."""
+        h = self.encoder(own)
+        h_opp = self.oppEncoder(opp)
+        a = self.oppAttn                                   # mpnn.py:372-443
+        q = h_opp @ a.W_query[0]
+        v = h_opp @ a.W_val[0]
+        k = h @ a.W_key[0]
+        opp_attn = F.softmax(a.norm_factor * (k @ q.transpose(1, 2)), dim=-1)
+        e_opp = (opp_attn @ v) @ a.W_out[0]
+        h = torch.cat((h, e_opp), dim=2)
+        m = self.messages                                  # mpnn.py:250-332
+        attn = None
+        for _ in range(self.K):
+            if h.shape[1] == 1:                            # mpnn.py:266-274
+                msg = torch.zeros(h.shape[0], 1, m.embed_dim, device=h.device, dtype=h.dtype)
+                attn = torch.zeros(h.shape[0], 1, 1, device=h.device, dtype=h.dtype)
+            else:
+                qq, kk, vv = h @ m.W_query[0], h @ m.W_key[0], h @ m.W_val[0]
+                comp = m.norm_factor * (qq @ kk.transpose(1, 2)) + self._diag
+                attn = F.softmax(comp, dim=-1)
+                msg = (attn @ vv) @ m.W_out[0]
+            h = self.update(torch.cat((h, msg), 2))
+        if return_attn:
+            return h, attn, opp_attn
+        return h
+
+    def logits_value(self, own, opp):
+        h = self.trunk(own, opp)
+        return self.dist(self.policy_head(h)), self.value_head(h)
+
+    # ---- env-major API used by the batched rollout ---------------------------------------
+    def act(self, own, opp, deterministic=False, generator=None):
+        """-> value (B,n,1), action (B,n,1) int64, action_log_prob (B,n,1)  (mpnn.py:183-192)."""
+        logits, value = self.logits_value(own, opp)
+        logp_all = F.log_softmax(logits, dim=-1)
+        if deterministic:
+            action = logits.argmax(dim=-1, keepdim=True)
+        else:
+            B, n, na = logits.shape
+            action = torch.multinomial(logp_all.exp().view(B * n, na), 1, generator=generator).view(B, n, 1)
+        return value, action, logp_all.gather(-1, action)
+
+    def get_value(self, own, opp):                         # mpnn.py:202-205
+        return self.value_head(self.trunk(own, opp))
+
+    def evaluate_actions(self, own, opp, action):
+        """-> value, log-prob of `action`, per-sample entropy (all (B,n,1)/(B,n))  (mpnn.py:194-200)."""
+        logits, value = self.logits_value(own, opp)
+        logp_all = F.log_softmax(logits, dim=-1)
+        entropy = -(logp_all.exp() * logp_all).sum(-1)
+        return value, logp_all.gather(-1, action), entropy
+
+    # ---- the reference's agent-major calling convention (learner.py:150, mpnn.py:132) ------
+    def _env_major(self, flat, n):
+        return flat.view(n, -1, flat.shape[-1]).transpose(0, 1)
+
+    def evaluate_actions_agent_major(self, inp, opp_inp, action):
+        """inp (n*B, 6), opp_inp (m*B, 6), action (n*B, 1), rows ordered agent-major."""
+        own = self._env_major(inp, self.num_agents)
+        opp = self._env_major(opp_inp, self.num_opp_agents)
+        act = self._env_major(action, self.num_agents)
+        value, logp, ent = self.evaluate_actions(own, opp, act)
+        flat = lambda t: t.transpose(0, 1).reshape(-1, t.shape[-1])
+        return flat(value), flat(logp), ent.transpose(0, 1).reshape(-1)

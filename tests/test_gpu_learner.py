@@ -1,0 +1,92 @@
+"""GPU: the closed-loop batched rollout (MPNN forward -> sample -> fa_collect_step, eager and
+replayed from hipGraphs), checked for consistency against the CPU oracle driven by the
+actions the policies actually sampled, then GAE / PPO update / after_update / checkpoint."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def fa():
+    import emergent_multiagent_strategies_amd as m
+    assert torch.cuda.is_available()
+    m._lib.load()
+    return m
+
+
+def _check_rollout_against_oracle(fa, learner, orc, first):
+    import collector_oracle as co
+    st, T, E, N, G = learner.storage, learner.T, learner.E, learner.N, learner.G
+    obs, rew, msk, done, acts = [getattr(st, k).cpu().numpy() for k in ("obs", "rewards", "masks", "done", "actions")]
+    if first:
+        assert np.array_equal(obs[0], orc.reset().astype(np.float32))
+    ep_start = np.zeros((T, E), bool)
+    for s in range(T):
+        ref = orc.step(acts[s, :, :, 0], auto_reset=True)
+        assert np.array_equal(done[s], ref["done"]), s
+        assert np.array_equal(obs[s + 1], ref["obs"].astype(np.float32)), s
+        assert np.array_equal(rew[s, :, :, 0], ref["reward"].astype(np.float32)), s
+        want_mask = np.where(ref["done"][:, None] != 0, 1, ref["alive_before"]).astype(np.float32)
+        assert np.array_equal(msk[s + 1, :, :, 0], want_mask), s
+        if s + 1 < T:
+            ep_start[s + 1] = ref["done"] != 0
+    # policy-side rows are what the policies compute from the stored observations
+    with torch.no_grad():
+        for ti, (own, opp) in enumerate(((slice(0, G), slice(G, N)), (slice(G, N), slice(0, G)))):
+            pol = learner.policies[ti]
+            v, lp, _ = pol.evaluate_actions(st.obs[:-1].flatten(0, 1)[:, own], st.obs[:-1].flatten(0, 1)[:, opp],
+                                            st.actions.flatten(0, 1)[:, own])
+            assert (v.view(T, E, -1, 1) - st.value_preds[:-1, :, own]).abs().max() < 1e-4
+            assert (lp.view(T, E, -1, 1) - st.action_log_probs[:, :, own]).abs().max() < 1e-4
+            vT = pol.get_value(st.obs[T][:, own], st.obs[T][:, opp])
+            assert (vT - st.value_preds[T, :, own]).abs().max() < 1e-4
+    # GAE over the stored rows == numpy oracle, bit for bit
+    vals, rets = st.value_preds.cpu().numpy(), st.returns.cpu().numpy()
+    return ep_start, rew, vals, msk, rets
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_closed_loop_rollout_and_update(fa, use_graph, tmp_path):
+    import collector_oracle as co
+    from fa_oracle import OracleEnv
+    torch.manual_seed(0)
+    E, G, A, T, max_t = 96, 3, 3, 24, 10
+    N = G + A
+    eng = fa.BatchedFortAttack(E, G, A, max_t, base_seed=21)
+    orc = OracleEnv(E, G, A, max_t, base_seed=21)
+    L = fa.BatchedLearner(eng, num_steps=T, hidden_dim=32, num_mini_batch=4, ppo_epoch=2, use_graph=use_graph)
+    L.reset()
+    stale = np.zeros((T + 1, E, N, 1), np.float32)
+    for upd in range(2):
+        L.collect()
+        ep_start, rew, vals, msk, rets = _check_rollout_against_oracle(fa, L, orc, first=(upd == 0))
+        want = stale.copy()
+        for i in range(N):
+            co.gae_single_pass(rew[:, :, i], vals[:, :, i], msk[:, :, i], want[:, :, i], ep_start, 0.99, 0.95)
+        assert np.array_equal(rets, want)
+        stale = rets
+        assert int(L.storage.done.sum()) > 0
+        before = [p.detach().clone() for p in L.policies[0].parameters()]
+        losses = L.update()
+        assert losses.shape == (2, 3) and bool(torch.isfinite(losses).all())
+        assert any(not torch.equal(b, p) for b, p in zip(before, L.policies[0].parameters()))
+        adv = L.adv.cpu().numpy()
+        for i in range(N):
+            assert np.abs(adv[:, :, i] - co.normalized_advantages(rets[:, :, i], vals[:, :, i])).max() < 2e-5
+        last_obs, last_mask = L.storage.obs[T].clone(), L.storage.masks[T].clone()
+        L.after_update()
+        assert torch.equal(L.storage.obs[0], last_obs) and torch.equal(L.storage.masks[0], last_mask)
+        assert float(L.storage.obs[1:].abs().sum()) == 0.0
+    # checkpoint in the reference's wire format (train_fortattack.py:123-128)
+    path = str(tmp_path / "ep0.pt")
+    L.save(path)
+    ck = torch.load(path, weights_only=False)
+    assert set(ck) == {"models", "ob_rms"} and len(ck["models"]) == N and ck["ob_rms"] == (None, None)
+    L2 = fa.BatchedLearner(fa.BatchedFortAttack(8, G, A, max_t), num_steps=4, hidden_dim=32)
+    L2.load(path)
+    for a, b in zip(L.policies[1].parameters(), L2.policies[1].parameters()):
+        assert torch.equal(a, b)
+    only_guards = L.update(train_guards_only=True)      # train_fortattack_v2 path (learner.py:177)
+    assert only_guards.shape == (1, 3)
