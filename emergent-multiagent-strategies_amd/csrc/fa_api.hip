@@ -17,7 +17,7 @@ hipError_t fa_launch_gae(const float *rewards, const float *value_preds, const f
                          const uint8_t *done, int T, int E, int N, double gamma, double tau, hipStream_t st);
 hipError_t fa_launch_adv_stats(int pass, const float *returns, const float *value_preds, const double *mean,
                                long long rows, int N, double *partial, int nblocks, double *stats,
-                               hipStream_t st);
+                               double *derived, hipStream_t st);
 hipError_t fa_launch_adv_norm(const float *returns, const float *value_preds, const double *mean,
                               const double *std_, long long total, int N, float *out, hipStream_t st);
 
@@ -44,6 +44,7 @@ struct fa_env {
     fa_storage st;
     bool bound;
     double *adv_partial; // [ADV_BLOCKS][N]
+    double *adv_stats;   // [N][3] scratch of fa_adv_mean_std
     int adv_blocks;
 };
 
@@ -210,6 +211,7 @@ int fa_create(const fa_config *cfg, fa_env **out) {
     const size_t o_pos = carve(E * sizeof(int32_t));
     const size_t o_cnt = carve(E * sizeof(uint32_t));
     const size_t o_adv = carve((size_t)env->adv_blocks * FA_MAX_AGENTS * sizeof(double));
+    const size_t o_advs = carve((size_t)FA_MAX_AGENTS * 3 * sizeof(double));
     env->slab_bytes = off;
     hipError_t he = hipMalloc(&env->slab, env->slab_bytes);
     if (he != hipSuccess) {
@@ -234,6 +236,7 @@ int fa_create(const fa_config *cfg, fa_env **out) {
     env->s.mt_pos = reinterpret_cast<int32_t *>(b + o_pos);
     env->s.reset_count = reinterpret_cast<uint32_t *>(b + o_cnt);
     env->adv_partial = reinterpret_cast<double *>(b + o_adv);
+    env->adv_stats = reinterpret_cast<double *>(b + o_advs);
 
     // construction state (core.py:102-104): alive, prevDist None (NaN); positions are
     // defined by the first reset.
@@ -373,7 +376,23 @@ int fa_adv_stats(fa_env *env, int32_t pass, const double *mean, double *stats, v
     long long want = (rows + 255) / 256;
     const int nblocks = (int)(want < env->adv_blocks ? want : env->adv_blocks);
     FA_HIP(fa_launch_adv_stats(pass, st.returns, st.value_preds, mean, rows, env->N, env->adv_partial,
-                               nblocks, stats, static_cast<hipStream_t>(stream)));
+                               nblocks, stats, nullptr, static_cast<hipStream_t>(stream)));
+    return FA_OK;
+}
+
+int fa_adv_mean_std(fa_env *env, double *mean_out, double *std_out, void *stream) {
+    if (!env || !mean_out || !std_out) return fail(FA_ERR_INVALID, "fa_adv_mean_std: null argument");
+    if (!env->bound) return fail(FA_ERR_STATE, "fa_adv_mean_std: no storage bound");
+    DeviceGuard guard(env->cfg.device_id);
+    const fa_storage &st = env->st;
+    const long long rows = (long long)st.num_steps * env->cfg.num_envs;
+    long long want = (rows + 255) / 256;
+    const int nblocks = (int)(want < env->adv_blocks ? want : env->adv_blocks);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    FA_HIP(fa_launch_adv_stats(0, st.returns, st.value_preds, nullptr, rows, env->N, env->adv_partial, nblocks,
+                               env->adv_stats, mean_out, s));
+    FA_HIP(fa_launch_adv_stats(1, st.returns, st.value_preds, mean_out, rows, env->N, env->adv_partial, nblocks,
+                               env->adv_stats, std_out, s));
     return FA_OK;
 }
 

@@ -42,7 +42,10 @@ __global__ __launch_bounds__(64) void fa_gae_kernel(const float *__restrict__ re
             r[k] = rewards[o];
             v[k] = value_preds[o];
             m[k] = masks[o];
-            skip[k] = in && t > 0 && done[(long long)(t - 1) * E + e] != 0;
+            // unconditional, clamped load (a short-circuit here becomes a branch + vmcnt(0) per
+            // step and serialises the whole chunk)
+            const uint8_t dflag = done[(long long)(t > 0 ? t - 1 : 0) * E + e];
+            skip[k] = (t > 0) & (dflag != 0);
         }
 #pragma unroll
         for (int k = 0; k < FA_GAE_CHUNK; ++k) {
@@ -55,6 +58,73 @@ __global__ __launch_bounds__(64) void fa_gae_kernel(const float *__restrict__ re
                 } else {
                     gae = g;
                     returns[(long long)t * EN + col] = g + v[k];
+                }
+                v_next = v[k];
+                m_next = m[k];
+            }
+        }
+    }
+}
+
+// Four adjacent columns per lane: 16-byte loads (1 KiB per wave instruction instead of
+// 256 B) and four independent scan chains per lane.  Same arithmetic per column as above.
+#define FA_GAE4_CHUNK 16
+__global__ __launch_bounds__(64) void fa_gae4_kernel(const float *__restrict__ rewards,
+                                                     const float *__restrict__ value_preds,
+                                                     const float *__restrict__ masks,
+                                                     float *__restrict__ returns,
+                                                     const uint8_t *__restrict__ done, int T, int E,
+                                                     int N, float g32, float gt32) {
+    const long long EN = (long long)E * N;
+    const long long col = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (col >= EN) return;
+    int e[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) e[q] = (int)((col + q) / N);
+    float gae[4] = {0.f, 0.f, 0.f, 0.f};
+    float4 v_next = *reinterpret_cast<const float4 *>(value_preds + (long long)T * EN + col);
+    float4 m_next = *reinterpret_cast<const float4 *>(masks + (long long)T * EN + col);
+    for (int t0 = T - 1; t0 >= 0; t0 -= FA_GAE4_CHUNK) {
+        float4 r[FA_GAE4_CHUNK], v[FA_GAE4_CHUNK], m[FA_GAE4_CHUNK];
+        unsigned skip[FA_GAE4_CHUNK];
+#pragma unroll
+        for (int k = 0; k < FA_GAE4_CHUNK; ++k) {
+            const int t = t0 - k;
+            const bool in = t >= 0;
+            const long long o = (long long)(in ? t : 0) * EN + col;
+            r[k] = *reinterpret_cast<const float4 *>(rewards + o);
+            v[k] = *reinterpret_cast<const float4 *>(value_preds + o);
+            m[k] = *reinterpret_cast<const float4 *>(masks + o);
+            unsigned sk = 0;
+            const uint8_t *d = done + (long long)(t > 0 ? t - 1 : 0) * E;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) sk |= ((unsigned)(t > 0) & (unsigned)(d[e[q]] != 0)) << q;
+            skip[k] = sk;
+        }
+#pragma unroll
+        for (int k = 0; k < FA_GAE4_CHUNK; ++k) {
+            const int t = t0 - k;
+            if (t >= 0) {
+                const float rr[4] = {r[k].x, r[k].y, r[k].z, r[k].w};
+                const float vv[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+                const float vn[4] = {v_next.x, v_next.y, v_next.z, v_next.w};
+                const float mn[4] = {m_next.x, m_next.y, m_next.z, m_next.w};
+                float out[4];
+                float *ret = returns + (long long)t * EN + col;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float delta = rr[q] + g32 * vn[q] * mn[q] - vv[q];
+                    const float g = delta + gt32 * mn[q] * gae[q];
+                    const bool sk = (skip[k] >> q) & 1u;
+                    gae[q] = sk ? 0.0f : g;
+                    out[q] = g + vv[q];
+                }
+                if (skip[k] == 0u) {
+                    *reinterpret_cast<float4 *>(ret) = make_float4(out[0], out[1], out[2], out[3]);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (!((skip[k] >> q) & 1u)) ret[q] = out[q];
                 }
                 v_next = v[k];
                 m_next = m[k];
@@ -111,7 +181,7 @@ __global__ __launch_bounds__(256) void fa_adv_partial_kernel(const float *__rest
 // folds partials l, l+64, ... in order, then a fixed shuffle tree => reproducible.
 template <int PASS>
 __global__ void fa_adv_final_kernel(const double *__restrict__ partial, int nblocks, int N, double n_rows,
-                                    double *__restrict__ stats) {
+                                    double *__restrict__ stats, double *__restrict__ derived) {
     const int i = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (i >= N) return;
     double s = 0.0;
@@ -119,8 +189,13 @@ __global__ void fa_adv_final_kernel(const double *__restrict__ partial, int nblo
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
     if (lane == 0) {
-        if (PASS == 0) { stats[i * 3 + 0] = n_rows; stats[i * 3 + 1] = s; stats[i * 3 + 2] = 0.0; }
-        else stats[i * 3 + 2] = s;
+        if (PASS == 0) {
+            stats[i * 3 + 0] = n_rows; stats[i * 3 + 1] = s; stats[i * 3 + 2] = 0.0;
+            if (derived) derived[i] = s / n_rows;                           // local mean
+        } else {
+            stats[i * 3 + 2] = s;
+            if (derived) derived[i] = sqrt(s / (n_rows - 1.0));             // local unbiased std
+        }
     }
 }
 
@@ -141,25 +216,35 @@ __global__ __launch_bounds__(256) void fa_adv_norm_kernel(const float *__restric
 hipError_t fa_launch_gae(const float *rewards, const float *value_preds, const float *masks, float *returns,
                          const uint8_t *done, int T, int E, int N, double gamma, double tau, hipStream_t st) {
     const long long EN = (long long)E * N;
-    const int grid = (int)((EN + 63) / 64);
-    hipLaunchKernelGGL(fa_gae_kernel, dim3(grid), dim3(64), 0, st, rewards, value_preds, masks, returns,
-                       done, T, E, N, (float)gamma, (float)(gamma * tau));
+    // four columns per lane pay off only once there are enough columns to fill the chip with
+    // 16-byte lanes; below that the one-column kernel has 4x the waves in flight
+    const bool vec4 = (EN >= 4LL * 64 * 1024) && (EN % 4 == 0) && ((((uintptr_t)rewards | (uintptr_t)value_preds | (uintptr_t)masks |
+                                          (uintptr_t)returns) & 15) == 0);
+    if (vec4) {
+        const int grid = (int)((EN / 4 + 63) / 64);
+        hipLaunchKernelGGL(fa_gae4_kernel, dim3(grid), dim3(64), 0, st, rewards, value_preds, masks, returns,
+                           done, T, E, N, (float)gamma, (float)(gamma * tau));
+    } else {
+        const int grid = (int)((EN + 63) / 64);
+        hipLaunchKernelGGL(fa_gae_kernel, dim3(grid), dim3(64), 0, st, rewards, value_preds, masks, returns,
+                           done, T, E, N, (float)gamma, (float)(gamma * tau));
+    }
     return hipGetLastError();
 }
 
 hipError_t fa_launch_adv_stats(int pass, const float *returns, const float *value_preds, const double *mean,
                                long long rows, int N, double *partial, int nblocks, double *stats,
-                               hipStream_t st) {
+                               double *derived, hipStream_t st) {
     if (pass == 0) {
         hipLaunchKernelGGL(fa_adv_partial_kernel<0>, dim3(nblocks), dim3(256), 0, st, returns, value_preds,
                            mean, rows, N, partial);
         hipLaunchKernelGGL(fa_adv_final_kernel<0>, dim3(1), dim3(64 * N), 0, st, partial, nblocks, N,
-                           (double)rows, stats);
+                           (double)rows, stats, derived);
     } else {
         hipLaunchKernelGGL(fa_adv_partial_kernel<1>, dim3(nblocks), dim3(256), 0, st, returns, value_preds,
                            mean, rows, N, partial);
         hipLaunchKernelGGL(fa_adv_final_kernel<1>, dim3(1), dim3(64 * N), 0, st, partial, nblocks, N,
-                           (double)rows, stats);
+                           (double)rows, stats, derived);
     }
     return hipGetLastError();
 }

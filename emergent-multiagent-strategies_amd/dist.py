@@ -33,6 +33,8 @@ def two_pass_mean_std(pass0, pass1, group=None):
 
 def adv_mean_std(eng, group=None):
     """Global per-agent advantage mean / std for the storage bound to `eng` (fa_adv_stats)."""
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
+        return eng.adv_mean_std()                      # one rank: four launches, no torch glue
     mean, std, _ = two_pass_mean_std(lambda: eng.adv_stats(0),
                                      lambda m: eng.adv_stats(1, mean=m)[:, 2], group)
     return mean, std

@@ -142,6 +142,14 @@ class BatchedFortAttack(object):
         _lib.check(self._lib.fa_adv_stats(self._h, int(pass_), _ptr(mean), _ptr(out), _stream()), "fa_adv_stats")
         return out
 
+    def adv_mean_std(self):
+        """fa_adv_mean_std: per-agent mean / unbiased std of this handle's advantages (N,), on device."""
+        if not hasattr(self, "_adv_ms"):
+            self._adv_ms = torch.zeros((2, self.N), dtype=torch.float64, device=self.device)
+        _lib.check(self._lib.fa_adv_mean_std(self._h, _ptr(self._adv_ms[0]), _ptr(self._adv_ms[1]), _stream()),
+                   "fa_adv_mean_std")
+        return self._adv_ms[0], self._adv_ms[1]
+
     def adv_normalize(self, mean, std, out=None):
         if out is None:
             out = self._new((self.storage.num_steps, self.E, self.N, 1), torch.float32)

@@ -184,6 +184,10 @@ int fa_gae(fa_env *env, double gamma, double tau, void *stream);
  * stats: device (N,3) doubles; mean: device (N) doubles.  The only quantities that
  * cross GPUs (all-reduce sum of `stats`). */
 int fa_adv_stats(fa_env *env, int32_t pass, const double *mean, double *stats, void *stream);
+/* Single-GPU form of ppo.py:122-123: both passes on this handle's samples only; writes
+ * mean[i] and the unbiased std[i] (device, N doubles each).  With several GPUs use
+ * fa_adv_stats and all-reduce between the passes instead. */
+int fa_adv_mean_std(fa_env *env, double *mean_out, double *std_out, void *stream);
 /* ppo.py:123: adv_out (T,E,N) = (A - mean[i]) / (std[i] + 1e-5), float32. */
 int fa_adv_normalize(fa_env *env, const double *mean, const double *std, float *adv_out, void *stream);
 /* RolloutStorage.after_update (storage.py:51-56). */

@@ -104,6 +104,8 @@ def test_gae_and_stats_vs_numpy_oracle(fa, E, G, A, T):
     adv = eng.adv_normalize(mean, std).cpu().numpy()
     for i in range(N):
         assert np.abs(adv[:, :, i] - co.normalized_advantages(want[:, :, i], values[:, :, i])).max() < 2e-6
+    m2, s2 = eng.adv_mean_std()                              # single-GPU fused form
+    assert torch.equal(m2, mean) and torch.allclose(s2, std, rtol=1e-14, atol=0)
     # run-to-run determinism of the two-stage reduction
     assert torch.equal(eng.adv_stats(0), s0)
 
