@@ -325,8 +325,9 @@ __global__ __launch_bounds__(FA_WAVE) void fa_step_kernel(FaStepArgs a) {
                     const double k = c.contact_margin, size = c.agent_size;
                     const double d0 = px - size - c.wall_xmin, d1 = c.wall_xmax - px - size;
                     const double d2 = py - size - c.wall_ymin, d3 = c.wall_ymax - py - size;
-                    // exact skips: a wall whose clearance is > 1000*margin contributes a penalty of
-                    // exactly +0.0 (its division is not needed); if all four do, nothing changes.
+                    // a wall whose clearance is > 1000*margin contributes exactly +0.0 and its division
+                    // is skipped; measured: per-wall branches beat four unconditional ILP divisions
+                    // (typically only one or two walls are touched by some lane of the wave)
                     const bool w0 = !(d0 > c.wall_skip), w1 = !(d1 > c.wall_skip);
                     const bool w2 = !(d2 > c.wall_skip), w3 = !(d3 > c.wall_skip);
                     if (w0 || w1 || w2 || w3) {
