@@ -100,24 +100,33 @@ class MPNN(nn.Module):
         """own (B, n, 6), opp (B, m, 6) -> h (B, n, h_dim)."""
         h = self.encoder(own)
         h_opp = self.oppEncoder(opp)
+        # Projections that share an input are one GEMM (weights concatenated on the fly: the
+        # parameters stay separate so reference state_dicts load), and the n x m attention is a
+        # broadcast multiply-sum: per-env (3x64)@(64x3) batched GEMMs over thousands of envs are
+        # the slowest way to spend MFMA time.
         a = self.oppAttn                                   # mpnn.py:372-443
-        q = h_opp @ a.W_query[0]
-        v = h_opp @ a.W_val[0]
+        kd = a.key_dim
+        qv = h_opp @ torch.cat((a.W_query[0], a.W_val[0]), dim=1)
+        q, v = qv[..., :kd], qv[..., kd:]
         k = h @ a.W_key[0]
-        opp_attn = F.softmax(a.norm_factor * (k @ q.transpose(1, 2)), dim=-1)
-        e_opp = (opp_attn @ v) @ a.W_out[0]
+        scores = (k.unsqueeze(2) * q.unsqueeze(1)).sum(-1)             # (B, n, m)
+        opp_attn = F.softmax(a.norm_factor * scores, dim=-1)
+        e_opp = (opp_attn.unsqueeze(-1) * v.unsqueeze(1)).sum(2) @ a.W_out[0]
         h = torch.cat((h, e_opp), dim=2)
         m = self.messages                                  # mpnn.py:250-332
         attn = None
+        if h.shape[1] > 1:
+            w_qkv = torch.cat((m.W_query[0], m.W_key[0], m.W_val[0]), dim=1)
         for _ in range(self.K):
             if h.shape[1] == 1:                            # mpnn.py:266-274
                 msg = torch.zeros(h.shape[0], 1, m.embed_dim, device=h.device, dtype=h.dtype)
                 attn = torch.zeros(h.shape[0], 1, 1, device=h.device, dtype=h.dtype)
             else:
-                qq, kk, vv = h @ m.W_query[0], h @ m.W_key[0], h @ m.W_val[0]
-                comp = m.norm_factor * (qq @ kk.transpose(1, 2)) + self._diag
+                qkv = h @ w_qkv
+                qq, kk, vv = qkv[..., :m.key_dim], qkv[..., m.key_dim:2 * m.key_dim], qkv[..., 2 * m.key_dim:]
+                comp = m.norm_factor * (qq.unsqueeze(2) * kk.unsqueeze(1)).sum(-1) + self._diag
                 attn = F.softmax(comp, dim=-1)
-                msg = (attn @ vv) @ m.W_out[0]
+                msg = (attn.unsqueeze(-1) * vv.unsqueeze(1)).sum(2) @ m.W_out[0]
             h = self.update(torch.cat((h, msg), 2))
         if return_attn:
             return h, attn, opp_attn
@@ -135,8 +144,12 @@ class MPNN(nn.Module):
         if deterministic:
             action = logits.argmax(dim=-1, keepdim=True)
         else:
-            B, n, na = logits.shape
-            action = torch.multinomial(logp_all.exp().view(B * n, na), 1, generator=generator).view(B, n, 1)
+            # inverse-CDF sampling: same categorical distribution as torch.multinomial
+            # (FixedCategorical.sample, distributions.py:12-13) without its host-visible
+            # validity assert and extra reductions
+            cdf = logp_all.exp().cumsum(-1)
+            u = torch.rand(cdf.shape[:-1] + (1,), device=cdf.device, dtype=cdf.dtype, generator=generator)
+            action = (u > cdf).sum(-1, keepdim=True).clamp_(max=logits.shape[-1] - 1)
         return value, action, logp_all.gather(-1, action)
 
     def get_value(self, own, opp):                         # mpnn.py:202-205
