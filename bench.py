@@ -173,6 +173,20 @@ def main():
     bytes_per_launch = algorithmic_bytes_per_env_step(N) * E * (T // launches_per_rollout)
     achieved = bytes_per_launch / launch_s / 1e9
 
+    # HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this
+    # same command (tools/profile_gpu.sh -> tools/summarize_prof.py; FETCH_SIZE x2 + WRITE_SIZE,
+    # MI355X_MICROARCH.md); only attached when the run uses the profiled configuration.
+    traffic, traffic_src = None, None
+    prof = os.path.join(ROOT, "profiles", "r01_%s_summary.json" % ("fused" if graph is None else "perstep"))
+    if (E, G, A, T) == (4096, 3, 3, 128) and os.path.isfile(prof):
+        try:
+            ks = json.load(open(prof))["kernels"]
+            k = [v for n, v in ks.items() if "fa_step_kernel<3, 3, false" in n and "hbm_bytes_per_launch" in v]
+            if k:
+                traffic, traffic_src = k[0]["hbm_bytes_per_launch"], os.path.relpath(prof, ROOT)
+        except Exception:
+            pass
+
     if rank == 0:
         res = {
             "metric": "env-steps/sec FortAttack %dv%d, %d parallel envs per GPU" % (G, A, E),
@@ -195,7 +209,8 @@ def main():
                 "bound": "hbm", "kernel": "fa_step_kernel<%d,%d>" % (G if (G, A) in ((3, 3), (5, 5)) else 0,
                                                                    A if (G, A) in ((3, 3), (5, 5)) else 0),
                 "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                "traffic": None,
+                "traffic": traffic, "traffic_source": traffic_src,
+                "algorithmic_bytes_per_launch": bytes_per_launch,
                 "algorithmic_bytes_per_env_step": algorithmic_bytes_per_env_step(N),
                 "env_steps_per_launch": E * (T // launches_per_rollout),
                 "avg_launch_us": launch_s * 1e6, "timed_by": "hipEvents on the launch stream, %d launches" % (
