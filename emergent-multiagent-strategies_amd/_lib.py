@@ -44,7 +44,7 @@ class Storage(C.Structure):
 class StateHost(C.Structure):
     _fields_ = [(n, c_p) for n in (
         "pos_x", "pos_y", "vel_x", "vel_y", "ang", "prev_dist", "alive", "time_step", "num_hit",
-        "num_was_hit", "game_result", "result_count")]
+        "num_was_hit", "game_result", "result_count", "episode_reward_sum", "alive_at_end")]
 
 
 FA_RNG_MT19937, FA_RNG_PHILOX = 0, 1

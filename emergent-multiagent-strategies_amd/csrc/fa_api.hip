@@ -210,6 +210,8 @@ int fa_create(const fa_config *cfg, fa_env **out) {
     const size_t o_mt = carve(E * FA_MT_N * sizeof(uint32_t));
     const size_t o_pos = carve(E * sizeof(int32_t));
     const size_t o_cnt = carve(E * sizeof(uint32_t));
+    const size_t o_epr = carve(2 * EN * sizeof(double));
+    const size_t o_ale = carve(EN * sizeof(uint32_t));
     const size_t o_adv = carve((size_t)env->adv_blocks * FA_MAX_AGENTS * sizeof(double));
     const size_t o_advs = carve((size_t)FA_MAX_AGENTS * 3 * sizeof(double));
     env->slab_bytes = off;
@@ -235,6 +237,9 @@ int fa_create(const fa_config *cfg, fa_env **out) {
     env->s.mt = reinterpret_cast<uint32_t *>(b + o_mt);
     env->s.mt_pos = reinterpret_cast<int32_t *>(b + o_pos);
     env->s.reset_count = reinterpret_cast<uint32_t *>(b + o_cnt);
+    env->s.ep_rew = reinterpret_cast<double *>(b + o_epr);
+    env->s.ep_rew_sum = env->s.ep_rew + EN;
+    env->s.alive_end = reinterpret_cast<uint32_t *>(b + o_ale);
     env->adv_partial = reinterpret_cast<double *>(b + o_adv);
     env->adv_stats = reinterpret_cast<double *>(b + o_advs);
 
@@ -445,6 +450,14 @@ int fa_get_state(fa_env *env, const fa_state_host *o) {
     FA_D2H(o->num_was_hit, s.num_was_hit, EN * 4);
     FA_D2H(o->game_result, s.game_result, E * 3);
 #undef FA_D2H
+#define FA_D2H_LATE(dst, src, bytes) \
+    if (dst) FA_HIP(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost))
+    FA_D2H_LATE(o->episode_reward_sum, s.ep_rew_sum, EN * 8);
+    if (o->alive_at_end) {
+        std::vector<uint32_t> ae(EN);
+        FA_HIP(hipMemcpy(ae.data(), s.alive_end, EN * 4, hipMemcpyDeviceToHost));
+        for (size_t k = 0; k < EN; ++k) o->alive_at_end[k] = (int64_t)ae[k];
+    }
     if (o->result_count) {
         std::vector<uint32_t> rc(E * 3);
         FA_HIP(hipMemcpy(rc.data(), s.result_count, E * 3 * 4, hipMemcpyDeviceToHost));

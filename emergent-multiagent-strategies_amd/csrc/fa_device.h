@@ -42,6 +42,8 @@ struct FaState {
     uint32_t *mt;                            // (E,624)
     int32_t *mt_pos;                         // (E)
     uint32_t *reset_count;                   // (E)   Philox counter
+    double *ep_rew, *ep_rew_sum;             // (E,N) running / finished-episode sum of reward*mask
+    uint32_t *alive_end;                     // (E,N) episodes this agent was alive at the end of
 };
 
 struct FaStepArgs {

@@ -154,12 +154,13 @@ __global__ __launch_bounds__(FA_WAVE) void fa_step_kernel(FaStepArgs a) {
     double px = 0, py = 0, vx = 0, vy = 0, ang = 0, prev = 0;
     bool alive = false;
     int t = 0, nh = 0, nwh = 0;
+    double ep_rew = 0.0; // episode return so far (reward * alive-before mask), track_counters only
     if (valid) {
         px = a.s.px[idx]; py = a.s.py[idx]; vx = a.s.vx[idx]; vy = a.s.vy[idx];
         ang = a.s.ang[idx]; prev = a.s.prev[idx];
         alive = a.s.alive[idx] != 0;
         t = a.s.tstep[e];
-        if (a.track_counters) { nh = a.s.num_hit[idx]; nwh = a.s.num_was_hit[idx]; }
+        if (a.track_counters) { nh = a.s.num_hit[idx]; nwh = a.s.num_was_hit[idx]; ep_rew = a.s.ep_rew[idx]; }
     }
     bool dirty = false; // state changed => write it back
 
@@ -409,6 +410,17 @@ __global__ __launch_bounds__(FA_WAVE) void fa_step_kernel(FaStepArgs a) {
                 if (COLLECT || a.done) a.done[(size_t)s * a.E + e] = done ? 1 : 0;
             }
             t += 1;
+            // evaluation statistics (test_fortattack_v2.py:88-101): episode_rewards += reward*mask;
+            // at the end of an episode: who is alive, and the episode's return per agent
+            if (a.track_counters) {
+                ep_rew += alive0 ? rew : 0.0;
+                if (done) {
+                    a.s.ep_rew_sum[idx] += ep_rew;
+                    if (alive1) a.s.alive_end[idx] += 1u;
+                    ep_rew = 0.0;
+                    dirty = true;
+                }
+            }
             do_reset = valid && done && a.auto_reset != 0;
             dirty = dirty || alive0;
             alive = alive1;
@@ -480,7 +492,7 @@ __global__ __launch_bounds__(FA_WAVE) void fa_step_kernel(FaStepArgs a) {
         a.s.px[idx] = px; a.s.py[idx] = py; a.s.vx[idx] = vx; a.s.vy[idx] = vy;
         a.s.ang[idx] = ang; a.s.prev[idx] = prev;
         a.s.alive[idx] = alive ? 1 : 0;
-        if (a.track_counters) { a.s.num_hit[idx] = nh; a.s.num_was_hit[idx] = nwh; }
+        if (a.track_counters) { a.s.num_hit[idx] = nh; a.s.num_was_hit[idx] = nwh; a.s.ep_rew[idx] = ep_rew; }
     }
     if (valid && i == 0 && (!RESET_ONLY || dirty)) a.s.tstep[e] = t;
 }

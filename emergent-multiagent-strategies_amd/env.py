@@ -168,12 +168,31 @@ class BatchedFortAttack(object):
         s = {k: np.empty((E, N), np.float64) for k in self._F64}
         s.update(alive=np.empty((E, N), np.uint8), time_step=np.empty(E, np.int32),
                  num_hit=np.empty((E, N), np.int32), num_was_hit=np.empty((E, N), np.int32),
-                 game_result=np.empty((E, 3), np.uint8), result_count=np.empty((E, 3), np.int64))
+                 game_result=np.empty((E, 3), np.uint8), result_count=np.empty((E, 3), np.int64),
+                 episode_reward_sum=np.empty((E, N), np.float64), alive_at_end=np.empty((E, N), np.int64))
         sh = _lib.StateHost()
         for k, v in s.items():
             setattr(sh, k, v.ctypes.data_as(C.c_void_p))
         _lib.check(self._lib.fa_get_state(self._h, C.byref(sh)), "fa_get_state")
         return s
+
+    def eval_stats(self):
+        """The row the reference's evaluation prints per attacker strategy
+        (test_fortattack_v2.py:94-101, mean over finished episodes):
+        [all attackers dead, timeout, guards win (sum of the two), attacker reached fort,
+         guards alive at the end, attackers alive at the end, mean guard return, mean attacker return]
+        -- computed from device-side counters over every env of this handle."""
+        s = self.get_state()
+        rc = s["result_count"].sum(0).astype(np.float64)
+        n_ep = rc.sum()
+        if n_ep == 0:
+            return np.zeros(8), 0
+        G = self.G
+        alive = s["alive_at_end"].sum(0) / n_ep
+        rew = s["episode_reward_sum"].sum(0) / n_ep
+        row = np.array([rc[0] / n_ep, rc[1] / n_ep, (rc[0] + rc[1]) / n_ep, rc[2] / n_ep,
+                        alive[:G].sum(), alive[G:].sum(), rew[:G].mean(), rew[G:].mean()])
+        return row, int(n_ep)
 
     def set_state(self, s):
         keep = []

@@ -73,6 +73,7 @@ class BatchedLearner(object):
         self.use_graph = use_graph
         self._graphs = None
         self.episode_rewards = torch.zeros((self.E, self.N), device=self.device)
+        self.attacker_pool, self.attacker_id = [], None
 
     # ---- model I/O (train_fortattack.py:123-128, learner.py:245-249) ----------------------
     def state_dicts(self):
@@ -88,6 +89,38 @@ class BatchedLearner(object):
 
     def load(self, path):
         self.load_models(torch.load(path, map_location=self.device, weights_only=False)["models"])
+
+    # ---- ensemble of frozen attacker strategies (train_fortattack_v2.py, learner.py:119-140) ----
+    def load_attacker_ensemble(self, checkpoints, hidden_dim=128):
+        """checkpoints: list of paths (reference `ep*.pt` files), checkpoint dicts, or attacker
+        state_dicts.  Every env plays against one of the K strategies; the strategy of an env is
+        re-drawn uniformly each time that env's episode ends (the reference re-draws after every
+        episode of its single env, train_fortattack_v2.py:104-111).  Train with
+        update(train_guards_only=True)."""
+        pool = []
+        for ck in checkpoints:
+            if isinstance(ck, str):
+                ck = torch.load(ck, map_location="cpu", weights_only=False)
+            sd = ck["models"][-1] if isinstance(ck, dict) and "models" in ck else ck   # learner.py:137-139
+            pol = MPNN(num_agents=self.A, num_opp_agents=self.G, hidden_dim=hidden_dim, num_actions=8)
+            pol.load_state_dict(sd)
+            pol.to(self.device).eval()
+            for p in pol.parameters():
+                p.requires_grad_(False)
+            pool.append(pol)
+        if self._graphs is not None:
+            raise RuntimeError("load the ensemble before the first reset() when use_graph is set")
+        self.attacker_pool = pool
+        self.attacker_id = torch.randint(len(pool), (self.E,), device=self.device)
+
+    def _attacker_forward(self, fn_name, own, opp):
+        """Run every strategy on the whole batch and keep, per env, the output of that env's."""
+        outs = [getattr(pol, fn_name)(own, opp) for pol in self.attacker_pool]
+        sel = self.attacker_id
+        pick = lambda ts: torch.stack(ts, 0)[sel, torch.arange(self.E, device=self.device)]
+        if isinstance(outs[0], tuple):
+            return tuple(pick([o[k] for o in outs]) for k in range(len(outs[0])))
+        return pick(outs)
 
     # ---- rollout -------------------------------------------------------------------------
     def reset(self):
@@ -106,7 +139,10 @@ class BatchedLearner(object):
         obs = st.obs[s]
         for pol, own_sl, opp_sl in ((self.policies[0], self.team_slices[0], self.team_slices[1]),
                                     (self.policies[1], self.team_slices[1], self.team_slices[0])):
-            value, action, logp = pol.act(obs[:, own_sl], obs[:, opp_sl])
+            if pol is self.policies[1] and self.attacker_pool:
+                value, action, logp = self._attacker_forward("act", obs[:, own_sl], obs[:, opp_sl])
+            else:
+                value, action, logp = pol.act(obs[:, own_sl], obs[:, opp_sl])
             st.value_preds[s, :, own_sl] = value
             st.actions[s, :, own_sl] = action
             st.action_log_probs[s, :, own_sl] = logp
@@ -115,6 +151,9 @@ class BatchedLearner(object):
         """One env-step of the rollout: act (learner.py:143-172) + env.step + insert."""
         self._act_into_storage(s)
         self.eng.collect_step(s, auto_reset=True)
+        if self.attacker_pool:   # sample_attacker() after every episode end (train_fortattack_v2.py:110-111)
+            fresh = torch.randint(len(self.attacker_pool), (self.E,), device=self.device)
+            self.attacker_id.copy_(torch.where(self.storage.done[s] != 0, fresh, self.attacker_id))  # in place: graph-safe
 
     def _warm_state(self):
         """A harmless world for the capture warm-up steps: teams on opposite walls facing
@@ -171,7 +210,10 @@ class BatchedLearner(object):
             obs = st.obs[self.T]
             for pol, own_sl, opp_sl in ((self.policies[0], self.team_slices[0], self.team_slices[1]),
                                         (self.policies[1], self.team_slices[1], self.team_slices[0])):
-                st.value_preds[self.T, :, own_sl] = pol.get_value(obs[:, own_sl], obs[:, opp_sl])
+                if pol is self.policies[1] and self.attacker_pool:
+                    st.value_preds[self.T, :, own_sl] = self._attacker_forward("get_value", obs[:, own_sl], obs[:, opp_sl])
+                else:
+                    st.value_preds[self.T, :, own_sl] = pol.get_value(obs[:, own_sl], obs[:, opp_sl])
         self.eng.gae(self.gamma, self.tau)
         # train_fortattack.py:88: episode_rewards += reward * masks (alive before the step)
         self.episode_rewards = (st.rewards * st.masks[1:]).sum(0)[..., 0]

@@ -135,6 +135,11 @@ typedef struct fa_state_host {
                                                                  last finished episode */
     int64_t *result_count;                                    /* (E,3) finished episodes by
                                                                  ending since fa_create */
+    /* evaluation statistics of test_fortattack_v2.py:88-101, summed over the finished episodes
+     * of each env (track_counters only): sum of per-episode returns (reward * alive-before
+     * mask, train_fortattack.py:88) and number of episodes the agent was alive at the end of */
+    double *episode_reward_sum;                               /* (E,N) */
+    int64_t *alive_at_end;                                    /* (E,N) */
 } fa_state_host;
 
 /* ---- lifecycle ---------------------------------------------------------------- */

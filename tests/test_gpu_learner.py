@@ -90,3 +90,43 @@ def test_closed_loop_rollout_and_update(fa, use_graph, tmp_path):
         assert torch.equal(a, b)
     only_guards = L.update(train_guards_only=True)      # train_fortattack_v2 path (learner.py:177)
     assert only_guards.shape == (1, 3)
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_ensemble_attackers_per_env_strategy(fa, use_graph):
+    """Config-5 path (train_fortattack_v2.py): frozen attacker strategies, one per env, re-drawn
+    at that env's episode end; guards only are trained."""
+    torch.manual_seed(1)
+    E, G, A, T, max_t = 64, 3, 3, 20, 9
+    eng = fa.BatchedFortAttack(E, G, A, max_t, base_seed=4)
+    L = fa.BatchedLearner(eng, num_steps=T, hidden_dim=32, num_mini_batch=2, ppo_epoch=1, use_graph=use_graph)
+    pool_sd = [fa.MPNN(num_agents=A, num_opp_agents=G, hidden_dim=32, num_actions=8).state_dict() for _ in range(3)]
+    L.load_attacker_ensemble([{"models": [None] * G + [sd] * A, "ob_rms": (None, None)} for sd in pool_sd],
+                             hidden_dim=32)
+    L.reset()
+    ids_before = L.attacker_id.clone()
+    st = L.storage
+    # step by step (eager path of collect) so the strategy ids in force at each step are known
+    ids_at = []
+    for s in range(T):
+        ids_at.append(L.attacker_id.clone())
+        if L._graphs is not None:
+            L._graphs[s].replay()
+        else:
+            L.step(s)
+    att = slice(G, G + A)
+    with torch.no_grad():
+        for s in range(T):
+            obs = st.obs[s]
+            lp_all = torch.stack([p.evaluate_actions(obs[:, att], obs[:, :G], st.actions[s, :, att])[1]
+                                  for p in L.attacker_pool])            # (K,E,A,1)
+            want = lp_all[ids_at[s], torch.arange(E, device="cuda")]
+            assert (want - st.action_log_probs[s, :, att]).abs().max() < 1e-4, s
+    changed = (L.attacker_id != ids_before)
+    ended = st.done.sum(0) > 0
+    assert bool((changed <= ended).all()) and int(ended.sum()) > 0   # ids only move where an episode ended
+    att_before = [p.detach().clone() for p in L.attacker_pool[0].parameters()]
+    L.collect()
+    out = L.update(train_guards_only=True)
+    assert out.shape == (1, 3)
+    assert all(torch.equal(a, b) for a, b in zip(att_before, L.attacker_pool[0].parameters()))

@@ -251,3 +251,36 @@ def test_full_size_invariants(fa):
         prev = cur.clone()
     s = eng.get_state()
     assert int(s["result_count"].sum()) == episodes and episodes >= E  # every env finished >= 1 episode
+
+
+def test_eval_stats_match_oracle_bookkeeping(fa):
+    """Device-side evaluation counters (fa_state_host.episode_reward_sum / alive_at_end /
+    result_count) == the reference's per-episode bookkeeping (test_fortattack_v2.py:88-101)
+    done on the host from the oracle's per-step outputs."""
+    from fa_oracle import OracleEnv
+    E, G, A, T, max_t = 300, 3, 3, 150, 30
+    N = G + A
+    rng = np.random.RandomState(9)
+    orc = OracleEnv(E, G, A, max_t, base_seed=77)
+    eng = fa.BatchedFortAttack(E, G, A, max_t, base_seed=77)
+    eng.reset(), orc.reset()
+    ep_rew = np.zeros((E, N))
+    rows = []
+    for t in range(T):
+        a = np.where(rng.rand(E, N) < 0.3, 7, rng.randint(0, 8, size=(E, N)))
+        eng.step(_dev(a, torch.int64), auto_reset=True, want=("done",))
+        ref = orc.step(a, auto_reset=False)
+        ep_rew += ref["reward"] * ref["alive_before"]
+        d = ref["done"].astype(bool)
+        if d.any():
+            gr = orc.get_state()["game_result"]
+            alive = ref["obs"][:, :, 0]
+            for e in np.nonzero(d)[0]:
+                rows.append([gr[e, 0], gr[e, 1], gr[e, 0] + gr[e, 1], gr[e, 2], alive[e, :G].sum(),
+                             alive[e, G:].sum(), ep_rew[e, :G].mean(), ep_rew[e, G:].mean()])
+                ep_rew[e] = 0
+            orc.reset(mask=d)
+    want = np.array(rows, dtype=np.float64).mean(0)
+    got, n_ep = eng.eval_stats()
+    assert n_ep == len(rows) and n_ep > 500
+    assert np.abs(got - want).max() < 1e-9

@@ -96,3 +96,21 @@ def test_seed_identical_construction_vs_live_reference(MPNN):
         rv, rl, re_, _ = ref.evaluate_actions(inp, None, opp, None, act)
         ov, ol, oe = ours.evaluate_actions_agent_major(inp, opp, act)
     assert (rv - ov).abs().max() < TOL and (rl - ol).abs().max() < TOL and (re_ - oe).abs().max() < TOL
+
+
+def test_shipped_reference_checkpoints_load(MPNN):
+    """The reference's published 5v5 checkpoints (marlsave/tmp_1/ep*.pt) load unchanged; the
+    weights do not depend on team size, so they also drive 3v3."""
+    import glob
+    paths = sorted(glob.glob("/root/reference/marlsave/tmp_1/ep*.pt"))
+    if not paths:
+        pytest.skip("reference checkpoints not present (build container only)")
+    ck = torch.load(paths[0], map_location="cpu", weights_only=False)
+    assert set(ck) == {"models", "ob_rms"} and len(ck["models"]) == 10
+    guard = MPNN(num_agents=5, num_opp_agents=5, num_actions=8)
+    guard.load_state_dict(ck["models"][0])
+    att3 = MPNN(num_agents=3, num_opp_agents=3, num_actions=8)
+    att3.load_state_dict(ck["models"][-1])
+    with torch.no_grad():
+        v, a, lp = att3.act(torch.randn(4, 3, 6), torch.randn(4, 3, 6))
+    assert torch.isfinite(v).all() and torch.isfinite(lp).all()
