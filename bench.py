@@ -85,6 +85,10 @@ def main():
                          "per-step: T launches replayed from one hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-collector", action="store_true", help="time the step kernel only")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL on ROCm)")
+    ap.add_argument("--share-devices", action="store_true",
+                    help="map ranks onto the visible GPUs round-robin (smoke-testing the multi-rank "
+                         "path on a box with fewer GPUs than ranks; use with --backend gloo)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -92,11 +96,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+    if args.share_devices:
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     import emergent_multiagent_strategies_amd as fa
     from emergent_multiagent_strategies_amd.dist import adv_mean_std

@@ -66,6 +66,8 @@ EXPORTS = {
     "fa_gae": (C.c_int, [c_p, C.c_double, C.c_double, c_p]),
     "fa_adv_stats": (C.c_int, [c_p, C.c_int32, c_p, c_p, c_p]),
     "fa_adv_mean_std": (C.c_int, [c_p, c_p, c_p, c_p]),
+    "fa_adv_moments": (C.c_int, [c_p, c_p, c_p]),
+    "fa_adv_merge": (C.c_int, [c_p, c_p, C.c_int32, c_p, c_p, c_p]),
     "fa_adv_normalize": (C.c_int, [c_p, c_p, c_p, c_p, c_p]),
     "fa_after_update": (C.c_int, [c_p, c_p]),
     "fa_get_state": (C.c_int, [c_p, C.POINTER(StateHost)]),

@@ -18,6 +18,9 @@ hipError_t fa_launch_gae(const float *rewards, const float *value_preds, const f
 hipError_t fa_launch_adv_stats(int pass, const float *returns, const float *value_preds, const double *mean,
                                long long rows, int N, double *partial, int nblocks, double *stats,
                                double *derived, hipStream_t st);
+hipError_t fa_launch_adv_merge(const double *gathered, int W, int N, double *mean_out, double *std_out,
+                               hipStream_t st);
+hipError_t fa_launch_adv_moments_fix(double *stats, int N, hipStream_t st);
 hipError_t fa_launch_adv_norm(const float *returns, const float *value_preds, const double *mean,
                               const double *std_, long long total, int N, float *out, hipStream_t st);
 
@@ -213,7 +216,7 @@ int fa_create(const fa_config *cfg, fa_env **out) {
     const size_t o_epr = carve(2 * EN * sizeof(double));
     const size_t o_ale = carve(EN * sizeof(uint32_t));
     const size_t o_adv = carve((size_t)env->adv_blocks * FA_MAX_AGENTS * sizeof(double));
-    const size_t o_advs = carve((size_t)FA_MAX_AGENTS * 3 * sizeof(double));
+    const size_t o_advs = carve((size_t)FA_MAX_AGENTS * 4 * sizeof(double));
     env->slab_bytes = off;
     hipError_t he = hipMalloc(&env->slab, env->slab_bytes);
     if (he != hipSuccess) {
@@ -398,6 +401,33 @@ int fa_adv_mean_std(fa_env *env, double *mean_out, double *std_out, void *stream
                                env->adv_stats, mean_out, s));
     FA_HIP(fa_launch_adv_stats(1, st.returns, st.value_preds, mean_out, rows, env->N, env->adv_partial, nblocks,
                                env->adv_stats, std_out, s));
+    return FA_OK;
+}
+
+int fa_adv_moments(fa_env *env, double *moments_out, void *stream) {
+    if (!env || !moments_out) return fail(FA_ERR_INVALID, "fa_adv_moments: null argument");
+    if (!env->bound) return fail(FA_ERR_STATE, "fa_adv_moments: no storage bound");
+    DeviceGuard guard(env->cfg.device_id);
+    const fa_storage &st = env->st;
+    const long long rows = (long long)st.num_steps * env->cfg.num_envs;
+    long long want = (rows + 255) / 256;
+    const int nblocks = (int)(want < env->adv_blocks ? want : env->adv_blocks);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    double *mean = env->adv_stats + 3 * FA_MAX_AGENTS; // scratch: local mean
+    FA_HIP(fa_launch_adv_stats(0, st.returns, st.value_preds, nullptr, rows, env->N, env->adv_partial, nblocks,
+                               moments_out, mean, s));
+    FA_HIP(fa_launch_adv_stats(1, st.returns, st.value_preds, mean, rows, env->N, env->adv_partial, nblocks,
+                               moments_out, nullptr, s));
+    FA_HIP(fa_launch_adv_moments_fix(moments_out, env->N, s));
+    return FA_OK;
+}
+
+int fa_adv_merge(fa_env *env, const double *gathered, int32_t world, double *mean_out, double *std_out,
+                 void *stream) {
+    if (!env || !gathered || !mean_out || !std_out) return fail(FA_ERR_INVALID, "fa_adv_merge: null argument");
+    if (world < 1) return fail(FA_ERR_INVALID, "fa_adv_merge: world must be >= 1");
+    DeviceGuard guard(env->cfg.device_id);
+    FA_HIP(fa_launch_adv_merge(gathered, world, env->N, mean_out, std_out, static_cast<hipStream_t>(stream)));
     return FA_OK;
 }
 

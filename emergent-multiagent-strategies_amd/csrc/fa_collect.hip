@@ -213,6 +213,44 @@ __global__ __launch_bounds__(256) void fa_adv_norm_kernel(const float *__restric
     }
 }
 
+// Chan-Golub-LeVeque merge of per-rank (n, mean, M2) triples in rank order: exact combination
+// of two-pass statistics, identical on every rank, one collective instead of two.
+// gathered: (W, N, 3); one lane per agent.
+__global__ void fa_adv_merge_kernel(const double *__restrict__ gathered, int W, int N,
+                                    double *__restrict__ mean_out, double *__restrict__ std_out) {
+    const int i = threadIdx.x;
+    if (i >= N) return;
+    double n = 0.0, mean = 0.0, m2 = 0.0;
+    for (int r = 0; r < W; ++r) {
+        const double *g = gathered + ((long long)r * N + i) * 3;
+        const double nr = g[0], mr = g[1], m2r = g[2];
+        if (nr <= 0.0) continue;
+        const double nn = n + nr, delta = mr - mean;
+        mean += delta * (nr / nn);
+        m2 += m2r + delta * delta * (n * nr / nn);
+        n = nn;
+    }
+    mean_out[i] = mean;
+    std_out[i] = sqrt(m2 / (n - 1.0));
+}
+
+// (n, sum, ssd) -> (n, mean, M2) in place, one lane per agent
+__global__ void fa_adv_moments_kernel(double *__restrict__ stats, int N) {
+    const int i = threadIdx.x;
+    if (i >= N) return;
+    stats[i * 3 + 1] = stats[i * 3 + 1] / stats[i * 3 + 0];
+}
+
+hipError_t fa_launch_adv_merge(const double *gathered, int W, int N, double *mean_out, double *std_out,
+                               hipStream_t st) {
+    hipLaunchKernelGGL(fa_adv_merge_kernel, dim3(1), dim3(64), 0, st, gathered, W, N, mean_out, std_out);
+    return hipGetLastError();
+}
+hipError_t fa_launch_adv_moments_fix(double *stats, int N, hipStream_t st) {
+    hipLaunchKernelGGL(fa_adv_moments_kernel, dim3(1), dim3(64), 0, st, stats, N);
+    return hipGetLastError();
+}
+
 hipError_t fa_launch_gae(const float *rewards, const float *value_preds, const float *masks, float *returns,
                          const uint8_t *done, int T, int E, int N, double gamma, double tau, hipStream_t st) {
     const long long EN = (long long)E * N;

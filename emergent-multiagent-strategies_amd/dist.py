@@ -32,12 +32,35 @@ def two_pass_mean_std(pass0, pass1, group=None):
 
 
 def adv_mean_std(eng, group=None):
-    """Global per-agent advantage mean / std for the storage bound to `eng` (fa_adv_stats)."""
+    """Global per-agent advantage mean / unbiased std for the storage bound to `eng`.
+    One rank: fa_adv_mean_std (four launches, no collective).  Several ranks: local two-pass
+    moments, ONE all-gather of (N,3) doubles per rank, exact merge kernel (fa_adv_merge)."""
     if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
-        return eng.adv_mean_std()                      # one rank: four launches, no torch glue
-    mean, std, _ = two_pass_mean_std(lambda: eng.adv_stats(0),
-                                     lambda m: eng.adv_stats(1, mean=m)[:, 2], group)
-    return mean, std
+        return eng.adv_mean_std()
+    world = dist.get_world_size(group)
+    buf = getattr(eng, "_adv_gather", None)
+    if buf is None or buf.shape[0] != world:
+        buf = eng._adv_gather = torch.zeros((world, eng.N, 3), dtype=torch.float64, device=eng.device)
+        eng._adv_local = torch.zeros((eng.N, 3), dtype=torch.float64, device=eng.device)
+    eng.adv_moments(out=eng._adv_local)
+    dist.all_gather_into_tensor(buf.view(-1), eng._adv_local.view(-1), group=group)   # flat: backend-neutral
+    return eng.adv_merge(buf)
+
+
+def merge_moments(gathered):
+    """Host/torch restatement of fa_adv_merge (tests): gathered (W, N, 3) -> mean, std."""
+    W, N, _ = gathered.shape
+    n = torch.zeros(N, dtype=torch.float64)
+    mean = torch.zeros(N, dtype=torch.float64)
+    m2 = torch.zeros(N, dtype=torch.float64)
+    for r in range(W):
+        nr, mr, m2r = gathered[r, :, 0].cpu(), gathered[r, :, 1].cpu(), gathered[r, :, 2].cpu()
+        nn = n + nr
+        delta = mr - mean
+        mean = mean + delta * (nr / nn)
+        m2 = m2 + m2r + delta * delta * (n * nr / nn)
+        n = nn
+    return mean, torch.sqrt(m2 / (n - 1))
 
 
 def shard_range(num_envs_total, rank, world):

@@ -150,6 +150,22 @@ class BatchedFortAttack(object):
                    "fa_adv_mean_std")
         return self._adv_ms[0], self._adv_ms[1]
 
+    def adv_moments(self, out=None):
+        """fa_adv_moments: (N,3) {n, mean, M2} of this handle's advantages, on device."""
+        if out is None:
+            out = torch.zeros((self.N, 3), dtype=torch.float64, device=self.device)
+        _lib.check(self._lib.fa_adv_moments(self._h, _ptr(out), _stream()), "fa_adv_moments")
+        return out
+
+    def adv_merge(self, gathered):
+        """fa_adv_merge: gathered (world, N, 3) -> global (mean, std), each (N,)."""
+        assert gathered.is_contiguous() and gathered.dtype == torch.float64 and gathered.shape[1:] == (self.N, 3)
+        if not hasattr(self, "_adv_ms"):
+            self._adv_ms = torch.zeros((2, self.N), dtype=torch.float64, device=self.device)
+        _lib.check(self._lib.fa_adv_merge(self._h, _ptr(gathered), int(gathered.shape[0]), _ptr(self._adv_ms[0]),
+                                          _ptr(self._adv_ms[1]), _stream()), "fa_adv_merge")
+        return self._adv_ms[0], self._adv_ms[1]
+
     def adv_normalize(self, mean, std, out=None):
         if out is None:
             out = self._new((self.storage.num_steps, self.E, self.N, 1), torch.float32)

@@ -201,6 +201,8 @@ class BatchedLearner(object):
         st = self.storage
         if self.use_graph and self._graphs is None:
             raise RuntimeError("call reset() before collect()")
+        for pol in self.policies + list(self.attacker_pool):
+            pol.refresh_fused_weights()   # captured graphs read these buffers; weights may have moved
         for s in range(self.T):
             if self._graphs is not None:
                 self._graphs[s].replay()

@@ -95,6 +95,34 @@ class MPNN(nn.Module):
         diag.fill_diagonal_(-math.inf)
         self.register_buffer("_diag", diag, persistent=False)
 
+    def _fused_weights(self):
+        """[W_query | W_val] of the opponent attention and [W_query | W_key | W_val] of the team
+        attention as single GEMM operands.  Under autograd they are rebuilt every call (so
+        gradients flow to the separate parameters); in no-grad rollouts they are cached until a
+        parameter changes (optimizer step / load_state_dict bump the version counters)."""
+        a, m = self.oppAttn, self.messages
+        ps = (a.W_query, a.W_val, m.W_query, m.W_key, m.W_val)
+        if torch.is_grad_enabled():
+            return (torch.cat((a.W_query[0], a.W_val[0]), dim=1),
+                    torch.cat((m.W_query[0], m.W_key[0], m.W_val[0]), dim=1))
+        key = tuple((p._version, p.data_ptr()) for p in ps)
+        if getattr(self, "_wcache_key", None) != key:
+            self.refresh_fused_weights()
+        return self._w_qv, self._w_qkv
+
+    @torch.no_grad()
+    def refresh_fused_weights(self):
+        """Rewrite the cached operands IN PLACE (same storage): hipGraphs captured over a rollout
+        step keep pointing at them, so the learner calls this after every optimizer phase."""
+        a, m = self.oppAttn, self.messages
+        if getattr(self, "_w_qv", None) is None or self._w_qv.device != a.W_query.device:
+            self._w_qv = torch.empty(a.input_dim, 2 * a.key_dim, device=a.W_query.device, dtype=a.W_query.dtype)
+            self._w_qkv = torch.empty(m.input_dim, 3 * m.key_dim, device=m.W_query.device, dtype=m.W_query.dtype)
+        torch.cat((a.W_query[0], a.W_val[0]), dim=1, out=self._w_qv)
+        torch.cat((m.W_query[0], m.W_key[0], m.W_val[0]), dim=1, out=self._w_qkv)
+        self._wcache_key = tuple((p._version, p.data_ptr()) for p in
+                                 (a.W_query, a.W_val, m.W_query, m.W_key, m.W_val))
+
     # ---- trunk (mpnn.py:117-172 _fwd) ---------------------------------------------------
     def trunk(self, own, opp, return_attn=False):
         """own (B, n, 6), opp (B, m, 6) -> h (B, n, h_dim)."""
@@ -106,7 +134,8 @@ class MPNN(nn.Module):
         # the slowest way to spend MFMA time.
         a = self.oppAttn                                   # mpnn.py:372-443
         kd = a.key_dim
-        qv = h_opp @ torch.cat((a.W_query[0], a.W_val[0]), dim=1)
+        w_qv, w_qkv = self._fused_weights()
+        qv = h_opp @ w_qv
         q, v = qv[..., :kd], qv[..., kd:]
         k = h @ a.W_key[0]
         scores = (k.unsqueeze(2) * q.unsqueeze(1)).sum(-1)             # (B, n, m)
@@ -115,8 +144,6 @@ class MPNN(nn.Module):
         h = torch.cat((h, e_opp), dim=2)
         m = self.messages                                  # mpnn.py:250-332
         attn = None
-        if h.shape[1] > 1:
-            w_qkv = torch.cat((m.W_query[0], m.W_key[0], m.W_val[0]), dim=1)
         for _ in range(self.K):
             if h.shape[1] == 1:                            # mpnn.py:266-274
                 msg = torch.zeros(h.shape[0], 1, m.embed_dim, device=h.device, dtype=h.dtype)
@@ -144,12 +171,13 @@ class MPNN(nn.Module):
         if deterministic:
             action = logits.argmax(dim=-1, keepdim=True)
         else:
-            # inverse-CDF sampling: same categorical distribution as torch.multinomial
-            # (FixedCategorical.sample, distributions.py:12-13) without its host-visible
-            # validity assert and extra reductions
-            cdf = logp_all.exp().cumsum(-1)
-            u = torch.rand(cdf.shape[:-1] + (1,), device=cdf.device, dtype=cdf.dtype, generator=generator)
-            action = (u > cdf).sum(-1, keepdim=True).clamp_(max=logits.shape[-1] - 1)
+            # Gumbel-max sampling: argmax(logits + G), G = -log(-log U), is a draw from
+            # softmax(logits) -- the same categorical distribution as torch.multinomial
+            # (FixedCategorical.sample, distributions.py:12-13) without its validity assert,
+            # reductions and scan kernels
+            u = torch.rand(logits.shape, device=logits.device, dtype=logits.dtype, generator=generator)
+            gumbel = -torch.log(-torch.log(u.clamp_(min=1e-20, max=1.0 - 1e-7)))
+            action = (logits + gumbel).argmax(dim=-1, keepdim=True)
         return value, action, logp_all.gather(-1, action)
 
     def get_value(self, own, opp):                         # mpnn.py:202-205

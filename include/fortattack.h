@@ -193,6 +193,14 @@ int fa_adv_stats(fa_env *env, int32_t pass, const double *mean, double *stats, v
  * mean[i] and the unbiased std[i] (device, N doubles each).  With several GPUs use
  * fa_adv_stats and all-reduce between the passes instead. */
 int fa_adv_mean_std(fa_env *env, double *mean_out, double *std_out, void *stream);
+/* Multi-GPU form with ONE collective: moments_out (N,3) = {n, mean, M2} of this handle's
+ * samples (two passes, M2 = sum of squared deviations from the local mean); all-gather the
+ * triples of every rank and give them to fa_adv_merge, which combines them exactly
+ * (Chan-Golub-LeVeque, rank order => identical on all ranks) into the global mean / unbiased
+ * std.  gathered: device (world, N, 3) doubles. */
+int fa_adv_moments(fa_env *env, double *moments_out, void *stream);
+int fa_adv_merge(fa_env *env, const double *gathered, int32_t world, double *mean_out, double *std_out,
+                 void *stream);
 /* ppo.py:123: adv_out (T,E,N) = (A - mean[i]) / (std[i] + 1e-5), float32. */
 int fa_adv_normalize(fa_env *env, const double *mean, const double *std, float *adv_out, void *stream);
 /* RolloutStorage.after_update (storage.py:51-56). */

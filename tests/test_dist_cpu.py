@@ -38,6 +38,15 @@ def _worker(rank, world, port, returns, values, q):
         return ((adv - mean.view(1, 1, N, 1)) ** 2).sum(dim=(0, 1, 3))
 
     mean, std, n = two_pass_mean_std(pass0, pass1)
+    # the single-collective form used on GPUs: local (n, mean, M2) -> all-gather -> exact merge
+    from emergent_multiagent_strategies_amd.dist import merge_moments
+    lm = adv.mean(dim=(0, 1, 3))
+    local = torch.stack([torch.full((N,), float(T * per), dtype=torch.float64), lm,
+                         ((adv - lm.view(1, 1, N, 1)) ** 2).sum(dim=(0, 1, 3))], 1).contiguous()
+    gathered = [torch.zeros_like(local) for _ in range(world)]
+    dist.all_gather(gathered, local)
+    mean2, std2 = merge_moments(torch.stack(gathered))
+    assert torch.allclose(mean2, mean, rtol=0, atol=1e-13) and torch.allclose(std2, std, rtol=1e-13, atol=0)
     q.put((rank, mean.numpy(), std.numpy(), n.numpy()))
     dist.barrier()
     dist.destroy_process_group()

@@ -164,3 +164,33 @@ def test_fused_rollout_equals_per_step_launches(fa, G, A, E, T, chunk):
         assert np.array_equal(xa[k], xb[k], equal_nan=True), k
     assert np.array_equal(ra, rb)
     assert int(sa.done.sum()) > 0
+
+
+def test_moments_and_merge_equal_global_two_pass(fa):
+    """fa_adv_moments + fa_adv_merge (the one-collective multi-GPU form): three 'ranks' worth of
+    data merged on the device == the two-pass statistics of the concatenation."""
+    import collector_oracle as co
+    from emergent_multiagent_strategies_amd.dist import merge_moments
+    E, G, A, T, W = 128, 3, 3, 32, 3
+    N = G + A
+    rng = np.random.RandomState(5)
+    eng = fa.BatchedFortAttack(E, G, A, 50)
+    st = fa.JointRolloutStorage(T, E, N, device="cuda")
+    eng.bind_storage(st)
+    parts, gathered = [], torch.zeros((W, N, 3), dtype=torch.float64, device="cuda")
+    for r in range(W):
+        ret = (rng.randn(T + 1, E, N, 1) * (1 + r) + 0.3 * r).astype(np.float32)
+        val = rng.randn(T + 1, E, N, 1).astype(np.float32)
+        st.returns.copy_(_t(ret)); st.value_preds.copy_(_t(val))
+        eng.adv_moments(out=gathered[r])
+        m, s_ = eng.adv_mean_std()
+        assert torch.allclose(gathered[r, :, 1], m, rtol=0, atol=1e-15)
+        assert torch.allclose(torch.sqrt(gathered[r, :, 2] / (gathered[r, :, 0] - 1)), s_, rtol=1e-14, atol=0)
+        parts.append((ret[:-1] - val[:-1]).astype(np.float32).astype(np.float64))
+    mean, std = eng.adv_merge(gathered)
+    allp = np.concatenate(parts, axis=1)                       # (T, W*E, N, 1)
+    for i in range(N):
+        assert abs(float(mean[i]) - allp[:, :, i].mean()) < 1e-12
+        assert abs(float(std[i]) - allp[:, :, i].std(ddof=1)) < 1e-12
+    hm, hs = merge_moments(gathered)
+    assert torch.allclose(hm, mean.cpu(), rtol=0, atol=1e-15) and torch.allclose(hs, std.cpu(), rtol=1e-15, atol=0)
