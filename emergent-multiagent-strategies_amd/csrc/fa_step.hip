@@ -223,6 +223,19 @@ __global__ __launch_bounds__(FA_WAVE) void fa_step_kernel(FaStepArgs a) {
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
+            // partner deltas for the contact test, fetched now (they do not depend on the laser):
+            // the LDS latency and the 5 flops per partner overlap with the laser tests below
+            constexpr int NT = (TG != 0) ? TG + TA : 0;
+            double dxs[NT ? NT : 1], dys[NT ? NT : 1], d2s[NT ? NT : 1];
+            if constexpr (NT != 0) {
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    dxs[j] = px - s_px[gbase + j];
+                    dys[j] = py - s_py[gbase + j];
+                    d2s[j] = dxs[j] * dxs[j] + dys[j] * dys[j];
+                }
+            }
+
             // ---- core.py:254-302 apply_laser_effect ------------------------------------
             // iteration k: every lane tests the triangle of its k-th opponent; the ballot
             // of the results gives shooter k of either team its hit list.
@@ -287,17 +300,8 @@ __global__ __launch_bounds__(FA_WAVE) void fa_step_kernel(FaStepArgs a) {
                 // for agent i that is partner j ascending, with f_i = +f for j>i and
                 // -(f(j,i)) for j<i, which is bitwise the same number as f computed from
                 // i's side (negation commutes exactly with *, / and the sqrt argument).
-                constexpr int NT = (TG != 0) ? TG + TA : 0;
                 if constexpr (NT != 0) {
-                    // all partner positions in one LDS batch; the cheap reject for every partner
-                    // is independent work; only partners actually in range take the slow path
-                    double dxs[NT], dys[NT], d2s[NT];
-#pragma unroll
-                    for (int j = 0; j < NT; ++j) {
-                        dxs[j] = px - s_px[gbase + j];
-                        dys[j] = py - s_py[gbase + j];
-                        d2s[j] = dxs[j] * dxs[j] + dys[j] * dys[j];
-                    }
+                    // only partners actually in range take the slow path
 #pragma unroll
                     for (int j = 0; j < NT; ++j) {
                         // exact skip: farther than dist_min + 1000*margin => t < -1000 =>

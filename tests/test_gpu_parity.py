@@ -105,7 +105,12 @@ def test_env_golden_auto_reset(fa, golden_dir):
 
 
 @pytest.mark.parametrize("G,A,E,T,max_t", [(3, 3, 1000, 160, 50), (5, 5, 333, 120, 40), (1, 4, 77, 60, 20),
-                                           (8, 8, 50, 60, 25), (4, 2, 129, 80, 30)])
+                                           (8, 8, 50, 60, 25), (4, 2, 129, 80, 30),
+                                           (3, 3, 1, 90, 12),       # a single env
+                                           (3, 3, 11, 40, 1),       # every step ends an episode
+                                           (15, 1, 9, 50, 20),      # 16 lanes per env, lopsided teams
+                                           (1, 1, 65, 70, 15),      # 32 envs per wave
+                                           (2, 5, 4097, 30, 10)])   # N=7: 9 envs per wave, ragged tail
 def test_env_vs_oracle_random(fa, G, A, E, T, max_t):
     """Same seeds, same random actions, auto reset: HIP vs CPU oracle every step."""
     from fa_oracle import OracleEnv
@@ -138,7 +143,7 @@ def test_env_vs_oracle_random(fa, G, A, E, T, max_t):
         assert np.array_equal(so[k], sg[k]), k
     print("%dv%d E=%d T=%d: deaths=%d episodes=%d float mismatches=%d worst=%.3e" % (
         G, A, E, T, deaths, ends, n_float_mismatch, worst))
-    assert deaths > 0 and ends > 0
+    assert ends > 0 and (deaths > 0 or T * E < 5000)
     assert worst <= FLOAT_TOL
 
 
