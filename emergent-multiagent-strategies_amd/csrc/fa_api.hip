@@ -13,6 +13,8 @@ hipError_t fa_launch_step(const FaStepArgs &a, hipStream_t st);
 hipError_t fa_launch_reset(const FaStepArgs &a, hipStream_t st);
 hipError_t fa_launch_seed(const FaState &s, int E, uint64_t base_seed, int64_t env_offset, int skip_words,
                           hipStream_t st);
+hipError_t fa_launch_selftest(unsigned long long n_per_thread, unsigned long long seed, unsigned long long *mismatch,
+                              hipStream_t st);
 hipError_t fa_launch_gae(const float *rewards, const float *value_preds, const float *masks, float *returns,
                          const uint8_t *done, int T, int E, int N, double gamma, double tau, hipStream_t st);
 hipError_t fa_launch_adv_stats(int pass, const float *returns, const float *value_preds, const double *mean,
@@ -513,6 +515,18 @@ int fa_set_state(fa_env *env, const fa_state_host *in) {
     FA_H2D(s.alive, in->alive, EN);
     FA_H2D(s.tstep, in->time_step, E * 4);
 #undef FA_H2D
+    return FA_OK;
+}
+
+int fa_selftest_math(fa_env *env, uint64_t samples, uint64_t seed, uint64_t *mismatch_host) {
+    if (!env || !mismatch_host) return fail(FA_ERR_INVALID, "fa_selftest_math: null argument");
+    DeviceGuard guard(env->cfg.device_id);
+    unsigned long long *d = reinterpret_cast<unsigned long long *>(env->adv_partial); // scratch
+    FA_HIP(hipDeviceSynchronize());
+    FA_HIP(hipMemset(d, 0, 16));
+    const unsigned long long per = samples / (1024ull * 256ull) + 1ull;
+    FA_HIP(fa_launch_selftest(per, seed, d, nullptr));
+    FA_HIP(hipMemcpy(mismatch_host, d, 16, hipMemcpyDeviceToHost));
     return FA_OK;
 }
 

@@ -94,6 +94,38 @@ __device__ __forceinline__ void reset_advance(const FaStepArgs &a, int e, int N)
     else a.s.reset_count[e] += 1u;
 }
 
+// ---- correctly rounded fp64 divide / sqrt without the range-scaling wrappers -----------------
+// hipcc expands a/b into v_div_scale x2 + v_rcp + 2 Newton FMAs + mul + residual FMA +
+// v_div_fmas + v_div_fixup (11 instructions, serialised through VCC) and sqrt(x) into a
+// scale/ldexp/class wrapper around v_rsq + a 9-FMA Goldschmidt core (17 instructions).  The
+// wrappers only matter when a quotient or root leaves the normal range or an input is 0/inf/nan;
+// every operand on the step's slow paths is a normal number of magnitude 1e-17 .. 1e11 (wall /
+// contact clearances over k = 1e-10, forces over distances, door and pair distances), so the
+// cores alone produce the same correctly rounded bits with 8 resp. 10 instructions and no VCC
+// dependency (independent divisions can overlap).  fa_selftest_math() checks them bit for bit
+// against `/` and sqrt() on the device.
+__device__ __forceinline__ double div_rn(double a, double b) {
+    double r = __builtin_amdgcn_rcp(b);
+    double e = fma(-b, r, 1.0);
+    r = fma(r, e, r);
+    e = fma(-b, r, 1.0);
+    r = fma(r, e, r);
+    const double q = a * r;
+    const double e2 = fma(-b, q, a);
+    return fma(e2, r, q);
+}
+__device__ __forceinline__ double sqrt_rn(double x) {
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = y * 0.5;
+    const double r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    double d = fma(-g, g, x);
+    g = fma(d, h, g);
+    d = fma(-g, g, x);
+    return fma(d, h, g);
+}
+
 // np.logaddexp(0, t) * k, numpy npy_logaddexp with x = 0 (core.py:452, :469).
 //   t >= 40  : t + log1p(exp(-t)) == t exactly (exp(-t) <= 4.3e-18 < ulp(40)/2)
 //   t < -746 : exp underflows to +0, log1p(0) = 0
@@ -308,10 +340,10 @@ __global__ __launch_bounds__(FA_WAVE) void fa_step_kernel(FaStepArgs a) {
                         // exp(t) == +0 => penetration == +0.0 => force == +-0.0, and F (never
                         // -0.0) is unchanged by adding it.
                         if (j == i || !((grp_alive1 >> j) & 1ull) || d2s[j] > c.contact_skip_d2) continue;
-                        const double dist = sqrt(d2s[j]);
-                        const double pen = softplus_pen(-(dist - c.dist_min) / c.contact_margin, c.contact_margin);
-                        Fx = c.contact_force * dxs[j] / dist * pen + Fx;
-                        Fy = c.contact_force * dys[j] / dist * pen + Fy;
+                        const double dist = sqrt_rn(d2s[j]);
+                        const double pen = softplus_pen(div_rn(-(dist - c.dist_min), c.contact_margin), c.contact_margin);
+                        Fx = div_rn(c.contact_force * dxs[j], dist) * pen + Fx;
+                        Fy = div_rn(c.contact_force * dys[j], dist) * pen + Fy;
                     }
                 } else {
                     for (int j = 0; j < N; ++j) {
@@ -319,10 +351,10 @@ __global__ __launch_bounds__(FA_WAVE) void fa_step_kernel(FaStepArgs a) {
                         const double dx = px - s_px[gbase + j], dy = py - s_py[gbase + j];
                         const double d2 = dx * dx + dy * dy;
                         if (d2 > c.contact_skip_d2) continue; // exact skip, see above
-                        const double dist = sqrt(d2);
-                        const double pen = softplus_pen(-(dist - c.dist_min) / c.contact_margin, c.contact_margin);
-                        Fx = c.contact_force * dx / dist * pen + Fx;
-                        Fy = c.contact_force * dy / dist * pen + Fy;
+                        const double dist = sqrt_rn(d2);
+                        const double pen = softplus_pen(div_rn(-(dist - c.dist_min), c.contact_margin), c.contact_margin);
+                        Fx = div_rn(c.contact_force * dx, dist) * pen + Fx;
+                        Fy = div_rn(c.contact_force * dy, dist) * pen + Fy;
                     }
                 }
                 // core.py:246-252 + :459-472 walls
@@ -337,10 +369,10 @@ __global__ __launch_bounds__(FA_WAVE) void fa_step_kernel(FaStepArgs a) {
                     const bool w2 = !(d2 > c.wall_skip), w3 = !(d3 > c.wall_skip);
                     if (w0 || w1 || w2 || w3) {
                         double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0;
-                        if (w0) p0 = softplus_pen(-d0 / k, k);
-                        if (w1) p1 = softplus_pen(-d1 / k, k);
-                        if (w2) p2 = softplus_pen(-d2 / k, k);
-                        if (w3) p3 = softplus_pen(-d3 / k, k);
+                        if (w0) p0 = softplus_pen(div_rn(-d0, k), k);
+                        if (w1) p1 = softplus_pen(div_rn(-d1, k), k);
+                        if (w2) p2 = softplus_pen(div_rn(-d2, k), k);
+                        if (w3) p3 = softplus_pen(div_rn(-d3, k), k);
                         const double fx1 = c.contact_force * p0, fx2 = c.contact_force * p1;
                         const double fy1 = c.contact_force * p2, fy2 = c.contact_force * p3;
                         Fx = (fx1 - fx2) + Fx;
@@ -357,9 +389,9 @@ __global__ __launch_bounds__(FA_WAVE) void fa_step_kernel(FaStepArgs a) {
                 // the comparison below is the reference's comparison, exactly.
                 const double speed2 = vx * vx + vy * vy;
                 if (speed2 > c.speed2_max) {
-                    const double speed = sqrt(speed2);
-                    vx = vx / speed * c.max_speed;
-                    vy = vy / speed * c.max_speed;
+                    const double speed = sqrt_rn(speed2);
+                    vx = div_rn(vx, speed) * c.max_speed;
+                    vy = div_rn(vy, speed) * c.max_speed;
                 }
                 ang += rot;
                 px += vx * c.dt;
@@ -368,7 +400,7 @@ __global__ __launch_bounds__(FA_WAVE) void fa_step_kernel(FaStepArgs a) {
 
             // ---- rewards (fortattack_env_v1.py:87-188), after World.step ---------------
             const double ddx = px - c.door_x, ddy = py - c.door_y;
-            const double dist_door = sqrt(ddx * ddx + ddy * ddy);
+            const double dist_door = sqrt_rn(ddx * ddx + ddy * ddy);
             const unsigned long long in_fort_b =
                 __ballot(valid && is_att && alive1 && dist_door < c.fort_dim);
             const bool any_in_fort = ((in_fort_b >> gbase) & grp_mask) != 0ull;
@@ -545,5 +577,35 @@ hipError_t fa_launch_seed(const FaState &s, int E, uint64_t base_seed, int64_t e
                           int skip_words, hipStream_t st) {
     hipLaunchKernelGGL(fa_seed_kernel, dim3((E + 255) / 256), dim3(256), 0, st, s, E, base_seed,
                        env_offset, skip_words);
+    return hipGetLastError();
+}
+
+// ---- device self-test of div_rn / sqrt_rn against the compiler's `/` and sqrt() ----------------
+__global__ void fa_selftest_kernel(unsigned long long n_per_thread, unsigned long long seed,
+                                   unsigned long long *mismatch) {
+    unsigned long long x = seed ^ (0x9E3779B97F4A7C15ull * (blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x + 1));
+    auto next = [&]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return x; };
+    auto mag = [&](int lo, int hi) {   // log-uniform magnitude 10^lo .. 10^hi, random mantissa
+        const double u = (next() >> 11) * (1.0 / 9007199254740992.0);
+        const double v = (next() >> 11) * (1.0 / 9007199254740992.0);
+        return exp10(lo + (hi - lo) * u) * (1.0 + v);
+    };
+    unsigned long long bad_div = 0, bad_sqrt = 0;
+    for (unsigned long long k = 0; k < n_per_thread; ++k) {
+        const double a = ((next() & 1ull) ? -1.0 : 1.0) * mag(-17, 11), b = mag(-17, 11);
+        const double q1 = a / b, q2 = div_rn(a, b);
+        bad_div += __double_as_longlong(q1) != __double_as_longlong(q2);
+        const double bk = (k & 1ull) ? 1e-10 : b;   // the divisor the step uses most
+        bad_div += __double_as_longlong(a / bk) != __double_as_longlong(div_rn(a, bk));
+        const double s1 = sqrt(b), s2 = sqrt_rn(b);
+        bad_sqrt += __double_as_longlong(s1) != __double_as_longlong(s2);
+    }
+    atomicAdd(&mismatch[0], bad_div);
+    atomicAdd(&mismatch[1], bad_sqrt);
+}
+
+hipError_t fa_launch_selftest(unsigned long long n_per_thread, unsigned long long seed, unsigned long long *mismatch,
+                              hipStream_t st) {
+    hipLaunchKernelGGL(fa_selftest_kernel, dim3(1024), dim3(256), 0, st, n_per_thread, seed, mismatch);
     return hipGetLastError();
 }
