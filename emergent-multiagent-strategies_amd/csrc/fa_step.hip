@@ -202,16 +202,21 @@ __global__ __launch_bounds__(FA_WAVE) void fa_step_kernel(FaStepArgs a) {
     // returns in order, so a per-step action load would make every step wait (s_waitcnt vmcnt)
     // for the acknowledgement of its predecessor's stores.  One batch = 16 loads in flight,
     // one wait per 16 steps; inside a batch the step only touches LDS (lgkmcnt).
+    // (double buffered: the loads of batch b+1 are issued while batch b is being stepped, so
+    // the wait at a batch boundary only sees the most recent stores, not a load round trip)
+    int av[FA_ACT_BATCH];
+#pragma unroll
+    for (int k = 0; k < FA_ACT_BATCH; ++k)
+        av[k] = (!RESET_ONLY && k < nsteps) ? (int)act_ptr[(int64_t)k * a.as_t] : 0; // uniform
     for (int s = 0; s < nsteps; ++s) {
         if (!RESET_ONLY && (s & (FA_ACT_BATCH - 1)) == 0) {
-            int av[FA_ACT_BATCH];
-#pragma unroll
-            for (int k = 0; k < FA_ACT_BATCH; ++k)
-                av[k] = (s + k < nsteps) ? (int)act_ptr[(int64_t)(s + k) * a.as_t] : 0; // uniform
 #pragma unroll
             for (int k = 0; k < FA_ACT_BATCH; ++k) s_act[k][lane] = av[k];
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int k = 0; k < FA_ACT_BATCH; ++k)
+                av[k] = (s + FA_ACT_BATCH + k < nsteps) ? (int)act_ptr[(int64_t)(s + FA_ACT_BATCH + k) * a.as_t] : 0;
         }
         bool do_reset;
         if (RESET_ONLY) {
