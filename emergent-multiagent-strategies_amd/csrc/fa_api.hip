@@ -523,10 +523,10 @@ int fa_selftest_math(fa_env *env, uint64_t samples, uint64_t seed, uint64_t *mis
     DeviceGuard guard(env->cfg.device_id);
     unsigned long long *d = reinterpret_cast<unsigned long long *>(env->adv_partial); // scratch
     FA_HIP(hipDeviceSynchronize());
-    FA_HIP(hipMemset(d, 0, 16));
+    FA_HIP(hipMemset(d, 0, 24));
     const unsigned long long per = samples / (1024ull * 256ull) + 1ull;
     FA_HIP(fa_launch_selftest(per, seed, d, nullptr));
-    FA_HIP(hipMemcpy(mismatch_host, d, 16, hipMemcpyDeviceToHost));
+    FA_HIP(hipMemcpy(mismatch_host, d, 24, hipMemcpyDeviceToHost));
     return FA_OK;
 }
 

@@ -126,6 +126,38 @@ __device__ __forceinline__ double sqrt_rn(double x) {
     return fma(d, h, g);
 }
 
+// ---- sin and cos of a heading ---------------------------------------------------------------
+// The heading is an unbounded sum of +0.17 / +(2pi - 0.17) steps (quirk Q3): |x| < ~1e3.
+// Cody-Waite reduction by pi/2 in three FMA steps (exact to < 1 ulp of the reduced argument for
+// |x| < 1e5), then the fdlibm __kernel_sin / __kernel_cos minimax polynomials on [-pi/4, pi/4]
+// (< 1 ulp).  ~40 instructions instead of the ~100 of the general-purpose sincos (whose
+// Payne-Hanek path for huge arguments is dead weight here).  Like any libm it differs from
+// glibc's results in the last ulp now and then; that reaches only the laser triangle's vertices
+// (see the note at the call site).  fa_selftest_math() reports the largest deviation from the
+// device library.
+__device__ __forceinline__ void sincos_heading(double x, double &sn, double &cs) {
+    const double kf = rint(x * 0.63661977236758134308);          // x * 2/pi
+    double r = fma(-kf, 1.5707963267948966, x);                    // pi/2 = P1 + P2 + P3
+    r = fma(-kf, 6.123233995736766e-17, r);
+    r = fma(-kf, -1.4973849048591698e-33, r);
+    const double z = r * r;
+    // __kernel_sin
+    const double ps = fma(z, fma(z, fma(z, fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08),
+                                        2.75573137070700676789e-06), -1.98412698298579493134e-04),
+                          8.33333333332248946124e-03);
+    const double s = fma(z * r, fma(z, ps, -1.66666666666666324348e-01), r);
+    // __kernel_cos
+    const double pc = z * fma(z, fma(z, fma(z, fma(z, fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09),
+                                                   -2.75573143513906633035e-07), 2.48015872894767294178e-05),
+                                     -1.38888888888741095749e-03), 4.16666666666666019037e-02);
+    const double hz = 0.5 * z, w = 1.0 - hz;
+    const double c = w + (((1.0 - w) - hz) + z * pc);
+    const int q = (int)kf & 3;
+    const double s2 = (q & 1) ? c : s, c2 = (q & 1) ? s : c;
+    sn = (q & 2) ? -s2 : s2;
+    cs = ((q + 1) & 2) ? -c2 : c2;
+}
+
 // np.logaddexp(0, t) * k, numpy npy_logaddexp with x = 0 (core.py:452, :469).
 //   t >= 40  : t + log1p(exp(-t)) == t exactly (exp(-t) <= 4.3e-18 < ulp(40)/2)
 //   t < -746 : exp underflows to +0, log1p(0) = 0
@@ -246,7 +278,7 @@ __global__ __launch_bounds__(FA_WAVE) void fa_step_kernel(FaStepArgs a) {
                 // directly only in the last ulp, which can move a hit decision only for a target
                 // within ~1e-16 of a triangle edge (same class as libm-vs-libm differences).
                 double sn, cs;
-                sincos(ang, &sn, &cs);
+                sincos_heading(ang, sn, cs);
                 const double x1 = px + c.agent_size * cs, y1 = py + c.agent_size * sn;
                 const double cp = cs * c.cos_hw - sn * c.sin_hw, sp = sn * c.cos_hw + cs * c.sin_hw;
                 const double cm = cs * c.cos_hw + sn * c.sin_hw, sm = sn * c.cos_hw - cs * c.sin_hw;
@@ -596,6 +628,7 @@ __global__ void fa_selftest_kernel(unsigned long long n_per_thread, unsigned lon
         return exp10(lo + (hi - lo) * u) * (1.0 + v);
     };
     unsigned long long bad_div = 0, bad_sqrt = 0;
+    double max_ulp = 0.0;
     for (unsigned long long k = 0; k < n_per_thread; ++k) {
         const double a = ((next() & 1ull) ? -1.0 : 1.0) * mag(-17, 11), b = mag(-17, 11);
         const double q1 = a / b, q2 = div_rn(a, b);
@@ -604,9 +637,19 @@ __global__ void fa_selftest_kernel(unsigned long long n_per_thread, unsigned lon
         bad_div += __double_as_longlong(a / bk) != __double_as_longlong(div_rn(a, bk));
         const double s1 = sqrt(b), s2 = sqrt_rn(b);
         bad_sqrt += __double_as_longlong(s1) != __double_as_longlong(s2);
+        // headings: 1.5 pi + multiples of the two rotation steps, up to ~1e3 rad
+        const double ang = 4.71238898038469 + (double)(next() % 120) * 0.17 + (double)(next() % 120) * 6.113185307179586;
+        double ls, lc, fs, fc;
+        sincos(ang, &ls, &lc);
+        sincos_heading(ang, fs, fc);
+        const double us = fabs(fs - ls) / (fabs(ls) * 2.220446049250313e-16 + 1e-300);
+        const double uc = fabs(fc - lc) / (fabs(lc) * 2.220446049250313e-16 + 1e-300);
+        const double u = us > uc ? us : uc;
+        max_ulp = u > max_ulp ? u : max_ulp;
     }
     atomicAdd(&mismatch[0], bad_div);
     atomicAdd(&mismatch[1], bad_sqrt);
+    atomicMax(&mismatch[2], (unsigned long long)(max_ulp * 1000.0));   // milli-ulp vs the device libm
 }
 
 hipError_t fa_launch_selftest(unsigned long long n_per_thread, unsigned long long seed, unsigned long long *mismatch,

@@ -223,11 +223,12 @@ class BatchedFortAttack(object):
         _lib.check(self._lib.fa_set_state(self._h, C.byref(sh)), "fa_set_state")
 
     def selftest_math(self, samples=1 << 26, seed=1):
-        """fa_selftest_math -> (mismatching quotients, mismatching roots); both must be 0."""
-        out = np.zeros(2, np.uint64)
+        """fa_selftest_math -> (mismatching quotients, mismatching roots, max sin/cos deviation from
+        the device libm in ulp); the first two must be 0."""
+        out = np.zeros(3, np.uint64)
         _lib.check(self._lib.fa_selftest_math(self._h, int(samples), int(seed), out.ctypes.data_as(C.c_void_p)),
                    "fa_selftest_math")
-        return int(out[0]), int(out[1])
+        return int(out[0]), int(out[1]), float(out[2]) / 1000.0
 
     def rng_peek(self, e, count):
         out = np.empty(count, np.float64)

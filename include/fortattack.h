@@ -211,7 +211,9 @@ int fa_get_state(fa_env *env, const fa_state_host *out);
 int fa_set_state(fa_env *env, const fa_state_host *in); /* pos/vel/ang/prev_dist/alive/time_step */
 /* Device self-test: the step kernel's hand-sequenced fp64 divide / sqrt (no range-scaling
  * wrappers) against the compiler's `/` and sqrt() on >= `samples` random operands of the
- * magnitudes the step uses; mismatch_host[0] = differing quotients, [1] = differing roots. */
+ * magnitudes the step uses; mismatch_host[0] = differing quotients, [1] = differing roots,
+ * [2] = largest deviation of the heading sin/cos from the device libm, in 1/1000 ulp
+ * (mismatch_host holds 3 values). */
 int fa_selftest_math(fa_env *env, uint64_t samples, uint64_t seed, uint64_t *mismatch_host);
 /* next `count` random_sample() doubles env e would draw (does not advance the stream) */
 int fa_rng_peek(fa_env *env, int32_t e, int32_t count, double *out_host);
