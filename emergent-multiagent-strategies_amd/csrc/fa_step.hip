@@ -181,13 +181,13 @@ __device__ __forceinline__ double softplus_pen(double t, double k) {
 // the reference's SVD pseudo-inverse is the exact inverse of this never-singular matrix).
 __device__ __forceinline__ bool laser_hit(double x1, double y1, double x2, double y2, double x3,
                                           double y3, double px, double py) {
-    double w1 = (x2 - px) * (y3 - py) - (x3 - px) * (y2 - py);
-    double w2 = (x3 - px) * (y1 - py) - (x1 - px) * (y3 - py);
-    double w3 = (x1 - px) * (y2 - py) - (x2 - px) * (y1 - py);
-    double det = (w1 + w2) + w3;
-    if (det > 0) return w1 >= 0 && w2 >= 0 && w3 >= 0;
-    if (det < 0) return w1 <= 0 && w2 <= 0 && w3 <= 0;
-    return false;
+    const double w1 = (x2 - px) * (y3 - py) - (x3 - px) * (y2 - py);
+    const double w2 = (x3 - px) * (y1 - py) - (x1 - px) * (y3 - py);
+    const double w3 = (x1 - px) * (y2 - py) - (x2 - px) * (y1 - py);
+    const double det = (w1 + w2) + w3;
+    // bitwise, not short-circuit: no divergent branches (each costs a VALU->SALU round trip)
+    const bool pos = (w1 >= 0) & (w2 >= 0) & (w3 >= 0), neg = (w1 <= 0) & (w2 <= 0) & (w3 <= 0);
+    return ((det > 0) & pos) | ((det < 0) & neg);
 }
 
 // COLLECT: the four trainer rows (obs32, rew32, mask32, done) are all present and nothing
@@ -332,7 +332,7 @@ __global__ __launch_bounds__(FA_WAVE) void fa_step_kernel(FaStepArgs a) {
                     for (int k = 0; k < KT; ++k) {
                         const int j = gbase + opp0 + k;
                         const bool cand = alive0 && k < n_opp && ((shooters_b >> j) & 1ull);
-                        hk[k] = cand && laser_hit(tr[k][0], tr[k][1], tr[k][2], tr[k][3], tr[k][4], tr[k][5], px, py);
+                        hk[k] = cand & laser_hit(tr[k][0], tr[k][1], tr[k][2], tr[k][3], tr[k][4], tr[k][5], px, py);
                     }
 #pragma unroll
                     for (int k = 0; k < KT; ++k) {
@@ -443,32 +443,20 @@ __global__ __launch_bounds__(FA_WAVE) void fa_step_kernel(FaStepArgs a) {
             const bool any_in_fort = ((in_fort_b >> gbase) & grp_mask) != 0ull;
             const bool rewarded = valid && (alive1 || just_died);
             const bool has_prev = !(prev != prev); // NaN encodes prevDist None
-            double rew = 0.0;
-            if (rewarded) {
-                if (is_att) { // :94-128
-                    double r0 = 0, r1 = 0, r2 = 0, r3 = 0, r4 = 0, r5 = 0;
-                    if (has_prev) r0 = 2 * (prev - dist_door);
-                    if (dist_door < c.fort_dim) r1 = 10;
-                    if (shoot) r2 = -1;
-                    if (hit) r3 = +3;
-                    if (was_hit) r4 = -3;
-                    if (n_alive_att == 0) r5 = -10;
-                    rew = r0 + r1 + r2 + r3 + r4 + r5;
-                } else {      // :130-188
-                    double r0 = 0, r3 = 0, r4 = 0, r5 = 0, r6 = 0, r7 = 0;
-                    if (has_prev) {
-                        if (dist_door > 0.3 && prev <= 0.3) r0 = -1;
-                        else if (dist_door <= 0.3 && prev > 0.3) r0 = 1;
-                    }
-                    if (n_alive_att != 0 && any_in_fort) r3 = -10; // min over alive attackers < th
-                    if (shoot) r4 = -0.1;
-                    if (hit) r5 = 3;
-                    if (was_hit) r6 = -3;
-                    if (n_alive_att == 0) r7 = 10;
-                    rew = r0 + 0.0 + 0.0 + r3 + r4 + r5 + r6 + r7 + 0.0;
-                }
-                prev = dist_door;
-            }
+            // attacker_reward (:94-128) and guard_reward (:130-188) as one select chain: both are
+            // a sum of six terms added left to right -- attacker r0..r5; guard r0, r3..r7 (its r1,
+            // r2, r8 are literal zeros and x + 0.0 == x) -- so the per-team terms are selected and
+            // the additions are shared.  No divergent team branch.
+            const double g0 = ((dist_door > 0.3) & (prev <= 0.3)) ? -1.0 : (((dist_door <= 0.3) & (prev > 0.3)) ? 1.0 : 0.0);
+            const double t0 = has_prev ? (is_att ? 2 * (prev - dist_door) : g0) : 0.0;
+            const bool c1 = is_att ? (dist_door < c.fort_dim) : ((n_alive_att != 0) & any_in_fort);
+            const double t1 = c1 ? (is_att ? 10.0 : -10.0) : 0.0;
+            const double t2 = shoot ? (is_att ? -1.0 : -0.1) : 0.0;
+            const double t3 = hit ? 3.0 : 0.0;
+            const double t4 = was_hit ? -3.0 : 0.0;
+            const double t5 = (n_alive_att == 0) ? (is_att ? -10.0 : 10.0) : 0.0;
+            const double rew = rewarded ? (t0 + t1 + t2 + t3 + t4 + t5) : 0.0;
+            prev = rewarded ? dist_door : prev;
 
             // ---- fortattack.py:202-225 _get_done, :171 time_step += 1 ------------------
             const bool timeout = t == a.max_t - 1;
