@@ -52,13 +52,14 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32
 
 // fortattack_env_v1.py:47-75 reset_world, for the lane's agent.  Agent i consumes the
 // 2 doubles (4 words) number 2i, 2i+1 of this reset.  All lanes of the env call together.
+// `base` = env cursor + 4*i, kept in a register across the launch (one dependent load less per
+// reset); on return it is the base of the lane's next draw.
 __device__ __forceinline__ void reset_agent(const FaStepArgs &a, int e, int i, int N, bool is_att,
-                                            bool active, double &px, double &py) {
+                                            bool active, int &base, double &px, double &py) {
     uint32_t w[4] = {0, 0, 0, 0};
     if (active) {
         if (a.rng_mode == 0) {
-            uint32_t *mt = a.s.mt + (size_t)e * FA_MT_N;
-            const int base = a.s.mt_pos[e] + 4 * i; // < 624 + 64
+            uint32_t *mt = a.s.mt + (size_t)e * FA_MT_N; // base < 624 + 64
             uint32_t cur[5], far_[4];
 #pragma unroll
             for (int k = 0; k < 5; ++k) cur[k] = mt[mt_wrap(base + k)];
@@ -71,6 +72,7 @@ __device__ __forceinline__ void reset_agent(const FaStepArgs &a, int e, int i, i
                 mt[mt_wrap(base + k)] = nw;
                 w[k] = mt_temper(nw);
             }
+            base = mt_wrap(base - 4 * i + 4 * N) + 4 * i;
         } else {
             const uint64_t genv = (uint64_t)(a.env_offset + e);
             uint32_t c[4] = {(uint32_t)genv, (uint32_t)(genv >> 32), a.s.reset_count[e], (uint32_t)i};
@@ -89,8 +91,9 @@ __device__ __forceinline__ void reset_agent(const FaStepArgs &a, int e, int i, i
 }
 
 // after every lane of the env has drawn: advance the env's cursor (one lane per env)
-__device__ __forceinline__ void reset_advance(const FaStepArgs &a, int e, int N) {
-    if (a.rng_mode == 0) a.s.mt_pos[e] = mt_wrap(a.s.mt_pos[e] + 4 * N);
+// (lane i == 0: its draw base IS the env's cursor)
+__device__ __forceinline__ void reset_advance(const FaStepArgs &a, int e, int next_base) {
+    if (a.rng_mode == 0) a.s.mt_pos[e] = next_base;
     else a.s.reset_count[e] += 1u;
 }
 
@@ -227,6 +230,7 @@ __global__ __launch_bounds__(FA_WAVE) void fa_step_kernel(FaStepArgs a) {
         if (a.track_counters) { nh = a.s.num_hit[idx]; nwh = a.s.num_was_hit[idx]; ep_rew = a.s.ep_rew[idx]; }
     }
     bool dirty = false; // state changed => write it back
+    int mt_base = (a.rng_mode == 0 ? a.s.mt_pos[e] : 0) + 4 * i; // cursor + 4*i of this lane's next reset draw
 
     const int nsteps = RESET_ONLY ? 1 : a.nsteps;
     const int64_t *act_ptr = RESET_ONLY ? nullptr : a.actions + (int64_t)e * a.as_e + (int64_t)i * a.as_i;
@@ -511,7 +515,7 @@ __global__ __launch_bounds__(FA_WAVE) void fa_step_kernel(FaStepArgs a) {
         // (prevDist and the action are NOT reset: SURVEY quirk Q1)
         if (__ballot(do_reset) != 0ull) {
             double npx = px, npy = py;
-            reset_agent(a, e, i, N, is_att, do_reset, npx, npy);
+            reset_agent(a, e, i, N, is_att, do_reset, mt_base, npx, npy);
             if (do_reset) {
                 px = npx; py = npy; vx = 0.0; vy = 0.0;
                 ang = is_att ? c.ang_attacker : c.ang_guard;
@@ -520,7 +524,7 @@ __global__ __launch_bounds__(FA_WAVE) void fa_step_kernel(FaStepArgs a) {
                 nh = 0; nwh = 0;
                 dirty = true;
                 if (i == 0) {
-                    reset_advance(a, e, N);
+                    reset_advance(a, e, mt_base);
                     if (RESET_ONLY) { uint8_t *gr = a.s.game_result + (size_t)e * 3; gr[0] = gr[1] = gr[2] = 0; }
                 }
             }
