@@ -298,9 +298,12 @@ __global__ __launch_bounds__(FA_WAVE) void fa_step_kernel(FaStepArgs a) {
 
             // partner deltas for the contact test, fetched now (they do not depend on the laser):
             // the LDS latency and the 5 flops per partner overlap with the laser tests below
+            // (only for small teams: at N = 10 the 30 extra live doubles push the kernel past
+            // 256 VGPRs and into scratch)
             constexpr int NT = (TG != 0) ? TG + TA : 0;
+            constexpr bool HOIST = NT != 0 && NT <= 8;
             double dxs[NT ? NT : 1], dys[NT ? NT : 1], d2s[NT ? NT : 1];
-            if constexpr (NT != 0) {
+            if constexpr (HOIST) {
 #pragma unroll
                 for (int j = 0; j < NT; ++j) {
                     dxs[j] = px - s_px[gbase + j];
@@ -374,6 +377,14 @@ __global__ __launch_bounds__(FA_WAVE) void fa_step_kernel(FaStepArgs a) {
                 // -(f(j,i)) for j<i, which is bitwise the same number as f computed from
                 // i's side (negation commutes exactly with *, / and the sqrt argument).
                 if constexpr (NT != 0) {
+                    if constexpr (!HOIST) {
+#pragma unroll
+                        for (int j = 0; j < NT; ++j) {
+                            dxs[j] = px - s_px[gbase + j];
+                            dys[j] = py - s_py[gbase + j];
+                            d2s[j] = dxs[j] * dxs[j] + dys[j] * dys[j];
+                        }
+                    }
                     // only partners actually in range take the slow path
 #pragma unroll
                     for (int j = 0; j < NT; ++j) {
