@@ -36,30 +36,29 @@ class JointRolloutStorage(object):
 
 
 class RolloutStorage(object):
-    """rlcore/storage.py:9 -- same constructor, fields, shapes and methods.
+    """rlcore/storage.py:9 -- same constructor signature, field names, shapes and methods.
 
-    Standalone (reference constructor) it owns contiguous tensors; as ``view_of`` a
-    JointRolloutStorage its tensors are strided windows and every method writes through.
+    Built standalone (the reference's constructor) it owns contiguous tensors; built with
+    ``view_of`` it is agent i's window onto a JointRolloutStorage and every method writes
+    through to the joint tensors.
     """
+    # field -> (rows beyond num_steps, trailing shape key, dtype, fill)   (storage.py:11-19)
+    _SPEC = (("obs", 1, "obs", torch.float32, 0.0), ("recurrent_hidden_states", 1, "hid", torch.float32, 0.0),
+             ("rewards", 0, "one", torch.float32, 0.0), ("value_preds", 1, "one", torch.float32, 0.0),
+             ("returns", 1, "one", torch.float32, 0.0), ("action_log_probs", 0, "one", torch.float32, 0.0),
+             ("actions", 0, "one", torch.int64, 0), ("masks", 1, "one", torch.float32, 1.0))
 
     def __init__(self, num_steps, num_processes, obs_shape, action_space, recurrent_hidden_state_size):
-        self.obs = torch.zeros(num_steps + 1, num_processes, *obs_shape)
-        self.recurrent_hidden_states = torch.zeros(num_steps + 1, num_processes, recurrent_hidden_state_size)
-        self.rewards = torch.zeros(num_steps, num_processes, 1)
-        self.value_preds = torch.zeros(num_steps + 1, num_processes, 1)
-        self.returns = torch.zeros(num_steps + 1, num_processes, 1)
-        self.action_log_probs = torch.zeros(num_steps, num_processes, 1)
-        self.actions = torch.zeros(num_steps, num_processes, 1).long()
-        self.masks = torch.ones(num_steps + 1, num_processes, 1)
-        self.num_steps = num_steps
-        self.step = 0
-        self._joint = None
+        tail = {"obs": tuple(obs_shape), "hid": (recurrent_hidden_state_size,), "one": (1,)}
+        for name, extra, key, dtype, fill in self._SPEC:
+            setattr(self, name, torch.full((num_steps + extra, num_processes) + tail[key], fill, dtype=dtype))
+        self.num_steps, self.step, self._joint = num_steps, 0, None
 
     @classmethod
     def view_of(cls, joint, i):
         self = cls.__new__(cls)
-        for k in JointRolloutStorage.FIELDS:
-            setattr(self, k, getattr(joint, k)[:, :, i])
+        for name in JointRolloutStorage.FIELDS:
+            setattr(self, name, getattr(joint, name)[:, :, i])
         self.num_steps, self.step, self._joint = joint.num_steps, 0, joint
         return self
 
@@ -68,63 +67,57 @@ class RolloutStorage(object):
             if torch.device(device) != self.obs.device:
                 raise ValueError("a joint-storage view lives on the joint tensors' device")
             return
-        for k in JointRolloutStorage.FIELDS:
-            setattr(self, k, getattr(self, k).to(device))
+        for name in JointRolloutStorage.FIELDS:
+            setattr(self, name, getattr(self, name).to(device))
 
     def insert(self, obs, recurrent_hidden_states, actions, action_log_probs, value_preds, rewards, masks):
-        s = self.step  # storage.py:33-43
-        self.obs[s + 1].copy_(obs)
-        self.recurrent_hidden_states[s + 1].copy_(recurrent_hidden_states)
-        self.actions[s].copy_(actions)
-        self.action_log_probs[s].copy_(action_log_probs)
-        self.value_preds[s].copy_(value_preds)
-        self.rewards[s].copy_(rewards)
-        self.masks[s + 1].copy_(masks)
+        """storage.py:33-43: rows s+1 get what the step produced, rows s what the policy chose."""
+        s = self.step
+        for dst, row, src in ((self.obs, s + 1, obs), (self.recurrent_hidden_states, s + 1, recurrent_hidden_states),
+                              (self.actions, s, actions), (self.action_log_probs, s, action_log_probs),
+                              (self.value_preds, s, value_preds), (self.rewards, s, rewards),
+                              (self.masks, s + 1, masks)):
+            dst[row].copy_(src)
         self.step = (s + 1) % self.num_steps
 
     def reset(self):  # storage.py:48-49
         self.step = 0
 
     def after_update(self):  # storage.py:51-56
-        self.obs[0].copy_(self.obs[-1])
+        for t in (self.obs, self.recurrent_hidden_states, self.masks):
+            t[0].copy_(t[-1])
         self.obs[1:] = 0
-        self.recurrent_hidden_states[0].copy_(self.recurrent_hidden_states[-1])
-        self.masks[0].copy_(self.masks[-1])
         self.step = 0
 
     def compute_returns(self, next_value, use_gae, gamma, tau, start_pt, end_pt):
-        """storage.py:59-71, torch ops (host-sequenced).  The batched path is fa_gae."""
-        if use_gae:
-            self.value_preds[end_pt] = next_value
-            gae = 0
-            for step in reversed(range(start_pt, end_pt)):
-                delta = self.rewards[step] + gamma * self.value_preds[step + 1] * self.masks[step + 1] \
-                    - self.value_preds[step]
-                gae = delta + gamma * tau * self.masks[step + 1] * gae
-                self.returns[step] = gae + self.value_preds[step]
-        else:
+        """storage.py:59-71 on torch tensors, host-sequenced (the batched path is fa_gae)."""
+        r, v, m = self.rewards, self.value_preds, self.masks
+        if not use_gae:
             self.returns[end_pt] = next_value
-            for step in reversed(range(start_pt, end_pt)):
-                self.returns[step] = self.returns[step + 1] * gamma * self.masks[step + 1] + self.rewards[step]
+            for t in range(end_pt - 1, start_pt - 1, -1):
+                self.returns[t] = self.returns[t + 1] * gamma * m[t + 1] + r[t]
+            return
+        v[end_pt] = next_value
+        gae = 0
+        for t in range(end_pt - 1, start_pt - 1, -1):
+            delta = r[t] + gamma * v[t + 1] * m[t + 1] - v[t]
+            gae = delta + gamma * tau * m[t + 1] * gae
+            self.returns[t] = gae + v[t]
 
     def feed_forward_generator(self, advantages, num_mini_batch, sampler=None):
-        """storage.py:74-96."""
+        """storage.py:74-96: random minibatches of flattened (T*P) samples, in the reference's
+        tuple order (obs, hidden, actions, value_preds, returns, masks, old log-probs, adv)."""
         from torch.utils.data.sampler import BatchSampler, SubsetRandomSampler
-        num_steps, num_processes = self.rewards.size()[0:2]
-        batch_size = num_processes * num_steps
+        T, P = self.rewards.shape[:2]
+        batch_size = T * P
         assert batch_size >= num_mini_batch, (
             "PPO requires the number of processes ({}) * number of steps ({}) = {} to be greater than "
-            "or equal to the number of PPO mini batches ({}).".format(
-                num_processes, num_steps, batch_size, num_mini_batch))
-        mini_batch_size = batch_size // num_mini_batch
+            "or equal to the number of PPO mini batches ({}).".format(P, T, batch_size, num_mini_batch))
         if sampler is None:
-            sampler = BatchSampler(SubsetRandomSampler(range(batch_size)), mini_batch_size, drop_last=False)
+            sampler = BatchSampler(SubsetRandomSampler(range(batch_size)), batch_size // num_mini_batch,
+                                   drop_last=False)
+        flat = [self.obs[:-1], self.recurrent_hidden_states[:-1], self.actions, self.value_preds[:-1],
+                self.returns[:-1], self.masks[:-1], self.action_log_probs, advantages]
+        flat = [t.view(batch_size, *t.shape[2:]) for t in flat]
         for indices in sampler:
-            yield (self.obs[:-1].view(-1, *self.obs.size()[2:])[indices],
-                   self.recurrent_hidden_states[:-1].view(-1, self.recurrent_hidden_states.size(-1))[indices],
-                   self.actions.view(-1, self.actions.size(-1))[indices],
-                   self.value_preds[:-1].view(-1, 1)[indices],
-                   self.returns[:-1].view(-1, 1)[indices],
-                   self.masks[:-1].view(-1, 1)[indices],
-                   self.action_log_probs.view(-1, 1)[indices],
-                   advantages.view(-1, 1)[indices])
+            yield tuple(t[indices] for t in flat)
