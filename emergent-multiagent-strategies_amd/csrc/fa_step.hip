@@ -1,17 +1,19 @@
 // fa_step.hip -- the FortAttack env.step / reset kernels for CDNA4 (gfx950).
 //
-// One launch advances every env of the handle by one step.  Mapping: lane = agent, a
-// wave64 = EPW = 64/N whole envs, one wave per workgroup (E=4096, N=6 -> 410 workgroups
-// over 256 CUs: the launch is latency bound, so the work is spread as thin as possible).
+// One launch advances every env of the handle by `nsteps` env-steps (1 = closed loop, the policy
+// runs between launches; K = open-loop rollout with the world state held in registers).
+// Mapping: lane = agent, a wave64 = EPW = 64/N whole envs, one wave per workgroup (E=4096, N=6
+// -> 410 workgroups over 256 CUs: the launch is latency bound, so the work is spread thin).
 // Cross-agent data moves two ways, both inside the wave (no workgroup barrier):
 //   * positions and laser triangles are staged in LDS and read back with per-lane
-//     addresses (broadcast reads inside an env);
+//     addresses (broadcast reads inside an env); actions reach the loop through LDS too;
 //   * every flag reduction (who shoots, who is alive, who was hit by whom, attackers in
 //     the fort) is a 64-bit wave ballot shifted to the env's lane group + popcount.
 // Float semantics: every fp64 operation is written in the order the reference evaluates
-// it (file:line cited per block); built with -ffp-contract=off so nothing is fused.
-// The exact shortcuts (skipping a contact whose soft penalty is exactly 0.0) are argued
-// where they are taken.
+// it (file:line cited per block); built with -ffp-contract=off so nothing is fused (the
+// explicit fma() calls below are the compiler's own divide / sqrt / polynomial sequences).
+// The exact shortcuts (skipping a contact whose soft penalty is exactly 0.0, sqrt-free speed
+// test, wrapper-free divide/sqrt) are argued where they are taken.
 #include "fa_device.h"
 
 // ---- numpy legacy RandomState (MT19937), incremental form --------------------------
@@ -207,7 +209,6 @@ __global__ __launch_bounds__(FA_WAVE) void fa_step_kernel(FaStepArgs a) {
     const int gbase = slot * N;           // first lane of this env's group
     const int e = blockIdx.x * EPW + slot;
     if (!((slot < EPW) && (e < a.E))) return; // padding lanes leave: ballots count live lanes only
-    const bool valid = true;
     const bool is_att = i >= G;
     const size_t idx = (size_t)e * N + i;
     const size_t EN = (size_t)a.E * N;
@@ -222,7 +223,7 @@ __global__ __launch_bounds__(FA_WAVE) void fa_step_kernel(FaStepArgs a) {
     bool alive = false;
     int t = 0, nh = 0, nwh = 0;
     double ep_rew = 0.0; // episode return so far (reward * alive-before mask), track_counters only
-    if (valid) {
+    {
         px = a.s.px[idx]; py = a.s.py[idx]; vx = a.s.vx[idx]; vy = a.s.vy[idx];
         ang = a.s.ang[idx]; prev = a.s.prev[idx];
         alive = a.s.alive[idx] != 0;
@@ -256,7 +257,7 @@ __global__ __launch_bounds__(FA_WAVE) void fa_step_kernel(FaStepArgs a) {
         }
         bool do_reset;
         if (RESET_ONLY) {
-            do_reset = valid && (a.reset_mask == nullptr || a.reset_mask[e] != 0);
+            do_reset = (a.reset_mask == nullptr || a.reset_mask[e] != 0);
         } else {
             const bool alive0 = alive;
             // ---- fortattack.py:253-263,:289 _set_action (all agents, dead ones too) ----
@@ -275,7 +276,7 @@ __global__ __launch_bounds__(FA_WAVE) void fa_step_kernel(FaStepArgs a) {
             // ---- stage positions + laser triangles in LDS (core.py:373-382) ------------
             s_px[lane] = px;
             s_py[lane] = py;
-            const bool shooter = valid && alive0 && shoot;
+            const bool shooter = alive0 && shoot;
             if (shooter) {
                 // one sincos; cos/sin(ang +- shootWin/2) by the angle-addition identities with
                 // host-evaluated cos/sin(shootWin/2).  Differs from evaluating cos(ang +- w/2)
@@ -366,11 +367,11 @@ __global__ __launch_bounds__(FA_WAVE) void fa_step_kernel(FaStepArgs a) {
             const bool hit = shooter && hit_cnt > 0;
             const bool alive1 = alive0 && !was_hit;       // :293-302 one shot kills
             const bool just_died = alive0 && was_hit;
-            const unsigned long long grp_alive1 = (__ballot(valid && alive1) >> gbase) & grp_mask;
+            const unsigned long long grp_alive1 = (__ballot(alive1) >> gbase) & grp_mask;
             const int n_alive_att = __popcll(grp_alive1 >> G);
 
             // ---- forces + integration for agents alive after the laser ----------------
-            if (valid && alive1) {
+            if (alive1) {
                 double Fx = u0 + 0.0, Fy = u1 + 0.0;      // core.py:221-228
                 // core.py:231-243 + :440-456.  Reference order: pairs (a,b), a<b, lexicographic;
                 // for agent i that is partner j ascending, with f_i = +f for j>i and
@@ -454,9 +455,9 @@ __global__ __launch_bounds__(FA_WAVE) void fa_step_kernel(FaStepArgs a) {
             const double ddx = px - c.door_x, ddy = py - c.door_y;
             const double dist_door = sqrt_rn(ddx * ddx + ddy * ddy);
             const unsigned long long in_fort_b =
-                __ballot(valid && is_att && alive1 && dist_door < c.fort_dim);
+                __ballot(is_att && alive1 && dist_door < c.fort_dim);
             const bool any_in_fort = ((in_fort_b >> gbase) & grp_mask) != 0ull;
-            const bool rewarded = valid && (alive1 || just_died);
+            const bool rewarded = (alive1 || just_died);
             const bool has_prev = !(prev != prev); // NaN encodes prevDist None
             // attacker_reward (:94-128) and guard_reward (:130-188) as one select chain: both are
             // a sum of six terms added left to right -- attacker r0..r5; guard r0, r3..r7 (its r1,
@@ -476,7 +477,7 @@ __global__ __launch_bounds__(FA_WAVE) void fa_step_kernel(FaStepArgs a) {
             // ---- fortattack.py:202-225 _get_done, :171 time_step += 1 ------------------
             const bool timeout = t == a.max_t - 1;
             const bool done = any_in_fort || n_alive_att == 0 || timeout;
-            if (valid && i == 0) {
+            if (i == 0) {
                 if (done) {
                     const int which = any_in_fort ? 2 : (n_alive_att == 0 ? 0 : 1);
                     uint8_t *gr = a.s.game_result + (size_t)e * 3;
@@ -497,7 +498,7 @@ __global__ __launch_bounds__(FA_WAVE) void fa_step_kernel(FaStepArgs a) {
                     dirty = true;
                 }
             }
-            do_reset = valid && done && a.auto_reset != 0;
+            do_reset = done && a.auto_reset != 0;
             dirty = dirty || alive0;
             alive = alive1;
             nh += hit_cnt;
@@ -542,7 +543,7 @@ __global__ __launch_bounds__(FA_WAVE) void fa_step_kernel(FaStepArgs a) {
         }
 
         // ---- observation row (fortattack_env_v1.py:238) ------------------------------------
-        if (valid && (!RESET_ONLY || do_reset)) {
+        if ((!RESET_ONLY || do_reset)) {
             const double al = alive ? 1.0 : 0.0;
             const size_t o6 = ((size_t)s * EN + idx) * 6;
             if (COLLECT || a.obs32) {
@@ -564,13 +565,13 @@ __global__ __launch_bounds__(FA_WAVE) void fa_step_kernel(FaStepArgs a) {
     }
 
     // ---- write back state once per launch ----------------------------------------------------
-    if (valid && dirty) {
+    if (dirty) {
         a.s.px[idx] = px; a.s.py[idx] = py; a.s.vx[idx] = vx; a.s.vy[idx] = vy;
         a.s.ang[idx] = ang; a.s.prev[idx] = prev;
         a.s.alive[idx] = alive ? 1 : 0;
         if (a.track_counters) { a.s.num_hit[idx] = nh; a.s.num_was_hit[idx] = nwh; a.s.ep_rew[idx] = ep_rew; }
     }
-    if (valid && i == 0 && (!RESET_ONLY || dirty)) a.s.tstep[e] = t;
+    if (i == 0 && (!RESET_ONLY || dirty)) a.s.tstep[e] = t;
 }
 
 // ---- np.random.seed(int): init_genrand, then discard the construction draws ----------
