@@ -177,6 +177,54 @@ __global__ __launch_bounds__(256) void fa_adv_partial_kernel(const float *__rest
     }
 }
 
+// Same reduction for a compile-time even N with 16-byte loads: a lane takes two whole rows
+// (2N floats = N/2 float4, 48 B at N = 6) per trip, so the agent of every loaded element is a
+// compile-time constant and the wave reads one contiguous span.  (The row-per-lane kernel above
+// issues N scalar loads with a 4N-byte lane stride and reaches only ~1.5 TB/s.)
+template <int PASS, int TN>
+__global__ __launch_bounds__(256) void fa_adv_partial_vec_kernel(const float *__restrict__ returns,
+                                                                 const float *__restrict__ value_preds,
+                                                                 const double *__restrict__ mean, long long row_pairs,
+                                                                 double *__restrict__ partial) {
+    constexpr int NV = TN / 2; // float4 per row pair
+    __shared__ double red[4][TN];
+    double acc[TN], mu[TN];
+#pragma unroll
+    for (int i = 0; i < TN; ++i) { acc[i] = 0.0; mu[i] = PASS == 1 ? mean[i] : 0.0; }
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < row_pairs; p += stride) {
+        const float4 *r4 = reinterpret_cast<const float4 *>(returns + p * 2 * TN);
+        const float4 *v4 = reinterpret_cast<const float4 *>(value_preds + p * 2 * TN);
+        float4 rr[NV], vv[NV];
+#pragma unroll
+        for (int q = 0; q < NV; ++q) { rr[q] = r4[q]; vv[q] = v4[q]; }
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+            const float a4[4] = {rr[q].x - vv[q].x, rr[q].y - vv[q].y, rr[q].z - vv[q].z, rr[q].w - vv[q].w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int i = (4 * q + j) % TN; // folds to a constant after unrolling
+                const double adv = (double)a4[j];
+                if (PASS == 0) acc[i] += adv;
+                else { const double d = adv - mu[i]; acc[i] += d * d; }
+            }
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+        double v = acc[i];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if (lane == 0) red[wave][i] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < TN) {
+        const int i = threadIdx.x;
+        partial[((long long)blockIdx.x * TN + i)] = ((red[0][i] + red[1][i]) + red[2][i]) + red[3][i];
+    }
+}
+
 // stats[i] = {n, sum, 0} (PASS 0) / stats[i][2] = ssd (PASS 1).  One wave per agent: lane l
 // folds partials l, l+64, ... in order, then a fixed shuffle tree => reproducible.
 template <int PASS>
@@ -270,17 +318,30 @@ hipError_t fa_launch_gae(const float *rewards, const float *value_preds, const f
     return hipGetLastError();
 }
 
+template <int PASS>
+static void launch_adv_partial(const float *returns, const float *value_preds, const double *mean, long long rows,
+                               int N, double *partial, int nblocks, hipStream_t st) {
+    const bool vec = (rows % 2 == 0) && ((((uintptr_t)returns | (uintptr_t)value_preds) & 15) == 0);
+    if (vec && N == 6)
+        hipLaunchKernelGGL((fa_adv_partial_vec_kernel<PASS, 6>), dim3(nblocks), dim3(256), 0, st, returns, value_preds,
+                           mean, rows / 2, partial);
+    else if (vec && N == 10)
+        hipLaunchKernelGGL((fa_adv_partial_vec_kernel<PASS, 10>), dim3(nblocks), dim3(256), 0, st, returns, value_preds,
+                           mean, rows / 2, partial);
+    else
+        hipLaunchKernelGGL(fa_adv_partial_kernel<PASS>, dim3(nblocks), dim3(256), 0, st, returns, value_preds, mean,
+                           rows, N, partial);
+}
+
 hipError_t fa_launch_adv_stats(int pass, const float *returns, const float *value_preds, const double *mean,
                                long long rows, int N, double *partial, int nblocks, double *stats,
                                double *derived, hipStream_t st) {
     if (pass == 0) {
-        hipLaunchKernelGGL(fa_adv_partial_kernel<0>, dim3(nblocks), dim3(256), 0, st, returns, value_preds,
-                           mean, rows, N, partial);
+        launch_adv_partial<0>(returns, value_preds, mean, rows, N, partial, nblocks, st);
         hipLaunchKernelGGL(fa_adv_final_kernel<0>, dim3(1), dim3(64 * N), 0, st, partial, nblocks, N,
                            (double)rows, stats, derived);
     } else {
-        hipLaunchKernelGGL(fa_adv_partial_kernel<1>, dim3(nblocks), dim3(256), 0, st, returns, value_preds,
-                           mean, rows, N, partial);
+        launch_adv_partial<1>(returns, value_preds, mean, rows, N, partial, nblocks, st);
         hipLaunchKernelGGL(fa_adv_final_kernel<1>, dim3(1), dim3(64 * N), 0, st, partial, nblocks, N,
                            (double)rows, stats, derived);
     }
