@@ -21,7 +21,7 @@ import torch.nn as nn
 from torch._utils import _flatten_dense_tensors, _unflatten_dense_tensors
 
 from .dist import adv_mean_std
-from .mpnn import MPNN
+from .mpnn import MPNN, TwinMPNN
 from .storage import JointRolloutStorage
 
 
@@ -74,6 +74,7 @@ class BatchedLearner(object):
         self._graphs = None
         self.episode_rewards = torch.zeros((self.E, self.N), device=self.device)
         self.attacker_pool, self.attacker_id = [], None
+        self._twin_net = None
 
     # ---- model I/O (train_fortattack.py:123-128, learner.py:245-249) ----------------------
     def state_dicts(self):
@@ -133,10 +134,25 @@ class BatchedLearner(object):
             self._graphs = self._capture()
         self.eng.collect_reset()
 
+    def _twin(self):
+        """One batched pass for both teams when they have the same size (and no ensemble)."""
+        if self.G != self.A or self.attacker_pool:
+            return None
+        if self._twin_net is None:
+            self._twin_net = TwinMPNN(self.policies[0], self.policies[1])
+        return self._twin_net
+
     @torch.no_grad()
     def _act_into_storage(self, s):
         st = self.storage
         obs = st.obs[s]
+        twin = self._twin()
+        if twin is not None:
+            value, action, logp = twin.act(obs)
+            st.value_preds[s].copy_(value)
+            st.actions[s].copy_(action)
+            st.action_log_probs[s].copy_(logp)
+            return
         for pol, own_sl, opp_sl in ((self.policies[0], self.team_slices[0], self.team_slices[1]),
                                     (self.policies[1], self.team_slices[1], self.team_slices[0])):
             if pol is self.policies[1] and self.attacker_pool:
@@ -203,6 +219,8 @@ class BatchedLearner(object):
             raise RuntimeError("call reset() before collect()")
         for pol in self.policies + list(self.attacker_pool):
             pol.refresh_fused_weights()   # captured graphs read these buffers; weights may have moved
+        if self._twin() is not None:
+            self._twin_net.refresh()
         for s in range(self.T):
             if self._graphs is not None:
                 self._graphs[s].replay()
@@ -210,12 +228,16 @@ class BatchedLearner(object):
                 self.step(s)
         with torch.no_grad():                      # wrap_horizon: V(obs[T]) (learner.py:196-202)
             obs = st.obs[self.T]
-            for pol, own_sl, opp_sl in ((self.policies[0], self.team_slices[0], self.team_slices[1]),
-                                        (self.policies[1], self.team_slices[1], self.team_slices[0])):
-                if pol is self.policies[1] and self.attacker_pool:
-                    st.value_preds[self.T, :, own_sl] = self._attacker_forward("get_value", obs[:, own_sl], obs[:, opp_sl])
-                else:
-                    st.value_preds[self.T, :, own_sl] = pol.get_value(obs[:, own_sl], obs[:, opp_sl])
+            if self._twin() is not None:
+                st.value_preds[self.T].copy_(self._twin_net.get_value(obs))
+            else:
+                for pol, own_sl, opp_sl in ((self.policies[0], self.team_slices[0], self.team_slices[1]),
+                                            (self.policies[1], self.team_slices[1], self.team_slices[0])):
+                    if pol is self.policies[1] and self.attacker_pool:
+                        st.value_preds[self.T, :, own_sl] = self._attacker_forward("get_value", obs[:, own_sl],
+                                                                                   obs[:, opp_sl])
+                    else:
+                        st.value_preds[self.T, :, own_sl] = pol.get_value(obs[:, own_sl], obs[:, opp_sl])
         self.eng.gae(self.gamma, self.tau)
         # train_fortattack.py:88: episode_rewards += reward * masks (alive before the step)
         self.episode_rewards = (st.rewards * st.masks[1:]).sum(0)[..., 0]

@@ -202,3 +202,108 @@ class MPNN(nn.Module):
         value, logp, ent = self.evaluate_actions(own, opp, act)
         flat = lambda t: t.transpose(0, 1).reshape(-1, t.shape[-1])
         return flat(value), flat(logp), ent.transpose(0, 1).reshape(-1)
+
+
+class TwinMPNN(object):
+    """Both teams' policies evaluated in ONE batched pass (no-grad rollouts only).
+
+    With equal team sizes the guard and the attacker MPNN have identical shapes, so every
+    GEMM becomes a 2-batch ``baddbmm`` over stacked weights and every elementwise op carries a
+    leading team dimension: half the kernel launches of two separate forwards, which is what a
+    small-network rollout on a big GPU is bound by.  The stacked weights live in persistent
+    buffers that ``refresh()`` rewrites IN PLACE (hipGraph-safe); the learner calls it whenever
+    the policies' parameters may have moved.  Numerically this is the same network (same
+    weights, same operation order per team); results equal the separate forwards to float32
+    rounding of the batched GEMM.
+    """
+
+    def __init__(self, guard, attacker):
+        if guard.num_agents != attacker.num_agents or guard.num_opp_agents != attacker.num_opp_agents \
+                or guard.h_dim != attacker.h_dim:
+            raise ValueError("TwinMPNN needs equal team sizes and hidden sizes")
+        self.pols = (guard, attacker)
+        self.n = guard.num_agents
+        self.K = guard.K
+        self._w = None
+        self.refresh()
+
+    @torch.no_grad()
+    def refresh(self):
+        g, a = self.pols
+        lin = lambda f: (torch.stack([f(g).weight.t(), f(a).weight.t()]), torch.stack([f(g).bias, f(a).bias])[:, None, :])
+        w = {}
+        w["enc"] = lin(lambda p: p.encoder[0])
+        w["oenc"] = lin(lambda p: p.oppEncoder[0])
+        w["upd"] = lin(lambda p: p.update[0])
+        w["v0"] = lin(lambda p: p.value_head[0])
+        w["v2"] = lin(lambda p: p.value_head[2])
+        w["p0"] = lin(lambda p: p.policy_head[0])
+        w["dist"] = lin(lambda p: p.dist.linear)
+        st = lambda f: torch.stack([f(g), f(a)])
+        w["o_qv"] = (st(lambda p: torch.cat((p.oppAttn.W_query[0], p.oppAttn.W_val[0]), 1)),)
+        w["o_k"] = (st(lambda p: p.oppAttn.W_key[0]),)
+        w["o_out"] = (st(lambda p: p.oppAttn.W_out[0]),)
+        w["m_qkv"] = (st(lambda p: torch.cat((p.messages.W_query[0], p.messages.W_key[0], p.messages.W_val[0]), 1)),)
+        w["m_out"] = (st(lambda p: p.messages.W_out[0]),)
+        if self._w is None:
+            self._w = {k: tuple(t.contiguous().clone() for t in v) for k, v in w.items()}
+        else:
+            for k, v in w.items():
+                for dst, src in zip(self._w[k], v):
+                    dst.copy_(src)
+
+    @staticmethod
+    def _lin(x, wb):                      # x (2, R, in) -> (2, R, out)
+        return torch.baddbmm(wb[1], x, wb[0])
+
+    @torch.no_grad()
+    def logits_value(self, obs):
+        """obs (E, 2n, 6), guards first -> logits (2, E, n, A), value (2, E, n, 1)."""
+        E, n, w = obs.shape[0], self.n, self._w
+        own = torch.stack((obs[:, :n], obs[:, n:]))                 # (2, E, n, 6)
+        opp = torch.stack((obs[:, n:], obs[:, :n]))
+        flat = lambda t: t.reshape(2, E * n, t.shape[-1])
+        unflat = lambda t: t.view(2, E, n, t.shape[-1])
+        h = torch.relu_(self._lin(flat(own), w["enc"]))
+        ho = torch.relu_(self._lin(flat(opp), w["oenc"]))
+        a = self.pols[0].oppAttn
+        qv = unflat(torch.bmm(ho, w["o_qv"][0]))
+        q, v = qv[..., :a.key_dim], qv[..., a.key_dim:]
+        k = unflat(torch.bmm(h, w["o_k"][0]))
+        att = torch.softmax(a.norm_factor * (k.unsqueeze(3) * q.unsqueeze(2)).sum(-1), dim=-1)   # (2,E,n,m)
+        e_opp = torch.bmm(flat((att.unsqueeze(-1) * v.unsqueeze(2)).sum(3)), w["o_out"][0])
+        h = torch.cat((h, e_opp), dim=2)                           # (2, E*n, h_dim)
+        m = self.pols[0].messages
+        diag = self.pols[0]._diag
+        for _ in range(self.K):
+            if n == 1:
+                msg = torch.zeros(2, E, m.embed_dim, device=h.device, dtype=h.dtype)
+            else:
+                qkv = unflat(torch.bmm(h, w["m_qkv"][0]))
+                qq, kk, vv = qkv[..., :m.key_dim], qkv[..., m.key_dim:2 * m.key_dim], qkv[..., 2 * m.key_dim:]
+                comp = m.norm_factor * (qq.unsqueeze(3) * kk.unsqueeze(2)).sum(-1) + diag
+                att = torch.softmax(comp, dim=-1)
+                msg = torch.bmm(flat((att.unsqueeze(-1) * vv.unsqueeze(2)).sum(3)), w["m_out"][0])
+            h = torch.relu_(self._lin(torch.cat((h, msg), dim=2), w["upd"]))
+        value = self._lin(torch.relu_(self._lin(h, w["v0"])), w["v2"])
+        logits = self._lin(torch.relu_(self._lin(h, w["p0"])), w["dist"])
+        return unflat(logits), unflat(value)
+
+    @torch.no_grad()
+    def act(self, obs, deterministic=False, generator=None):
+        """-> value (E, 2n, 1), action (E, 2n, 1) int64, log-prob (E, 2n, 1), guards first."""
+        logits, value = self.logits_value(obs)
+        logp_all = F.log_softmax(logits, dim=-1)
+        if deterministic:
+            action = logits.argmax(dim=-1, keepdim=True)
+        else:
+            u = torch.rand(logits.shape, device=logits.device, dtype=logits.dtype, generator=generator)
+            action = (logits - torch.log(-torch.log(u.clamp_(min=1e-20, max=1.0 - 1e-7)))).argmax(dim=-1, keepdim=True)
+        logp = logp_all.gather(-1, action)
+        team_major = lambda t: t.permute(1, 0, 2, 3).reshape(obs.shape[0], 2 * self.n, t.shape[-1])
+        return team_major(value), team_major(action), team_major(logp)
+
+    @torch.no_grad()
+    def get_value(self, obs):
+        _, value = self.logits_value(obs)
+        return value.permute(1, 0, 2, 3).reshape(obs.shape[0], 2 * self.n, 1)
