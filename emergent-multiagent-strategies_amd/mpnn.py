@@ -21,6 +21,52 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 
+class _SplitKMatmul(torch.autograd.Function):
+    """y = x @ w for a tall-skinny x (tens of thousands of rows, <= 384 columns).
+
+    Forward and dX are ordinary GEMMs.  dW = x^T @ dy reduces over the rows into a tiny
+    (K x M) output: hipBLASLt runs that as a handful of workgroups (one per output tile, no
+    split-K: ~6 TFLOP/s measured on MI355X), so the reduction is split here into S independent
+    batched GEMMs over row blocks plus one sum -- S workgroup-sets instead of one.
+    """
+
+    @staticmethod
+    def forward(ctx, x, w):
+        ctx.save_for_backward(x, w)
+        return x @ w
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            gx = gy @ w.t()
+        if ctx.needs_input_grad[1]:
+            R = x.shape[0]
+            S = 1
+            while S < 256 and R % (2 * S) == 0 and R // (2 * S) >= 256:
+                S *= 2
+            if S == 1:
+                gw = x.t() @ gy
+            else:
+                gw = torch.bmm(x.view(S, R // S, x.shape[1]).transpose(1, 2), gy.reshape(S, R // S, gy.shape[1])).sum(0)
+        return gx, gw
+
+
+def _mm(x, w):
+    """x (..., K) @ w (K, M); routes the weight gradient through the split-K path when training
+    on a large batch."""
+    if torch.is_grad_enabled() and w.requires_grad and x.numel() // x.shape[-1] >= 4096:
+        lead = x.shape[:-1]
+        return _SplitKMatmul.apply(x.reshape(-1, x.shape[-1]), w).view(*lead, w.shape[1])
+    return x @ w
+
+
+def _linear(x, lin):
+    """nn.Linear forward through _mm (same math: x @ W^T + b)."""
+    return _mm(x, lin.weight.t()) + lin.bias
+
+
 def _weights_init(m):  # mpnn.py:9-14
     name = m.__class__.__name__
     if name.find("Conv") != -1 or name.find("Linear") != -1:
@@ -126,8 +172,8 @@ class MPNN(nn.Module):
     # ---- trunk (mpnn.py:117-172 _fwd) ---------------------------------------------------
     def trunk(self, own, opp, return_attn=False):
         """own (B, n, 6), opp (B, m, 6) -> h (B, n, h_dim)."""
-        h = self.encoder(own)
-        h_opp = self.oppEncoder(opp)
+        h = torch.relu(_linear(own, self.encoder[0]))
+        h_opp = torch.relu(_linear(opp, self.oppEncoder[0]))
         # Projections that share an input are one GEMM (weights concatenated on the fly: the
         # parameters stay separate so reference state_dicts load), and the n x m attention is a
         # broadcast multiply-sum: per-env (3x64)@(64x3) batched GEMMs over thousands of envs are
@@ -135,12 +181,12 @@ class MPNN(nn.Module):
         a = self.oppAttn                                   # mpnn.py:372-443
         kd = a.key_dim
         w_qv, w_qkv = self._fused_weights()
-        qv = h_opp @ w_qv
+        qv = _mm(h_opp, w_qv)
         q, v = qv[..., :kd], qv[..., kd:]
-        k = h @ a.W_key[0]
+        k = _mm(h, a.W_key[0])
         scores = (k.unsqueeze(2) * q.unsqueeze(1)).sum(-1)             # (B, n, m)
         opp_attn = F.softmax(a.norm_factor * scores, dim=-1)
-        e_opp = (opp_attn.unsqueeze(-1) * v.unsqueeze(1)).sum(2) @ a.W_out[0]
+        e_opp = _mm((opp_attn.unsqueeze(-1) * v.unsqueeze(1)).sum(2), a.W_out[0])
         h = torch.cat((h, e_opp), dim=2)
         m = self.messages                                  # mpnn.py:250-332
         attn = None
@@ -149,19 +195,22 @@ class MPNN(nn.Module):
                 msg = torch.zeros(h.shape[0], 1, m.embed_dim, device=h.device, dtype=h.dtype)
                 attn = torch.zeros(h.shape[0], 1, 1, device=h.device, dtype=h.dtype)
             else:
-                qkv = h @ w_qkv
+                qkv = _mm(h, w_qkv)
                 qq, kk, vv = qkv[..., :m.key_dim], qkv[..., m.key_dim:2 * m.key_dim], qkv[..., 2 * m.key_dim:]
                 comp = m.norm_factor * (qq.unsqueeze(2) * kk.unsqueeze(1)).sum(-1) + self._diag
                 attn = F.softmax(comp, dim=-1)
-                msg = (attn.unsqueeze(-1) * vv.unsqueeze(1)).sum(2) @ m.W_out[0]
-            h = self.update(torch.cat((h, msg), 2))
+                msg = _mm((attn.unsqueeze(-1) * vv.unsqueeze(1)).sum(2), m.W_out[0])
+            h = torch.relu(_linear(torch.cat((h, msg), 2), self.update[0]))
         if return_attn:
             return h, attn, opp_attn
         return h
 
+    def _value(self, h):
+        return _linear(torch.relu(_linear(h, self.value_head[0])), self.value_head[2])
+
     def logits_value(self, own, opp):
         h = self.trunk(own, opp)
-        return self.dist(self.policy_head(h)), self.value_head(h)
+        return _linear(torch.relu(_linear(h, self.policy_head[0])), self.dist.linear), self._value(h)
 
     # ---- env-major API used by the batched rollout ---------------------------------------
     def act(self, own, opp, deterministic=False, generator=None):
@@ -181,7 +230,7 @@ class MPNN(nn.Module):
         return value, action, logp_all.gather(-1, action)
 
     def get_value(self, own, opp):                         # mpnn.py:202-205
-        return self.value_head(self.trunk(own, opp))
+        return self._value(self.trunk(own, opp))
 
     def evaluate_actions(self, own, opp, action):
         """-> value, log-prob of `action`, per-sample entropy (all (B,n,1)/(B,n))  (mpnn.py:194-200)."""
