@@ -299,3 +299,24 @@ def test_device_divide_and_sqrt_sequences_are_correctly_rounded(fa):
     print("heading sin/cos: max deviation from the device libm = %.3f ulp" % sincos_ulp)
     assert (bad_div, bad_sqrt) == (0, 0)
     assert sincos_ulp <= 2.0
+
+
+def test_large_batch_matches_oracle(fa):
+    """131 072 envs (13 108 workgroups, > 2^16 blocks' worth of lanes): every env of a big batch
+    equals the oracle -- catches index-width / grid-size mistakes that small batches cannot."""
+    from fa_oracle import OracleEnv
+    E, G, A, T = 131072, 3, 3, 6
+    N = G + A
+    rng = np.random.RandomState(11)
+    orc = OracleEnv(E, G, A, 4, base_seed=900000)          # max_time_steps 4: resets inside the run
+    eng = fa.BatchedFortAttack(E, G, A, 4, base_seed=900000)
+    o0 = torch.empty((E, N, 6), dtype=torch.float64, device="cuda")
+    eng.reset(obs_f64=o0)
+    assert np.array_equal(o0.cpu().numpy(), orc.reset())
+    for t in range(T):
+        a = rng.randint(0, 8, size=(E, N))
+        ref = orc.step(a, auto_reset=True)
+        out = eng.step(_dev(a, torch.int64), auto_reset=True, want=("obs_f64", "reward_f64", "done"))
+        assert np.array_equal(out["done"].cpu().numpy(), ref["done"]), t
+        assert np.array_equal(out["obs_f64"].cpu().numpy(), ref["obs"]), t
+        assert np.array_equal(out["reward_f64"].cpu().numpy(), ref["reward"]), t
