@@ -198,12 +198,23 @@ __device__ __forceinline__ bool laser_hit(double x1, double y1, double x2, doubl
 // COLLECT: the four trainer rows (obs32, rew32, mask32, done) are all present and nothing
 // else is: their stores are then unconditional, which lets the compiler wait for the
 // prefetched action with vmcnt(#stores) instead of draining the store queue every step.
-template <int TG, int TA, bool RESET_ONLY, bool COLLECT>
-__global__ __launch_bounds__(FA_WAVE) void fa_step_kernel(FaStepArgs a) {
+// TWO: two cooperating waves per workgroup (compile-time team sizes only).  Wave 0 is the step
+// as described above minus the contact/wall forces; wave 1 (the "force wave", stateless) computes
+// them for the same lanes from the positions wave 0 stages in LDS, concurrently with wave 0's
+// sin/cos + laser tests, and hands back F through LDS.  At E = 4096 there are fewer waves than
+// SIMDs and the step is a latency chain, so running its two longest independent pieces
+// (laser ~30 %, forces ~45 % of the chain) side by side on two SIMDs shortens it; the arithmetic
+// and its order are unchanged.  (A two-barrier variant in which wave 0 sums the candidates itself
+// measured 4 % slower: wave 0 is the critical path, the force wave has slack.)  Three workgroup barriers per step (raw s_barrier behind an LDS
+// wait -- __syncthreads() would also drain the global stores).
+#define FA_WG_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+template <int TG, int TA, bool RESET_ONLY, bool COLLECT, bool TWO>
+__global__ __launch_bounds__(TWO ? 2 * FA_WAVE : FA_WAVE) void fa_step_kernel(FaStepArgs a) {
     const int G = TG ? TG : a.G, A = TA ? TA : a.A;
     const int N = G + A;
     const int EPW = FA_WAVE / N;          // envs per wave
-    const int lane = threadIdx.x;         // one wave per workgroup
+    const int lane = threadIdx.x & (FA_WAVE - 1);
+    const bool force_wave = TWO && threadIdx.x >= FA_WAVE;
     const int slot = lane / N;            // env slot inside the wave
     const int i = lane - slot * N;        // agent index
     const int gbase = slot * N;           // first lane of this env's group
@@ -217,6 +228,79 @@ __global__ __launch_bounds__(FA_WAVE) void fa_step_kernel(FaStepArgs a) {
 
     __shared__ double s_px[FA_WAVE], s_py[FA_WAVE], s_tri[6][FA_WAVE];
     __shared__ int s_act[FA_ACT_BATCH][FA_WAVE];
+    __shared__ double s_F[2][TWO ? FA_WAVE : 1];  // TWO: total force per lane, from the force wave
+    __shared__ unsigned long long s_mask[2];        // TWO: ballots of alive-before / alive-after-laser
+
+    if constexpr (TWO) {
+        if (force_wave) {
+            // ---- the force wave: core.py:221-252 for its lane's agent, every step ----------------
+            constexpr int NT = TG + TA;
+            const int ns = a.nsteps;
+            for (int s = 0; s < ns; ++s) {
+                FA_WG_BARRIER(); // (1) actions, positions and the alive-before ballot are staged
+                const int act = s_act[s & (FA_ACT_BATCH - 1)][lane];
+                double u0 = 0.0, u1 = 0.0;
+                if (act == 1) u0 = +1.0;
+                if (act == 2) u0 = -1.0;
+                if (act == 3) u1 = +1.0;
+                if (act == 4) u1 = -1.0;
+                u0 *= c.accel;
+                u1 *= c.accel;
+                const unsigned long long grp_alive0 = (s_mask[0] >> gbase) & grp_mask;
+                const bool alive0 = (grp_alive0 >> i) & 1ull;
+                const double px = s_px[lane], py = s_py[lane];
+                // candidate pair force against every partner alive BEFORE the laser (a partner the
+                // laser kills this step is masked out below); exactly +0.0 when out of range, so
+                // that adding it is a no-op (F is never -0.0)
+                double fxj[NT], fyj[NT];
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const double dx = px - s_px[gbase + j], dy = py - s_py[gbase + j];
+                    const double d2 = dx * dx + dy * dy;
+                    fxj[j] = 0.0;
+                    fyj[j] = 0.0;
+                    if (alive0 && j != i && ((grp_alive0 >> j) & 1ull) && !(d2 > c.contact_skip_d2)) {
+                        const double dist = sqrt_rn(d2);
+                        const double pen = softplus_pen(div_rn(-(dist - c.dist_min), c.contact_margin), c.contact_margin);
+                        fxj[j] = div_rn(c.contact_force * dx, dist) * pen;
+                        fyj[j] = div_rn(c.contact_force * dy, dist) * pen;
+                    }
+                }
+                double wx = 0.0, wy = 0.0;   // (fx1 - fx2), (fy1 - fy2) of core.py:469-471; +0.0 off the walls
+                if (alive0) {
+                    const double k = c.contact_margin, size = c.agent_size;
+                    const double d0 = px - size - c.wall_xmin, d1 = c.wall_xmax - px - size;
+                    const double d2 = py - size - c.wall_ymin, d3 = c.wall_ymax - py - size;
+                    const bool w0 = !(d0 > c.wall_skip), w1 = !(d1 > c.wall_skip);
+                    const bool w2 = !(d2 > c.wall_skip), w3 = !(d3 > c.wall_skip);
+                    if (w0 || w1 || w2 || w3) {
+                        double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0;
+                        if (w0) p0 = softplus_pen(div_rn(-d0, k), k);
+                        if (w1) p1 = softplus_pen(div_rn(-d1, k), k);
+                        if (w2) p2 = softplus_pen(div_rn(-d2, k), k);
+                        if (w3) p3 = softplus_pen(div_rn(-d3, k), k);
+                        wx = c.contact_force * p0 - c.contact_force * p1;
+                        wy = c.contact_force * p2 - c.contact_force * p3;
+                    }
+                }
+                FA_WG_BARRIER(); // (2) the alive-after-laser ballot is published
+                const unsigned long long grp_alive1 = (s_mask[1] >> gbase) & grp_mask;
+                double Fx = u0 + 0.0, Fy = u1 + 0.0;   // core.py:221-228
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    if ((grp_alive1 >> j) & 1ull) { // ascending partner order == the reference's pair order
+                        Fx = fxj[j] + Fx;
+                        Fy = fyj[j] + Fy;
+                    }
+                Fx = wx + Fx;
+                Fy = wy + Fy;
+                s_F[0][lane] = Fx;
+                s_F[1][lane] = Fy;
+                FA_WG_BARRIER(); // (3) forces are published
+            }
+            return;
+        }
+    }
 
     // ---- load state once per launch (coalesced: lane-contiguous) --------------------
     double px = 0, py = 0, vx = 0, vy = 0, ang = 0, prev = 0;
@@ -276,6 +360,11 @@ __global__ __launch_bounds__(FA_WAVE) void fa_step_kernel(FaStepArgs a) {
             // ---- stage positions + laser triangles in LDS (core.py:373-382) ------------
             s_px[lane] = px;
             s_py[lane] = py;
+            if constexpr (TWO) {
+                const unsigned long long alive0_b = __ballot(alive0);
+                if (lane == 0) s_mask[0] = alive0_b;
+                FA_WG_BARRIER(); // (1) the force wave starts on this step's contacts and walls
+            }
             const bool shooter = alive0 && shoot;
             if (shooter) {
                 // one sincos; cos/sin(ang +- shootWin/2) by the angle-addition identities with
@@ -302,7 +391,7 @@ __global__ __launch_bounds__(FA_WAVE) void fa_step_kernel(FaStepArgs a) {
             // (only for small teams: at N = 10 the 30 extra live doubles push the kernel past
             // 256 VGPRs and into scratch)
             constexpr int NT = (TG != 0) ? TG + TA : 0;
-            constexpr bool HOIST = NT != 0 && NT <= 8;
+            constexpr bool HOIST = !TWO && NT != 0 && NT <= 8;
             double dxs[NT ? NT : 1], dys[NT ? NT : 1], d2s[NT ? NT : 1];
             if constexpr (HOIST) {
 #pragma unroll
@@ -367,12 +456,22 @@ __global__ __launch_bounds__(FA_WAVE) void fa_step_kernel(FaStepArgs a) {
             const bool hit = shooter && hit_cnt > 0;
             const bool alive1 = alive0 && !was_hit;       // :293-302 one shot kills
             const bool just_died = alive0 && was_hit;
-            const unsigned long long grp_alive1 = (__ballot(alive1) >> gbase) & grp_mask;
+            const unsigned long long alive1_b = __ballot(alive1);
+            const unsigned long long grp_alive1 = (alive1_b >> gbase) & grp_mask;
             const int n_alive_att = __popcll(grp_alive1 >> G);
+            if constexpr (TWO) {
+                if (lane == 0) s_mask[1] = alive1_b;
+                FA_WG_BARRIER(); // (2) the force wave masks its candidates with the survivors
+                FA_WG_BARRIER(); // (3) and has published the total force of every lane
+            }
 
             // ---- forces + integration for agents alive after the laser ----------------
             if (alive1) {
                 double Fx = u0 + 0.0, Fy = u1 + 0.0;      // core.py:221-228
+                if constexpr (TWO) {
+                    Fx = s_F[0][lane];
+                    Fy = s_F[1][lane];
+                } else {
                 // core.py:231-243 + :440-456.  Reference order: pairs (a,b), a<b, lexicographic;
                 // for agent i that is partner j ascending, with f_i = +f for j>i and
                 // -(f(j,i)) for j<i, which is bitwise the same number as f computed from
@@ -432,6 +531,7 @@ __global__ __launch_bounds__(FA_WAVE) void fa_step_kernel(FaStepArgs a) {
                         Fy = (fy1 - fy2) + Fy;
                     }
                 }
+                } // !TWO
                 // core.py:324-338 integrate_state (mass == 1.0: F/1.0 is exact)
                 vx = vx * c.one_minus_damping;
                 vy = vy * c.one_minus_damping;
@@ -600,12 +700,18 @@ static hipError_t launch_step_t(const FaStepArgs &a, hipStream_t st) {
     const int N = a.G + a.A;
     const int epw = FA_WAVE / N;
     const int grid = (a.E + epw - 1) / epw;
-    if (a.G == 3 && a.A == 3)
-        hipLaunchKernelGGL((fa_step_kernel<3, 3, RESET_ONLY, COLLECT>), dim3(grid), dim3(FA_WAVE), 0, st, a);
-    else if (a.G == 5 && a.A == 5)
-        hipLaunchKernelGGL((fa_step_kernel<5, 5, RESET_ONLY, COLLECT>), dim3(grid), dim3(FA_WAVE), 0, st, a);
-    else
-        hipLaunchKernelGGL((fa_step_kernel<0, 0, RESET_ONLY, COLLECT>), dim3(grid), dim3(FA_WAVE), 0, st, a);
+    // two cooperating waves per workgroup while that still leaves at most ~2 waves per SIMD
+    // (latency regime); beyond, one wave per workgroup uses the SIMDs better
+    const bool two = !RESET_ONLY && grid <= FA_TWO_WAVE_MAX_GRID;
+    if (a.G == 3 && a.A == 3) {
+        if (two) hipLaunchKernelGGL((fa_step_kernel<3, 3, RESET_ONLY, COLLECT, !RESET_ONLY>), dim3(grid), dim3(2 * FA_WAVE), 0, st, a);
+        else hipLaunchKernelGGL((fa_step_kernel<3, 3, RESET_ONLY, COLLECT, false>), dim3(grid), dim3(FA_WAVE), 0, st, a);
+    } else if (a.G == 5 && a.A == 5) {
+        if (two) hipLaunchKernelGGL((fa_step_kernel<5, 5, RESET_ONLY, COLLECT, !RESET_ONLY>), dim3(grid), dim3(2 * FA_WAVE), 0, st, a);
+        else hipLaunchKernelGGL((fa_step_kernel<5, 5, RESET_ONLY, COLLECT, false>), dim3(grid), dim3(FA_WAVE), 0, st, a);
+    } else {
+        hipLaunchKernelGGL((fa_step_kernel<0, 0, RESET_ONLY, COLLECT, false>), dim3(grid), dim3(FA_WAVE), 0, st, a);
+    }
     return hipGetLastError();
 }
 
