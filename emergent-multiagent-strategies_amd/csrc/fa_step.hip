@@ -2,9 +2,10 @@
 //
 // One launch advances every env of the handle by `nsteps` env-steps (1 = closed loop, the policy
 // runs between launches; K = open-loop rollout with the world state held in registers).
-// Mapping: lane = agent, a wave64 = EPW = 64/N whole envs, one wave per workgroup (E=4096, N=6
-// -> 410 workgroups over 256 CUs: the launch is latency bound, so the work is spread thin).
-// Cross-agent data moves two ways, both inside the wave (no workgroup barrier):
+// Mapping: lane = agent, a wave64 = EPW = 64/N whole envs, one workgroup per EPW envs (E=4096,
+// N=6 -> 410 workgroups over 256 CUs: the launch is latency bound, so the work is spread thin;
+// in that regime a second, cooperating wave per workgroup computes the contact/wall forces --
+// see TWO below).  Cross-agent data moves two ways, both inside the wave:
 //   * positions and laser triangles are staged in LDS and read back with per-lane
 //     addresses (broadcast reads inside an env); actions reach the loop through LDS too;
 //   * every flag reduction (who shoots, who is alive, who was hit by whom, attackers in
