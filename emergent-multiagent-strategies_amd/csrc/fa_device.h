@@ -15,7 +15,8 @@
 #define FA_MT_M 397
 #define FA_MAX_AGENTS_DEV 16
 #define FA_ACT_BATCH 16 // env-steps of actions staged in LDS per batch (power of two)
-#define FA_TWO_WAVE_MAX_GRID 1024 // workgroups up to which the two-wave step kernel is used
+#define FA_TWO_WAVE_MAX_GRID 1024  // workgroups up to which the two-wave step kernel is used
+#define FA_THREE_WAVE_MAX_GRID 680 // ... and the three-wave one (3 x 680 waves = 2 per SIMD)
 
 // Host-derived constants (evaluated once in double, in the reference's expression order).
 struct FaDerived {

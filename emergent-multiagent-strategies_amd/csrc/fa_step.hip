@@ -191,9 +191,12 @@ __device__ __forceinline__ bool laser_hit(double x1, double y1, double x2, doubl
     const double w2 = (x3 - px) * (y1 - py) - (x1 - px) * (y3 - py);
     const double w3 = (x1 - px) * (y2 - py) - (x2 - px) * (y1 - py);
     const double det = (w1 + w2) + w3;
-    // bitwise, not short-circuit: no divergent branches (each costs a VALU->SALU round trip)
-    const bool pos = (w1 >= 0) & (w2 >= 0) & (w3 >= 0), neg = (w1 <= 0) & (w2 <= 0) & (w3 <= 0);
-    return ((det > 0) & pos) | ((det < 0) & neg);
+    // all lam >= 0  <=>  the w_i share the sign of det (their sum): decided from min / max of the
+    // three instead of six compares -- every fp64 compare lands in an SGPR mask and each mask
+    // AND is a VALU->SALU round trip for a wave that is alone on its SIMD.  (min >= 0 forces
+    // det >= 0 and max <= 0 forces det <= 0, so `det != 0` is all that is left to check.)
+    const double mn = fmin(fmin(w1, w2), w3), mx = fmax(fmax(w1, w2), w3);
+    return ((mn >= 0) | (mx <= 0)) & (det != 0);
 }
 
 // COLLECT: the four trainer rows (obs32, rew32, mask32, done) are all present and nothing
@@ -209,13 +212,16 @@ __device__ __forceinline__ bool laser_hit(double x1, double y1, double x2, doubl
 // measured 4 % slower: wave 0 is the critical path, the force wave has slack.)  Three workgroup barriers per step (raw s_barrier behind an LDS
 // wait -- __syncthreads() would also drain the global stores).
 #define FA_WG_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
-template <int TG, int TA, bool RESET_ONLY, bool COLLECT, bool TWO>
-__global__ __launch_bounds__(TWO ? 2 * FA_WAVE : FA_WAVE) void fa_step_kernel(FaStepArgs a) {
+template <int TG, int TA, bool RESET_ONLY, bool COLLECT, int NW>
+__global__ __launch_bounds__(NW * FA_WAVE) void fa_step_kernel(FaStepArgs a) {
+    constexpr bool TWO = NW >= 2;    // wave 1: contact forces (+ walls when NW == 2)
+    constexpr bool THREE = NW >= 3;  // wave 2: wall forces
     const int G = TG ? TG : a.G, A = TA ? TA : a.A;
     const int N = G + A;
     const int EPW = FA_WAVE / N;          // envs per wave
     const int lane = threadIdx.x & (FA_WAVE - 1);
-    const bool force_wave = TWO && threadIdx.x >= FA_WAVE;
+    const int wave_id = threadIdx.x / FA_WAVE;
+    const bool force_wave = TWO && wave_id >= 1;
     const int slot = lane / N;            // env slot inside the wave
     const int i = lane - slot * N;        // agent index
     const int gbase = slot * N;           // first lane of this env's group
@@ -230,13 +236,50 @@ __global__ __launch_bounds__(TWO ? 2 * FA_WAVE : FA_WAVE) void fa_step_kernel(Fa
     __shared__ double s_px[FA_WAVE], s_py[FA_WAVE], s_tri[6][FA_WAVE];
     __shared__ int s_act[FA_ACT_BATCH][FA_WAVE];
     __shared__ double s_F[2][TWO ? FA_WAVE : 1];  // TWO: total force per lane, from the force wave
+    __shared__ double s_W[2][THREE ? FA_WAVE : 1]; // THREE: wall force per lane, from the wall wave
     __shared__ unsigned long long s_mask[2];        // TWO: ballots of alive-before / alive-after-laser
 
     if constexpr (TWO) {
         if (force_wave) {
-            // ---- the force wave: core.py:221-252 for its lane's agent, every step ----------------
             constexpr int NT = TG + TA;
             const int ns = a.nsteps;
+            // wall force of the lane's agent (core.py:246-252 + :459-472): (fx1 - fx2, fy1 - fy2),
+            // exactly +0.0 off the walls
+            auto wall_force = [&](bool alive0, double px, double py, double &wx, double &wy) {
+                wx = 0.0;
+                wy = 0.0;
+                if (alive0) {
+                    const double k = c.contact_margin, size = c.agent_size;
+                    const double d0 = px - size - c.wall_xmin, d1 = c.wall_xmax - px - size;
+                    const double d2 = py - size - c.wall_ymin, d3 = c.wall_ymax - py - size;
+                    const bool w0 = !(d0 > c.wall_skip), w1 = !(d1 > c.wall_skip);
+                    const bool w2 = !(d2 > c.wall_skip), w3 = !(d3 > c.wall_skip);
+                    if (w0 || w1 || w2 || w3) {
+                        double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0;
+                        if (w0) p0 = softplus_pen(div_rn(-d0, k), k);
+                        if (w1) p1 = softplus_pen(div_rn(-d1, k), k);
+                        if (w2) p2 = softplus_pen(div_rn(-d2, k), k);
+                        if (w3) p3 = softplus_pen(div_rn(-d3, k), k);
+                        wx = c.contact_force * p0 - c.contact_force * p1;
+                        wy = c.contact_force * p2 - c.contact_force * p3;
+                    }
+                }
+            };
+            if (THREE && wave_id == 2) {
+                // ---- the wall wave ---------------------------------------------------------------
+                for (int s = 0; s < ns; ++s) {
+                    FA_WG_BARRIER(); // (1)
+                    const bool alive0 = (s_mask[0] >> lane) & 1ull;
+                    double wx, wy;
+                    wall_force(alive0, s_px[lane], s_py[lane], wx, wy);
+                    s_W[0][lane] = wx;
+                    s_W[1][lane] = wy;
+                    FA_WG_BARRIER(); // (2)
+                    FA_WG_BARRIER(); // (3)
+                }
+                return;
+            }
+            // ---- the force wave: core.py:221-252 for its lane's agent, every step ----------------
             for (int s = 0; s < ns; ++s) {
                 FA_WG_BARRIER(); // (1) actions, positions and the alive-before ballot are staged
                 const int act = s_act[s & (FA_ACT_BATCH - 1)][lane];
@@ -267,25 +310,11 @@ __global__ __launch_bounds__(TWO ? 2 * FA_WAVE : FA_WAVE) void fa_step_kernel(Fa
                         fyj[j] = div_rn(c.contact_force * dy, dist) * pen;
                     }
                 }
-                double wx = 0.0, wy = 0.0;   // (fx1 - fx2), (fy1 - fy2) of core.py:469-471; +0.0 off the walls
-                if (alive0) {
-                    const double k = c.contact_margin, size = c.agent_size;
-                    const double d0 = px - size - c.wall_xmin, d1 = c.wall_xmax - px - size;
-                    const double d2 = py - size - c.wall_ymin, d3 = c.wall_ymax - py - size;
-                    const bool w0 = !(d0 > c.wall_skip), w1 = !(d1 > c.wall_skip);
-                    const bool w2 = !(d2 > c.wall_skip), w3 = !(d3 > c.wall_skip);
-                    if (w0 || w1 || w2 || w3) {
-                        double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0;
-                        if (w0) p0 = softplus_pen(div_rn(-d0, k), k);
-                        if (w1) p1 = softplus_pen(div_rn(-d1, k), k);
-                        if (w2) p2 = softplus_pen(div_rn(-d2, k), k);
-                        if (w3) p3 = softplus_pen(div_rn(-d3, k), k);
-                        wx = c.contact_force * p0 - c.contact_force * p1;
-                        wy = c.contact_force * p2 - c.contact_force * p3;
-                    }
-                }
+                double wx = 0.0, wy = 0.0;
+                if (!THREE) wall_force(alive0, px, py, wx, wy);
                 FA_WG_BARRIER(); // (2) the alive-after-laser ballot is published
                 const unsigned long long grp_alive1 = (s_mask[1] >> gbase) & grp_mask;
+                if (THREE) { wx = s_W[0][lane]; wy = s_W[1][lane]; }
                 double Fx = u0 + 0.0, Fy = u1 + 0.0;   // core.py:221-228
 #pragma unroll
                 for (int j = 0; j < NT; ++j)
@@ -432,13 +461,17 @@ __global__ __launch_bounds__(TWO ? 2 * FA_WAVE : FA_WAVE) void fa_step_kernel(Fa
                         const bool cand = alive0 && k < n_opp && ((shooters_b >> j) & 1ull);
                         hk[k] = cand & laser_hit(tr[k][0], tr[k][1], tr[k][2], tr[k][3], tr[k][4], tr[k][5], px, py);
                     }
+                    // the hit list of shooter k of either team is ballot k: pick the lane's own
+                    // (uniform values, per-lane select), then one shift / mask / popcount
+                    unsigned long long my_hb = 0ull;
 #pragma unroll
                     for (int k = 0; k < KT; ++k) {
                         const unsigned long long hb = __ballot(hk[k]);
-                        if (k == team_idx) hit_cnt = __popcll((hb >> gbase) & opp_mask);
-                        was_hit = was_hit || hk[k];
+                        my_hb = (k == team_idx) ? hb : my_hb;
+                        was_hit = was_hit | hk[k];
                         was_hit_cnt += hk[k] ? 1 : 0;
                     }
+                    hit_cnt = __popcll((my_hb >> gbase) & opp_mask);
                 } else {
                     const int KMAX = G > A ? G : A;
                     for (int k = 0; k < KMAX; ++k) {
@@ -703,16 +736,19 @@ static hipError_t launch_step_t(const FaStepArgs &a, hipStream_t st) {
     const int grid = (a.E + epw - 1) / epw;
     // two cooperating waves per workgroup while that still leaves at most ~2 waves per SIMD
     // (latency regime); beyond, one wave per workgroup uses the SIMDs better
-    const bool two = !RESET_ONLY && grid <= FA_TWO_WAVE_MAX_GRID;
+    // cooperating waves per workgroup while the launch is in the latency regime
+    const int nw = RESET_ONLY ? 1 : (grid <= FA_THREE_WAVE_MAX_GRID ? 3 : (grid <= FA_TWO_WAVE_MAX_GRID ? 2 : 1));
+#define FA_LAUNCH(TG_, TA_, NW_) \
+    hipLaunchKernelGGL((fa_step_kernel<TG_, TA_, RESET_ONLY, COLLECT, RESET_ONLY ? 1 : NW_>), dim3(grid), \
+                       dim3((RESET_ONLY ? 1 : NW_) * FA_WAVE), 0, st, a)
     if (a.G == 3 && a.A == 3) {
-        if (two) hipLaunchKernelGGL((fa_step_kernel<3, 3, RESET_ONLY, COLLECT, !RESET_ONLY>), dim3(grid), dim3(2 * FA_WAVE), 0, st, a);
-        else hipLaunchKernelGGL((fa_step_kernel<3, 3, RESET_ONLY, COLLECT, false>), dim3(grid), dim3(FA_WAVE), 0, st, a);
+        if (nw == 3) FA_LAUNCH(3, 3, 3); else if (nw == 2) FA_LAUNCH(3, 3, 2); else FA_LAUNCH(3, 3, 1);
     } else if (a.G == 5 && a.A == 5) {
-        if (two) hipLaunchKernelGGL((fa_step_kernel<5, 5, RESET_ONLY, COLLECT, !RESET_ONLY>), dim3(grid), dim3(2 * FA_WAVE), 0, st, a);
-        else hipLaunchKernelGGL((fa_step_kernel<5, 5, RESET_ONLY, COLLECT, false>), dim3(grid), dim3(FA_WAVE), 0, st, a);
+        if (nw == 3) FA_LAUNCH(5, 5, 3); else if (nw == 2) FA_LAUNCH(5, 5, 2); else FA_LAUNCH(5, 5, 1);
     } else {
-        hipLaunchKernelGGL((fa_step_kernel<0, 0, RESET_ONLY, COLLECT, false>), dim3(grid), dim3(FA_WAVE), 0, st, a);
+        FA_LAUNCH(0, 0, 1);
     }
+#undef FA_LAUNCH
     return hipGetLastError();
 }
 

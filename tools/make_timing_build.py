@@ -26,14 +26,13 @@ __device__ unsigned long long g_dbg[16];
 rep("    bool dirty = false; // state changed => write it back\n",
     "    bool dirty = false;\n    unsigned long long tacc[10] = {0,0,0,0,0,0,0,0,0,0}; unsigned long long tlast = clock64();\n")
 rep("            const bool alive0 = alive;\n", "            TICK(0)\n            const bool alive0 = alive;\n")
-rep("            // ---- stage positions + laser triangles in LDS (core.py:373-382) ------------\n",
-    "            TICK(1)\n            // ---- stage positions\n")
-rep("            // partner deltas for the contact test, fetched now", "            TICK(2)\n            // partner deltas")
-rep("            const bool hit = shooter && hit_cnt > 0;\n", "            TICK(3)\n            const bool hit = shooter && hit_cnt > 0;\n")
-rep("                // core.py:246-252 + :459-472 walls\n", "                TICK(4)\n                // walls\n")
-rep("                // core.py:324-338 integrate_state (mass == 1.0: F/1.0 is exact)\n", "                TICK(5)\n")
-rep("            // ---- rewards (fortattack_env_v1.py:87-188), after World.step ---------------\n", "            TICK(6)\n")
-rep("            // ---- fortattack.py:202-225 _get_done, :171 time_step += 1 ------------------\n", "            TICK(7)\n")
+rep("                FA_WG_BARRIER(); // (1) the force wave starts on this step's contacts and walls\n",
+    "                TICK(1)\n                FA_WG_BARRIER(); // (1)\n                TICK(2)\n")
+rep("            // partner deltas for the contact test, fetched now", "            TICK(3)\n            // partner deltas")
+rep("            const bool hit = shooter && hit_cnt > 0;\n", "            TICK(4)\n            const bool hit = shooter && hit_cnt > 0;\n")
+rep("                FA_WG_BARRIER(); // (2) the force wave masks its candidates with the survivors\n                FA_WG_BARRIER(); // (3) and has published the total force of every lane\n",
+    "                TICK(5)\n                FA_WG_BARRIER();\n                FA_WG_BARRIER();\n                TICK(6)\n")
+rep("            // ---- rewards (fortattack_env_v1.py:87-188), after World.step ---------------\n", "            TICK(7)\n")
 rep("        // ---- fortattack_env_v1.py:47-75 reset_world --------------------------------------\n", "        TICK(8)\n")
 rep("        // next iteration restages LDS: keep its writes behind this iteration's reads\n", "        TICK(9)\n")
 rep("    // ---- write back state once per launch ----------------------------------------------------\n",

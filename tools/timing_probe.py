@@ -21,8 +21,9 @@ for _ in range(5):
 torch.cuda.synchronize()
 lib.fa_dbg_read(buf, 0)
 waves = buf[10]
-names = ["loop+act batch", "decode", "trig+stage+barrier", "deltas+laser", "ballots+contact", "walls", "integrate",
-         "reward", "done+step outputs", "reset+obs store"]
+names = ["loop + action read", "decode + stage pos (to barrier 1)", "barrier 1", "sin/cos + triangle stage",
+         "laser tests", "ballots (to barrier 2)", "barriers 2+3 (force wave)", "F read + integrate", "reward + done + outputs",
+         "reset + obs store"]
 tot = sum(buf[k] for k in range(10))
 for k, n in enumerate(names):
     print("%-22s %8.1f cycles/step  %5.1f%%" % (n, buf[k] / waves / T, 100.0 * buf[k] / tot))
