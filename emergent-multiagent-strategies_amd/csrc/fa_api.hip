@@ -100,6 +100,12 @@ FaDerived derive(const fa_world_consts &w) {
         while (std::sqrt(std::nextafter(x, INFINITY)) <= w.max_speed) x = std::nextafter(x, INFINITY);
         d.speed2_max = x;
     }
+    {   // `sqrt(dd) < fort_dim` decided on dd: the largest double whose correctly rounded sqrt is < fort_dim
+        double x = w.fort_dim * w.fort_dim;
+        while (std::sqrt(x) >= w.fort_dim) x = std::nextafter(x, 0.0);
+        while (std::sqrt(std::nextafter(x, INFINITY)) < w.fort_dim) x = std::nextafter(x, INFINITY);
+        d.fort2_max = x;
+    }
     d.rot_pos = py_mod(+w.max_rot, 2 * pi);        // core.py:336
     d.rot_neg = py_mod(-w.max_rot, 2 * pi);
     d.ang_guard = 3 * pi / 2;                      // fortattack_env_v1.py:59

@@ -26,6 +26,7 @@ struct FaDerived {
     double shoot_rad, half_win;
     double cos_hw, sin_hw;          // cos/sin(shootWin/2), host libm
     double speed2_max;              // max{x : sqrt_rn(x) <= max_speed}
+    double fort2_max;               // max{x : sqrt_rn(x) <  fort_dim}
     double rot_pos, rot_neg;        // (+max_rot) % 2pi, (-max_rot) % 2pi  (Python modulo, core.py:336)
     double ang_guard, ang_attacker; // 3pi/2, pi/2                         (fortattack_env_v1.py:59)
     double att_x_lo, att_x_rng, att_y_lo, att_y_rng; // fortattack_env_v1.py:66

@@ -708,6 +708,498 @@ __global__ __launch_bounds__(NW * FA_WAVE) void fa_step_kernel(FaStepArgs a) {
     if (i == 0 && (!RESET_ONLY || dirty)) a.s.tstep[e] = t;
 }
 
+// ---- the pipelined multi-wave step (latency regime, compile-time team sizes) ------------------
+// Same arithmetic as fa_step_kernel, cut differently.  At E = 4096 there are fewer waves than
+// SIMDs and a rollout is one long dependent chain per wave, so the workgroup spends idle SIMDs
+// of its CU on shortening that chain.  Per step only this is left on wave 0:
+//     triangles -> laser tests -> (B2) -> ordered force sum -> integrate -> done -> reset -> publish -> (P)
+// and everything else runs beside it:
+//   * state(s+1) and the by-products of step s are published in LDS at the end of step s
+//     (double buffered by step parity; barrier P), so helpers work on step s+1 / finish step s
+//     while wave 0 is busy;
+//   * pair waves 1..NPW: the soft-contact pair forces are issue-bound fp64 (sqrt, three
+//     divisions, exp/log per pair in range).  They are computed once per UNORDERED pair --
+//     f(j,i) is bitwise -f(i,j) -- wave h taking the partner offsets d with (d-1) % NPW == h-1
+//     (lane i, offset d <-> pair (i, (i+d) mod N); d = 1..N/2, the last one only for i < N/2)
+//     and written from both sides into a per-lane partner row (s_fm[j][lane] = force on the
+//     lane's agent from partner j), which wave 0 sums in the reference's order after the laser;
+//   * the last pair wave also turns the published by-products of the PREVIOUS step into
+//     rewards and rollout rows (reward select chain, f64->f32, every global store, the episode
+//     statistics): none of that feeds the next state;
+//   * the last wave computes the wall forces and sin/cos of the NEXT step's heading: the heading
+//     only changes by the action's rotation (core.py:336) or by a reset to a constant, so it
+//     does not wait for this step's forces (a dead agent's value is never used; a reset agent
+//     takes the constant pair).
+// Two workgroup barriers per step: B2 (pair + wall forces of step s are in LDS) and P.
+#ifdef FA_TIMING
+__device__ unsigned long long g_dbg[32];
+#define FA_TICK_INIT unsigned long long tacc[24] = {0}; unsigned long long tlast = clock64();
+#define FA_TICK(k) { const unsigned long long _n = clock64(); tacc[k] += _n - tlast; tlast = _n; }
+#define FA_TICK_FLUSH(lo, hi, cnt) if (lane == 0) { for (int k = lo; k < hi; ++k) atomicAdd(&g_dbg[k], tacc[k]); atomicAdd(&g_dbg[cnt], 1ull); }
+#else
+#define FA_TICK_INIT
+#define FA_TICK(k)
+#define FA_TICK_FLUSH(lo, hi, cnt)
+#endif
+template <int TG, int TA, bool COLLECT, int NPW, int MINW>
+__global__ __launch_bounds__((NPW + 2) * FA_WAVE, MINW) void fa_step_pipe_kernel(FaStepArgs a) {
+    constexpr int G = TG, A = TA, N = TG + TA;
+    constexpr int NOFF = N / 2; // partner offsets that cover every unordered pair once
+    constexpr int EPW = FA_WAVE / N;
+    const int lane = threadIdx.x & (FA_WAVE - 1);
+    const int wave_id = threadIdx.x / FA_WAVE;
+    const int slot = lane / N;
+    const int i = lane - slot * N;
+    const int gbase = slot * N;
+    const int e = blockIdx.x * EPW + slot;
+    if (!((slot < EPW) && (e < a.E))) return;
+    const bool is_att = i >= G;
+    const size_t idx = (size_t)e * N + i;
+    const size_t EN = (size_t)a.E * N;
+    constexpr unsigned long long grp_mask = (1ull << N) - 1ull;
+    const FaDerived &c = a.c;
+    const int ns = a.nsteps;
+
+    // buffer s & 1: state at the start of step s (+ by-products of step s-1)
+    __shared__ double s_px[2][FA_WAVE], s_py[2][FA_WAVE], s_ang[2][FA_WAVE];
+    __shared__ double s_vx[2][FA_WAVE], s_vy[2][FA_WAVE], s_dd[2][FA_WAVE];
+    __shared__ unsigned long long s_mask[2][8]; // ballots: 0 alive, 1 alive after laser, 2 hit, 3 was hit, 4 done
+    __shared__ double s_tri[6][FA_WAVE], s_trig[2][FA_WAVE], s_W[2][FA_WAVE];
+    __shared__ double s_fmx[N][FA_WAVE], s_fmy[N][FA_WAVE]; // [partner j][lane]: pair force on the lane's agent
+    __shared__ int s_act[FA_ACT_BATCH][FA_WAVE];
+
+    if (wave_id == NPW + 1) {
+        // ---- last wave: walls of step s, sin/cos of the heading of step s+1 ----------------------
+        FA_TICK_INIT
+        FA_WG_BARRIER(); // P(-1)
+        for (int s = 0; s < ns; ++s) {
+            const int b = s & 1;
+            FA_TICK(16)
+            const int act = s_act[s & (FA_ACT_BATCH - 1)][lane];
+            const double ang = s_ang[b][lane];
+            const bool alive0 = (s_mask[b][0] >> lane) & 1ull;
+            const double px = s_px[b][lane], py = s_py[b][lane];
+            double wx = 0.0, wy = 0.0;
+            if (alive0) { // core.py:246-252 + :459-472; exactly +0.0 off the walls
+                const double k = c.contact_margin, size = c.agent_size;
+                const double d0 = px - size - c.wall_xmin, d1 = c.wall_xmax - px - size;
+                const double d2 = py - size - c.wall_ymin, d3 = c.wall_ymax - py - size;
+                const bool w0 = !(d0 > c.wall_skip), w1 = !(d1 > c.wall_skip);
+                const bool w2 = !(d2 > c.wall_skip), w3 = !(d3 > c.wall_skip);
+                if (w0 || w1 || w2 || w3) {
+                    double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0;
+                    if (w0) p0 = softplus_pen(div_rn(-d0, k), k);
+                    if (w1) p1 = softplus_pen(div_rn(-d1, k), k);
+                    if (w2) p2 = softplus_pen(div_rn(-d2, k), k);
+                    if (w3) p3 = softplus_pen(div_rn(-d3, k), k);
+                    wx = c.contact_force * p0 - c.contact_force * p1;
+                    wy = c.contact_force * p2 - c.contact_force * p3;
+                }
+            }
+            s_W[0][lane] = wx;
+            s_W[1][lane] = wy;
+            FA_TICK(17)
+            if (s + 1 < ns) {
+                double rot = 0.0;
+                if (act == 5) rot = c.rot_pos;
+                if (act == 6) rot = c.rot_neg;
+                double sn, cs;
+                sincos_heading(ang + rot, sn, cs); // == wave 0's `ang += rot` for a survivor
+                s_trig[0][lane] = cs;
+                s_trig[1][lane] = sn;
+            }
+            FA_TICK(18)
+            FA_WG_BARRIER(); // B2(s)
+            FA_TICK(19)
+            FA_WG_BARRIER(); // P(s)
+        }
+        FA_TICK_FLUSH(16, 20, 30)
+        return;
+    }
+    if (wave_id >= 1) {
+        // ---- pair waves: soft contact (core.py:231-243, :440-456), once per unordered pair; the
+        // last of them also emits the rewards and rollout rows of the previous step ---------------
+        const bool out_wave = wave_id == NPW;
+        double prev = 0.0, ep_rew = 0.0;
+        if (out_wave) {
+            prev = a.s.prev[idx];
+            if (a.track_counters) ep_rew = a.s.ep_rew[idx];
+            // complete the loads here: first used inside the loop, they would put a vmcnt(0) --
+            // which on gfx9 also drains every store in flight -- into each iteration
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(prev), "+v"(ep_rew));
+        }
+        int act_prev = 0;
+        bool alive0_prev = false;
+        // step `so` finished: buffer bo holds state(so+1) and the by-products of step so
+        auto emit = [&](int so, int bo) {
+            const unsigned long long m1 = s_mask[bo][1];
+            const bool alive_new = (s_mask[bo][0] >> lane) & 1ull;
+            const bool alive1 = (m1 >> lane) & 1ull;
+            const bool hit = (s_mask[bo][2] >> lane) & 1ull;
+            const bool was_hit = (s_mask[bo][3] >> lane) & 1ull;
+            const bool done = (s_mask[bo][4] >> lane) & 1ull;
+            const double px = s_px[bo][lane], py = s_py[bo][lane], ang = s_ang[bo][lane];
+            const double vx = s_vx[bo][lane], vy = s_vy[bo][lane];
+            const double dist_door = sqrt_rn(s_dd[bo][lane]);
+            const bool alive0 = alive0_prev;
+            const bool shoot = act_prev == 7;
+            const int n_alive_att = __popcll(((m1 >> gbase) & grp_mask) >> G);
+            const unsigned long long in_fort_b = __ballot(is_att && alive1 && dist_door < c.fort_dim);
+            const bool any_in_fort = ((in_fort_b >> gbase) & grp_mask) != 0ull;
+            const bool do_reset = done && a.auto_reset != 0;
+            // ---- rewards (fortattack_env_v1.py:87-188), after World.step ----------------------
+            // attacker_reward (:94-128) and guard_reward (:130-188) as one select chain: both are
+            // a sum of six terms added left to right -- attacker r0..r5; guard r0, r3..r7 (its r1,
+            // r2, r8 are literal zeros and x + 0.0 == x) -- so the per-team terms are selected and
+            // the additions are shared.
+            const bool just_died = alive0 && was_hit;
+            const bool rewarded = (alive1 || just_died);
+            const bool has_prev = !(prev != prev); // NaN encodes prevDist None
+            const double g0 = ((dist_door > 0.3) & (prev <= 0.3)) ? -1.0 : (((dist_door <= 0.3) & (prev > 0.3)) ? 1.0 : 0.0);
+            const double t0 = has_prev ? (is_att ? 2 * (prev - dist_door) : g0) : 0.0;
+            const bool c1 = is_att ? (dist_door < c.fort_dim) : ((n_alive_att != 0) & any_in_fort);
+            const double t1 = c1 ? (is_att ? 10.0 : -10.0) : 0.0;
+            const double t2 = shoot ? (is_att ? -1.0 : -0.1) : 0.0;
+            const double t3 = hit ? 3.0 : 0.0;
+            const double t4 = was_hit ? -3.0 : 0.0;
+            const double t5 = (n_alive_att == 0) ? (is_att ? -10.0 : 10.0) : 0.0;
+            const double rew = rewarded ? (t0 + t1 + t2 + t3 + t4 + t5) : 0.0;
+            prev = rewarded ? dist_door : prev;
+            // ---- fortattack.py:202-225 _get_done bookkeeping --------------------------------------
+            if (i == 0) {
+                if (done) {
+                    const int which = any_in_fort ? 2 : (n_alive_att == 0 ? 0 : 1);
+                    uint8_t *gr = a.s.game_result + (size_t)e * 3;
+                    gr[0] = which == 0; gr[1] = which == 1; gr[2] = which == 2;
+                    atomicAdd(a.s.result_count + (size_t)e * 3 + which, 1u);
+                }
+                if (COLLECT || a.done) a.done[(size_t)so * a.E + e] = done ? 1 : 0;
+            }
+            // evaluation statistics (test_fortattack_v2.py:88-101)
+            if (a.track_counters) {
+                ep_rew += alive0 ? rew : 0.0;
+                if (done) {
+                    a.s.ep_rew_sum[idx] += ep_rew;
+                    if (alive1) a.s.alive_end[idx] += 1u;
+                    ep_rew = 0.0;
+                }
+            }
+            const size_t o = (size_t)so * EN + idx;
+            // trainer mask (train_fortattack.py:53,87): alive BEFORE the step; an env that is
+            // reset here gets the post-reset mask 1 (initialize_new_episode, rlagent.py:31)
+            const float mk = (alive0 || do_reset) ? 1.0f : 0.0f;
+            if (COLLECT) {
+                a.rew32[o] = (float)rew;
+                a.mask32[o] = mk;
+            } else {
+                if (a.rew32) a.rew32[o] = (float)rew;
+                if (a.rew64) a.rew64[o] = rew;
+                if (a.mask32) a.mask32[o] = mk;
+                if (a.hit) a.hit[o] = hit ? 1 : 0;
+                if (a.was_hit) a.was_hit[o] = was_hit ? 1 : 0;
+            }
+            // observation row (fortattack_env_v1.py:238): the state after the step / reset
+            const double al = alive_new ? 1.0 : 0.0;
+            const size_t o6 = o * 6;
+            if (COLLECT || a.obs32) {
+                float2 *ob = reinterpret_cast<float2 *>(a.obs32 + o6);
+                ob[0] = make_float2((float)al, (float)px);
+                ob[1] = make_float2((float)py, (float)ang);
+                ob[2] = make_float2((float)vx, (float)vy);
+            }
+            if (!COLLECT && a.obs64) {
+                double2 *ob = reinterpret_cast<double2 *>(a.obs64 + o6);
+                ob[0] = make_double2(al, px);
+                ob[1] = make_double2(py, ang);
+                ob[2] = make_double2(vx, vy);
+            }
+        };
+        FA_TICK_INIT
+        FA_WG_BARRIER(); // P(-1)
+        for (int s = 0; s < ns; ++s) {
+            const int b = s & 1;
+            FA_TICK(10)
+            const unsigned long long grp_alive0 = (s_mask[b][0] >> gbase) & grp_mask;
+            const bool alive0 = (grp_alive0 >> i) & 1ull;
+            const double px = s_px[b][lane], py = s_py[b][lane];
+            const int act_cur = s_act[s & (FA_ACT_BATCH - 1)][lane];
+#pragma unroll
+            for (int d = 1; d <= NOFF; ++d) {
+                if ((d - 1) % NPW != wave_id - 1) continue; // uniform per wave
+                int j = i + d;
+                j = j >= N ? j - N : j;
+                const bool mine = (2 * d != N) || (i < N / 2); // the half offset: one side only
+                // candidate against a partner alive BEFORE the laser (one the laser kills this step
+                // is masked out in the sum); exactly +0.0 when out of range, so adding it is a no-op
+                const double dx = px - s_px[b][gbase + j], dy = py - s_py[b][gbase + j];
+                const double d2 = dx * dx + dy * dy;
+                double fxv = 0.0, fyv = 0.0;
+                bool near = false;
+                if (mine && alive0 && ((grp_alive0 >> j) & 1ull) && !(d2 > c.contact_skip_d2)) {
+                    const double dist = sqrt_rn(d2);
+                    const double pen = softplus_pen(div_rn(-(dist - c.dist_min), c.contact_margin), c.contact_margin);
+                    fxv = div_rn(c.contact_force * dx, dist) * pen;
+                    fyv = div_rn(c.contact_force * dy, dist) * pen;
+                    near = true;
+                }
+                if (mine) {
+                    s_fmx[j][lane] = fxv;               // on agent i from partner j
+                    s_fmy[j][lane] = fyv;
+                    s_fmx[i][gbase + j] = near ? -fxv : 0.0; // on agent j from partner i: the exact negative
+                    s_fmy[i][gbase + j] = near ? -fyv : 0.0;
+                }
+            }
+            FA_TICK(11)
+            FA_WG_BARRIER(); // B2(s)
+            FA_TICK(12)
+            if (out_wave && s > 0) emit(s - 1, b);
+            act_prev = act_cur;
+            alive0_prev = alive0;
+            FA_TICK(13)
+            FA_WG_BARRIER(); // P(s)
+        }
+        if (out_wave) {
+            emit(ns - 1, ns & 1);
+            a.s.prev[idx] = prev;
+            if (a.track_counters) a.s.ep_rew[idx] = ep_rew;
+        }
+        if (out_wave) { FA_TICK_FLUSH(10, 14, 29) }
+        return;
+    }
+
+    // ---- wave 0 ----------------------------------------------------------------------------------
+    double px = a.s.px[idx], py = a.s.py[idx], vx = a.s.vx[idx], vy = a.s.vy[idx];
+    double ang = a.s.ang[idx];
+    bool alive = a.s.alive[idx] != 0;
+    int t = a.s.tstep[e], nh = 0, nwh = 0;
+    if (a.track_counters) { nh = a.s.num_hit[idx]; nwh = a.s.num_was_hit[idx]; }
+    bool dirty = false;
+    int mt_base = (a.rng_mode == 0 ? a.s.mt_pos[e] : 0) + 4 * i;
+    const int64_t *act_ptr = a.actions + (int64_t)e * a.as_e + (int64_t)i * a.as_i;
+    int av[FA_ACT_BATCH];
+#pragma unroll
+    for (int k = 0; k < FA_ACT_BATCH; ++k) av[k] = (k < ns) ? (int)act_ptr[(int64_t)k * a.as_t] : 0;
+    // sin/cos of the current heading (first step: evaluated here) and of the reset heading
+    double sn, cs, sn_r = 0.0, cs_r = 0.0;
+    sincos_heading(ang, sn, cs);
+    if (ns > 1) sincos_heading(is_att ? c.ang_attacker : c.ang_guard, sn_r, cs_r);
+    int act = av[0];
+#pragma unroll
+    for (int k = 0; k < FA_ACT_BATCH; ++k) s_act[k][lane] = av[k];
+#pragma unroll
+    for (int k = 0; k < FA_ACT_BATCH; ++k)
+        av[k] = (FA_ACT_BATCH + k < ns) ? (int)act_ptr[(int64_t)(FA_ACT_BATCH + k) * a.as_t] : 0;
+    s_px[0][lane] = px;
+    s_py[0][lane] = py;
+    s_ang[0][lane] = ang;
+    {
+        const unsigned long long b0 = __ballot(alive);
+        if (lane == 0) s_mask[0][0] = b0;
+    }
+    FA_WG_BARRIER(); // P(-1)
+
+    FA_TICK_INIT
+    for (int s = 0; s < ns; ++s) {
+        const int nb = (s + 1) & 1;
+        const bool alive0 = alive;
+        // ---- fortattack.py:253-263,:289 _set_action ----------------------------------------
+        double u0 = 0.0, u1 = 0.0, rot = 0.0;
+        if (act == 1) u0 = +1.0;
+        if (act == 2) u0 = -1.0;
+        if (act == 3) u1 = +1.0;
+        if (act == 4) u1 = -1.0;
+        if (act == 5) rot = c.rot_pos;
+        if (act == 6) rot = c.rot_neg;
+        const bool shoot = act == 7;
+        u0 *= c.accel;
+        u1 *= c.accel;
+        const bool shooter = alive0 && shoot;
+        // ---- laser triangles (core.py:373-382) from the published sin/cos ---------------------
+        // cos/sin(ang +- shootWin/2) by the angle-addition identities with host-evaluated
+        // cos/sin(shootWin/2) (see fa_step_kernel)
+        if (shooter) {
+            const double x1 = px + c.agent_size * cs, y1 = py + c.agent_size * sn;
+            const double cp = cs * c.cos_hw - sn * c.sin_hw, sp = sn * c.cos_hw + cs * c.sin_hw;
+            const double cm = cs * c.cos_hw + sn * c.sin_hw, sm = sn * c.cos_hw - cs * c.sin_hw;
+            const double x2 = x1 + c.shoot_rad * cp, y2 = y1 + c.shoot_rad * sp;
+            const double x3 = x1 + c.shoot_rad * cm, y3 = y1 + c.shoot_rad * sm;
+            s_tri[0][lane] = x1; s_tri[1][lane] = y1; s_tri[2][lane] = x2;
+            s_tri[3][lane] = y2; s_tri[4][lane] = x3; s_tri[5][lane] = y3;
+        }
+        const unsigned long long shooters_b = __ballot(shooter);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        FA_TICK(0)
+
+        // ---- core.py:254-302 apply_laser_effect ------------------------------------------------
+        // iteration k: every lane tests the triangle of its k-th opponent; the ballot of the
+        // results gives shooter k of either team its hit list.
+        bool was_hit = false;
+        int hit_cnt = 0, was_hit_cnt = 0;
+        if (shooters_b != 0ull) {
+            const int n_opp = is_att ? G : A, opp0 = is_att ? 0 : G;
+            const int team_idx = is_att ? i - G : i;
+            const unsigned long long opp_mask = is_att ? ((1ull << G) - 1ull) : (((1ull << A) - 1ull) << G);
+            constexpr int KT = TG > TA ? TG : TA;
+            double tr[KT][6];
+            bool hk[KT];
+#pragma unroll
+            for (int k = 0; k < KT; ++k) {
+                const int j = gbase + opp0 + (k < n_opp ? k : 0);
+#pragma unroll
+                for (int q = 0; q < 6; ++q) tr[k][q] = s_tri[q][j];
+            }
+#pragma unroll
+            for (int k = 0; k < KT; ++k) {
+                const int j = gbase + opp0 + k;
+                const bool cand = alive0 && k < n_opp && ((shooters_b >> j) & 1ull);
+                hk[k] = cand & laser_hit(tr[k][0], tr[k][1], tr[k][2], tr[k][3], tr[k][4], tr[k][5], px, py);
+            }
+            unsigned long long my_hb = 0ull;
+#pragma unroll
+            for (int k = 0; k < KT; ++k) {
+                const unsigned long long hb = __ballot(hk[k]);
+                my_hb = (k == team_idx) ? hb : my_hb;
+                was_hit = was_hit | hk[k];
+                was_hit_cnt += hk[k] ? 1 : 0;
+            }
+            hit_cnt = __popcll((my_hb >> gbase) & opp_mask);
+        }
+        const bool hit = shooter && hit_cnt > 0;
+        const bool alive1 = alive0 && !was_hit;       // :293-302 one shot kills
+        const unsigned long long alive1_b = __ballot(alive1);
+        const unsigned long long hit_b = __ballot(hit), was_hit_b = __ballot(was_hit);
+        const unsigned long long grp_alive1 = (alive1_b >> gbase) & grp_mask;
+        const int n_alive_att = __popcll(grp_alive1 >> G);
+        FA_TICK(1)
+        FA_WG_BARRIER(); // B2(s): pair and wall forces of this step are in LDS
+        FA_TICK(2)
+
+        // ---- core.py:221-252: F = u + 0, the pairs in the reference's order (for agent i:
+        // partner j ascending), then the walls -------------------------------------------------
+        double fmx[N], fmy[N];
+#pragma unroll
+        for (int j = 0; j < N; ++j) { fmx[j] = s_fmx[j][lane]; fmy[j] = s_fmy[j][lane]; }
+        const double wx = s_W[0][lane], wy = s_W[1][lane];
+        const double cs_n = s_trig[0][lane], sn_n = s_trig[1][lane]; // heading of step s+1 (survivor)
+        const bool restage = ((s + 1) & (FA_ACT_BATCH - 1)) == 0;
+        const int act_lds = s_act[(s + 1) & (FA_ACT_BATCH - 1)][lane];
+        int act_next = restage ? av[0] : act_lds;
+        if (alive1) {
+            double Fx = u0 + 0.0, Fy = u1 + 0.0;
+#pragma unroll
+            for (int j = 0; j < N; ++j)
+                if (j != i && ((grp_alive1 >> j) & 1ull)) {
+                    Fx = fmx[j] + Fx;
+                    Fy = fmy[j] + Fy;
+                }
+            Fx = wx + Fx;
+            Fy = wy + Fy;
+            // core.py:324-338 integrate_state (mass == 1.0: F/1.0 is exact)
+            vx = vx * c.one_minus_damping;
+            vy = vy * c.one_minus_damping;
+            vx += Fx * c.dt;
+            vy += Fy * c.dt;
+            const double speed2 = vx * vx + vy * vy;
+            if (speed2 > c.speed2_max) { // == sqrt(v.v) > max_speed, see fa_step_kernel
+                const double speed = sqrt_rn(speed2);
+                vx = div_rn(vx, speed) * c.max_speed;
+                vy = div_rn(vy, speed) * c.max_speed;
+            }
+            ang += rot;
+            px += vx * c.dt;
+            py += vy * c.dt;
+        }
+        FA_TICK(3)
+        // ---- what the next state needs of the reward / done logic ------------------------------
+        // (`dist_door < fort_dim` decided on the squared distance, see FaDerived::fort2_max; the
+        // square root itself is only needed by the rewards and is taken by the output wave)
+        const double ddx = px - c.door_x, ddy = py - c.door_y;
+        const double dd2 = ddx * ddx + ddy * ddy;
+        const unsigned long long in_fort_b = __ballot(is_att && alive1 && dd2 <= c.fort2_max);
+        const bool any_in_fort = ((in_fort_b >> gbase) & grp_mask) != 0ull;
+        const bool timeout = t == a.max_t - 1;
+        const bool done = any_in_fort || n_alive_att == 0 || timeout; // fortattack.py:202-225
+        const bool do_reset = done && a.auto_reset != 0;
+        const unsigned long long done_b = __ballot(done);
+        t += 1;                                                        // fortattack.py:171
+        alive = alive1;
+        nh += hit_cnt;
+        nwh += was_hit_cnt; // one per shooter that hit (core.py:283)
+        dirty = dirty || alive0;
+        FA_TICK(4)
+        // ---- fortattack_env_v1.py:47-75 reset_world (prevDist is NOT reset: quirk Q1) ----------
+        if (__ballot(do_reset) != 0ull) {
+            double npx = px, npy = py;
+            reset_agent(a, e, i, N, is_att, do_reset, mt_base, npx, npy);
+            if (do_reset) {
+                px = npx; py = npy; vx = 0.0; vy = 0.0;
+                ang = is_att ? c.ang_attacker : c.ang_guard;
+                alive = true;
+                t = 0;
+                nh = 0; nwh = 0;
+                dirty = true;
+                if (i == 0) reset_advance(a, e, mt_base);
+            }
+        }
+        FA_TICK(5)
+        // ---- publish state(s+1) and the by-products of step s ----------------------------------
+        s_px[nb][lane] = px;
+        s_py[nb][lane] = py;
+        s_ang[nb][lane] = ang;
+        s_vx[nb][lane] = vx;
+        s_vy[nb][lane] = vy;
+        s_dd[nb][lane] = dd2;
+        {
+            const unsigned long long alive_b = __ballot(alive);
+            if (lane == 0) {
+                s_mask[nb][0] = alive_b;
+                s_mask[nb][1] = alive1_b;
+                s_mask[nb][2] = hit_b;
+                s_mask[nb][3] = was_hit_b;
+                s_mask[nb][4] = done_b;
+            }
+        }
+        if (restage) {
+#pragma unroll
+            for (int k = 0; k < FA_ACT_BATCH; ++k) s_act[k][lane] = av[k];
+        }
+        // (pinned here: selected after the barrier, av[0] would still be live when the next batch
+        // is loaded and the loop would carry a copy of a pending load -- a vmcnt(0) every step)
+        asm volatile("" : "+v"(act_next));
+        FA_TICK(6)
+        FA_WG_BARRIER(); // P(s)
+        FA_TICK(7)
+        if (restage) {
+#pragma unroll
+            for (int k = 0; k < FA_ACT_BATCH; ++k)
+                av[k] = (s + 1 + FA_ACT_BATCH + k < ns) ? (int)act_ptr[(int64_t)(s + 1 + FA_ACT_BATCH + k) * a.as_t] : 0;
+        }
+        // sin/cos of the next heading: the last wave's for a survivor, the constant pair after a reset
+        cs = do_reset ? cs_r : cs_n;
+        sn = do_reset ? sn_r : sn_n;
+        act = act_next;
+    }
+    FA_TICK_FLUSH(0, 8, 28)
+
+    if (dirty) {
+        a.s.px[idx] = px; a.s.py[idx] = py; a.s.vx[idx] = vx; a.s.vy[idx] = vy;
+        a.s.ang[idx] = ang;
+        a.s.alive[idx] = alive ? 1 : 0;
+        if (a.track_counters) { a.s.num_hit[idx] = nh; a.s.num_was_hit[idx] = nwh; }
+    }
+    if (i == 0) a.s.tstep[e] = t;
+}
+
+#ifdef FA_TIMING
+extern "C" int fa_dbg_read(unsigned long long *out, int reset) {
+    hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg), sizeof(unsigned long long) * 32);
+    if (reset) { unsigned long long z[32] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_dbg), z, sizeof(z)); }
+    return 0;
+}
+#endif
+
 // ---- np.random.seed(int): init_genrand, then discard the construction draws ----------
 __global__ void fa_seed_kernel(FaState s, int E, uint64_t base_seed, int64_t env_offset, int skip_words) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -737,18 +1229,25 @@ static hipError_t launch_step_t(const FaStepArgs &a, hipStream_t st) {
     // two cooperating waves per workgroup while that still leaves at most ~2 waves per SIMD
     // (latency regime); beyond, one wave per workgroup uses the SIMDs better
     // cooperating waves per workgroup while the launch is in the latency regime
-    const int nw = RESET_ONLY ? 1 : (grid <= FA_THREE_WAVE_MAX_GRID ? 3 : (grid <= FA_TWO_WAVE_MAX_GRID ? 2 : 1));
+    static const int max3 = getenv("FA_MAX3") ? atoi(getenv("FA_MAX3")) : FA_THREE_WAVE_MAX_GRID;
+    const int nw = RESET_ONLY ? 1 : (grid <= max3 ? 3 : (grid <= FA_TWO_WAVE_MAX_GRID ? 2 : 1));
 #define FA_LAUNCH(TG_, TA_, NW_) \
     hipLaunchKernelGGL((fa_step_kernel<TG_, TA_, RESET_ONLY, COLLECT, RESET_ONLY ? 1 : NW_>), dim3(grid), \
                        dim3((RESET_ONLY ? 1 : NW_) * FA_WAVE), 0, st, a)
+#define FA_LAUNCH_PIPE(TG_, TA_, NPW_, MINW_) \
+    hipLaunchKernelGGL((fa_step_pipe_kernel<TG_, TA_, COLLECT, NPW_, MINW_>), dim3(grid), dim3((NPW_ + 2) * FA_WAVE), 0, st, a)
+    static const int pipe_mode = getenv("FA_PIPE") ? atoi(getenv("FA_PIPE")) : 2;
     if (a.G == 3 && a.A == 3) {
-        if (nw == 3) FA_LAUNCH(3, 3, 3); else if (nw == 2) FA_LAUNCH(3, 3, 2); else FA_LAUNCH(3, 3, 1);
+        if (nw == 3 && pipe_mode == 1) FA_LAUNCH_PIPE(3, 3, 1, 2); else if (nw == 3 && pipe_mode == 2) FA_LAUNCH_PIPE(3, 3, 2, 2); else if (nw == 3 && pipe_mode == 3) FA_LAUNCH_PIPE(3, 3, 3, 3); else if (nw == 3 && pipe_mode == 4) FA_LAUNCH_PIPE(3, 3, 3, 4);
+        else if (nw == 3) FA_LAUNCH(3, 3, 3); else if (nw == 2) FA_LAUNCH(3, 3, 2); else FA_LAUNCH(3, 3, 1);
     } else if (a.G == 5 && a.A == 5) {
-        if (nw == 3) FA_LAUNCH(5, 5, 3); else if (nw == 2) FA_LAUNCH(5, 5, 2); else FA_LAUNCH(5, 5, 1);
+        if (nw == 3 && pipe_mode == 1) FA_LAUNCH_PIPE(5, 5, 1, 3); else if (nw == 3 && pipe_mode == 2) FA_LAUNCH_PIPE(5, 5, 2, 3); else if (nw == 3 && pipe_mode == 3) FA_LAUNCH_PIPE(5, 5, 3, 4); else if (nw == 3 && pipe_mode == 5) FA_LAUNCH_PIPE(5, 5, 5, 2);
+        else if (nw == 3) FA_LAUNCH(5, 5, 3); else if (nw == 2) FA_LAUNCH(5, 5, 2); else FA_LAUNCH(5, 5, 1);
     } else {
         FA_LAUNCH(0, 0, 1);
     }
 #undef FA_LAUNCH
+#undef FA_LAUNCH_PIPE
     return hipGetLastError();
 }
 

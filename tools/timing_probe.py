@@ -1,17 +1,21 @@
-"""Experiment: per-section shader-clock breakdown of the fused step kernel (needs the
--DFA_TIMING build in exp_libs/libfa_timing.so; run with FA_LIB_OVERRIDE pointing at it)."""
+"""Experiment: per-section shader-clock breakdown of the pipelined step kernel, per wave role
+(needs exp_libs/libfa_timing.so from tools/make_timing_build.py; run with FA_LIB_OVERRIDE
+pointing at it).  usage: timing_probe.py [E] [G] [A]"""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import emergent_multiagent_strategies_amd as fa
-E, G, A, T = 4096, 3, 3, 128
+E = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+G = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+A = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+T = 128
 eng = fa.BatchedFortAttack(E, G, A, 100, track_counters=False)
 st = fa.JointRolloutStorage(T, E, G + A, device="cuda")
 eng.bind_storage(st)
 st.actions.copy_(torch.randint(0, 8, st.actions.shape, device="cuda"))
 eng.collect_reset()
 lib = C.CDLL(os.environ["FA_LIB_OVERRIDE"])
-buf = (C.c_ulonglong * 16)()
+buf = (C.c_ulonglong * 32)()
 for _ in range(3):
     eng.collect_rollout(0, T)
 torch.cuda.synchronize()
@@ -20,11 +24,15 @@ for _ in range(5):
     eng.collect_rollout(0, T)
 torch.cuda.synchronize()
 lib.fa_dbg_read(buf, 0)
-waves = buf[10]
-names = ["loop + action read", "decode + stage pos (to barrier 1)", "barrier 1", "sin/cos + triangle stage",
-         "laser tests", "ballots (to barrier 2)", "barriers 2+3 (force wave)", "F read + integrate", "reward + done + outputs",
-         "reset + obs store"]
-tot = sum(buf[k] for k in range(10))
-for k, n in enumerate(names):
-    print("%-22s %8.1f cycles/step  %5.1f%%" % (n, buf[k] / waves / T, 100.0 * buf[k] / tot))
-print("total %.1f cycles/step" % (tot / waves / T))
+names = {0: "w0 decode + triangles", 1: "w0 laser + ballots", 2: "w0 wait B2", 3: "w0 force sum + integrate",
+         4: "w0 door distance + done", 5: "w0 reset", 6: "w0 publish", 7: "w0 wait P",
+         10: "out wait P", 11: "out pair forces", 12: "out wait B2", 13: "out rewards + stores",
+         16: "last wait P", 17: "last walls", 18: "last sin/cos", 19: "last wait B2"}
+for lo, hi, cnt in ((0, 8, 28), (10, 14, 29), (16, 20, 30)):
+    waves = max(buf[cnt], 1)
+    tot = 0.0
+    for k in range(lo, hi):
+        v = buf[k] / waves / T
+        tot += v
+        print("%-28s %8.1f cycles/step" % (names[k], v))
+    print("%-28s %8.1f cycles/step\n" % ("  total", tot))
