@@ -94,6 +94,7 @@ FaDerived derive(const fa_world_consts &w) {
     d.half_win = w.shoot_win / 2;                  // core.py:376
     d.cos_hw = std::cos(d.half_win);
     d.sin_hw = std::sin(d.half_win);
+    d.shoot_far = w.shoot_rad * d.cos_hw;
     {   // largest double x with sqrt(x) <= max_speed (host sqrt is correctly rounded)
         double x = w.max_speed * w.max_speed;
         while (std::sqrt(x) > w.max_speed) x = std::nextafter(x, 0.0);

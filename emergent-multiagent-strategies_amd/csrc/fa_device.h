@@ -25,6 +25,7 @@ struct FaDerived {
     double wall_xmin, wall_xmax, wall_ymin, wall_ymax;
     double shoot_rad, half_win;
     double cos_hw, sin_hw;          // cos/sin(shootWin/2), host libm
+    double shoot_far;               // shoot_rad * cos(shootWin/2): distance of the wedge's far edge
     double speed2_max;              // max{x : sqrt_rn(x) <= max_speed}
     double fort2_max;               // max{x : sqrt_rn(x) <  fort_dim}
     double rot_pos, rot_neg;        // (+max_rot) % 2pi, (-max_rot) % 2pi  (Python modulo, core.py:336)

@@ -100,6 +100,69 @@ __device__ __forceinline__ void reset_advance(const FaStepArgs &a, int e, int ne
     else a.s.reset_count[e] += 1u;
 }
 
+// The pipelined kernel draws reset positions AHEAD of the reset, on a helper wave: a draw only
+// depends on the RNG stream.  Two draws are pending per lane -- A, published in LDS for the next
+// reset, and B, which replaces A the moment A is used (an env can be reset in consecutive steps) --
+// plus the 9 MT words the draw after B needs, loaded early.  The twisted words of a draw and the
+// env's cursor are stored only when a reset really uses the draw, so the state in HBM always is
+// the stream position after the resets that took place.  Safe for N <= 18: the words of the two
+// following draws (cursor + 4N .. cursor + 12N) and their +397 partners are not written by A.
+struct ResetDraw {
+    double px, py;
+    uint32_t nw[4]; // MT: twisted words of the draw
+    int base;       // MT: cursor + 4*i of the draw;  Philox: the env's reset counter for the draw
+};
+struct MtWords { uint32_t cur[5], far_[4]; };
+__device__ __forceinline__ int draw_next_base(const FaStepArgs &a, int base, int i, int N) {
+    return a.rng_mode == 0 ? mt_wrap(base - 4 * i + 4 * N) + 4 * i : base + 1;
+}
+__device__ __forceinline__ void draw_load(const FaStepArgs &a, int e, int base, MtWords &w) {
+    if (a.rng_mode != 0) return;
+    const uint32_t *mt = a.s.mt + (size_t)e * FA_MT_N;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) w.cur[k] = mt[mt_wrap(base + k)];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) w.far_[k] = mt[mt_wrap(mt_wrap(base + k) + FA_MT_M)];
+}
+// positions of the draw at d.base from the loaded words (MT) or the counter (Philox); reset_world
+// fortattack_env_v1.py:47-75 as in reset_agent()
+__device__ __forceinline__ void draw_eval(const FaStepArgs &a, int e, int i, bool is_att, const MtWords &mw,
+                                          ResetDraw &d) {
+    uint32_t w[4];
+    if (a.rng_mode == 0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            d.nw[k] = mt_twist(mw.cur[k], mw.cur[k + 1], mw.far_[k]);
+            w[k] = mt_temper(d.nw[k]);
+        }
+    } else {
+        const uint64_t genv = (uint64_t)(a.env_offset + e);
+        uint32_t c[4] = {(uint32_t)genv, (uint32_t)(genv >> 32), (uint32_t)d.base, (uint32_t)i};
+        philox4x32_10(c, (uint32_t)a.seed, (uint32_t)(a.seed >> 32));
+        w[0] = c[0]; w[1] = c[1]; w[2] = c[2]; w[3] = c[3];
+    }
+    const double u1 = res53(w[0], w[1]), u2 = res53(w[2], w[3]);
+    if (is_att) { // :66
+        d.px = a.c.att_x_lo + a.c.att_x_rng * u1;
+        d.py = a.c.att_y_lo + a.c.att_y_rng * u2;
+    } else {      // :70
+        d.px = a.c.grd_x_lo + a.c.grd_x_rng * u1;
+        d.py = a.c.grd_y_lo + a.c.grd_y_rng * u2;
+    }
+}
+// the draw was used by a reset: make it part of the stream in HBM
+__device__ __forceinline__ void draw_commit(const FaStepArgs &a, int e, int i, int N, const ResetDraw &d) {
+    const int nb = draw_next_base(a, d.base, i, N);
+    if (a.rng_mode == 0) {
+        uint32_t *mt = a.s.mt + (size_t)e * FA_MT_N;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) mt[mt_wrap(d.base + k)] = d.nw[k];
+        if (i == 0) a.s.mt_pos[e] = nb;
+    } else {
+        if (i == 0) a.s.reset_count[e] = (uint32_t)nb;
+    }
+}
+
 // ---- correctly rounded fp64 divide / sqrt without the range-scaling wrappers -----------------
 // hipcc expands a/b into v_div_scale x2 + v_rcp + 2 Newton FMAs + mul + residual FMA +
 // v_div_fmas + v_div_fixup (11 instructions, serialised through VCC) and sqrt(x) into a
@@ -731,6 +794,9 @@ __global__ __launch_bounds__(NW * FA_WAVE) void fa_step_kernel(FaStepArgs a) {
 //     does not wait for this step's forces (a dead agent's value is never used; a reset agent
 //     takes the constant pair).
 // Two workgroup barriers per step: B2 (pair + wall forces of step s are in LDS) and P.
+#ifndef FA_ABL
+#define FA_ABL 0
+#endif
 #ifdef FA_TIMING
 __device__ unsigned long long g_dbg[32];
 #define FA_TICK_INIT unsigned long long tacc[24] = {0}; unsigned long long tlast = clock64();
@@ -764,9 +830,11 @@ __global__ __launch_bounds__((NPW + 2) * FA_WAVE, MINW) void fa_step_pipe_kernel
     __shared__ double s_px[2][FA_WAVE], s_py[2][FA_WAVE], s_ang[2][FA_WAVE];
     __shared__ double s_vx[2][FA_WAVE], s_vy[2][FA_WAVE], s_dd[2][FA_WAVE];
     __shared__ unsigned long long s_mask[2][8]; // ballots: 0 alive, 1 alive after laser, 2 hit, 3 was hit, 4 done
-    __shared__ double s_tri[6][FA_WAVE], s_trig[2][FA_WAVE], s_W[2][FA_WAVE];
+    __shared__ double s_trig[2][2][FA_WAVE]; // [step parity][cos, sin][lane]: heading of the step's start state
+    __shared__ double s_W[2][FA_WAVE];
     __shared__ double s_fmx[N][FA_WAVE], s_fmy[N][FA_WAVE]; // [partner j][lane]: pair force on the lane's agent
     __shared__ int s_act[FA_ACT_BATCH][FA_WAVE];
+    __shared__ double s_rp[2][FA_WAVE]; // positions of the lane's next reset (drawn ahead by wave 1)
 
     if (wave_id == NPW + 1) {
         // ---- last wave: walls of step s, sin/cos of the heading of step s+1 ----------------------
@@ -780,7 +848,7 @@ __global__ __launch_bounds__((NPW + 2) * FA_WAVE, MINW) void fa_step_pipe_kernel
             const bool alive0 = (s_mask[b][0] >> lane) & 1ull;
             const double px = s_px[b][lane], py = s_py[b][lane];
             double wx = 0.0, wy = 0.0;
-            if (alive0) { // core.py:246-252 + :459-472; exactly +0.0 off the walls
+            if (!(FA_ABL & 16) && alive0) { // core.py:246-252 + :459-472; exactly +0.0 off the walls
                 const double k = c.contact_margin, size = c.agent_size;
                 const double d0 = px - size - c.wall_xmin, d1 = c.wall_xmax - px - size;
                 const double d2 = py - size - c.wall_ymin, d3 = c.wall_ymax - py - size;
@@ -799,17 +867,17 @@ __global__ __launch_bounds__((NPW + 2) * FA_WAVE, MINW) void fa_step_pipe_kernel
             s_W[0][lane] = wx;
             s_W[1][lane] = wy;
             FA_TICK(17)
-            if (s + 1 < ns) {
+            FA_WG_BARRIER(); // B2(s)
+            FA_TICK(18)
+            if (!(FA_ABL & 32) && s + 1 < ns) {
                 double rot = 0.0;
                 if (act == 5) rot = c.rot_pos;
                 if (act == 6) rot = c.rot_neg;
                 double sn, cs;
                 sincos_heading(ang + rot, sn, cs); // == wave 0's `ang += rot` for a survivor
-                s_trig[0][lane] = cs;
-                s_trig[1][lane] = sn;
+                s_trig[(s + 1) & 1][0][lane] = cs;
+                s_trig[(s + 1) & 1][1][lane] = sn;
             }
-            FA_TICK(18)
-            FA_WG_BARRIER(); // B2(s)
             FA_TICK(19)
             FA_WG_BARRIER(); // P(s)
         }
@@ -914,11 +982,41 @@ __global__ __launch_bounds__((NPW + 2) * FA_WAVE, MINW) void fa_step_pipe_kernel
                 ob[2] = make_double2(vx, vy);
             }
         };
+        // wave 1 owns the env's reset stream during the launch (see ResetDraw)
+        const bool rng_wave = wave_id == 1;
+        ResetDraw rdA = {}, rdB = {};
+        MtWords mw = {};
+        bool need_b = false;
+        auto wait_words = [&]() { if (a.rng_mode == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
+        if (rng_wave) {
+            rdA.base = a.rng_mode == 0 ? a.s.mt_pos[e] + 4 * i : (int)a.s.reset_count[e];
+            draw_load(a, e, rdA.base, mw);
+            wait_words();
+            draw_eval(a, e, i, is_att, mw, rdA);
+            rdB.base = draw_next_base(a, rdA.base, i, N);
+            draw_load(a, e, rdB.base, mw);
+            wait_words();
+            draw_eval(a, e, i, is_att, mw, rdB);
+            draw_load(a, e, draw_next_base(a, rdB.base, i, N), mw);
+            s_rp[0][lane] = rdA.px;
+            s_rp[1][lane] = rdA.py;
+        }
         FA_TICK_INIT
         FA_WG_BARRIER(); // P(-1)
         for (int s = 0; s < ns; ++s) {
             const int b = s & 1;
             FA_TICK(10)
+            if (rng_wave && s > 0 && a.auto_reset != 0) {
+                // envs that were reset at the end of step s-1 used draw A: commit it, promote B (in
+                // LDS before B2(s), i.e. before wave 0 can need it); the new B is drawn after B2
+                need_b = (s_mask[b][4] >> lane) & 1ull;
+                if (need_b) {
+                    draw_commit(a, e, i, N, rdA);
+                    rdA = rdB;
+                    s_rp[0][lane] = rdA.px;
+                    s_rp[1][lane] = rdA.py;
+                }
+            }
             const unsigned long long grp_alive0 = (s_mask[b][0] >> gbase) & grp_mask;
             const bool alive0 = (grp_alive0 >> i) & 1ull;
             const double px = s_px[b][lane], py = s_py[b][lane];
@@ -935,7 +1033,7 @@ __global__ __launch_bounds__((NPW + 2) * FA_WAVE, MINW) void fa_step_pipe_kernel
                 const double d2 = dx * dx + dy * dy;
                 double fxv = 0.0, fyv = 0.0;
                 bool near = false;
-                if (mine && alive0 && ((grp_alive0 >> j) & 1ull) && !(d2 > c.contact_skip_d2)) {
+                if (!(FA_ABL & 8) && mine && alive0 && ((grp_alive0 >> j) & 1ull) && !(d2 > c.contact_skip_d2)) {
                     const double dist = sqrt_rn(d2);
                     const double pen = softplus_pen(div_rn(-(dist - c.dist_min), c.contact_margin), c.contact_margin);
                     fxv = div_rn(c.contact_force * dx, dist) * pen;
@@ -952,12 +1050,20 @@ __global__ __launch_bounds__((NPW + 2) * FA_WAVE, MINW) void fa_step_pipe_kernel
             FA_TICK(11)
             FA_WG_BARRIER(); // B2(s)
             FA_TICK(12)
-            if (out_wave && s > 0) emit(s - 1, b);
+            if (rng_wave && need_b) {
+                wait_words();
+                rdB.base = draw_next_base(a, rdA.base, i, N);
+                draw_eval(a, e, i, is_att, mw, rdB);
+                draw_load(a, e, draw_next_base(a, rdB.base, i, N), mw);
+            }
+            need_b = false;
+            if (!(FA_ABL & 1) && out_wave && s > 0) emit(s - 1, b);
             act_prev = act_cur;
             alive0_prev = alive0;
             FA_TICK(13)
             FA_WG_BARRIER(); // P(s)
         }
+        if (rng_wave && a.auto_reset != 0 && ((s_mask[ns & 1][4] >> lane) & 1ull)) draw_commit(a, e, i, N, rdA);
         if (out_wave) {
             emit(ns - 1, ns & 1);
             a.s.prev[idx] = prev;
@@ -974,15 +1080,34 @@ __global__ __launch_bounds__((NPW + 2) * FA_WAVE, MINW) void fa_step_pipe_kernel
     int t = a.s.tstep[e], nh = 0, nwh = 0;
     if (a.track_counters) { nh = a.s.num_hit[idx]; nwh = a.s.num_was_hit[idx]; }
     bool dirty = false;
-    int mt_base = (a.rng_mode == 0 ? a.s.mt_pos[e] : 0) + 4 * i;
     const int64_t *act_ptr = a.actions + (int64_t)e * a.as_e + (int64_t)i * a.as_i;
     int av[FA_ACT_BATCH];
 #pragma unroll
     for (int k = 0; k < FA_ACT_BATCH; ++k) av[k] = (k < ns) ? (int)act_ptr[(int64_t)k * a.as_t] : 0;
-    // sin/cos of the current heading (first step: evaluated here) and of the reset heading
-    double sn, cs, sn_r = 0.0, cs_r = 0.0;
+    // ---- the laser test (core.py:373-390) in the shooter's frame -------------------------------
+    // The reference's triangle is the isosceles wedge with its apex at p + size*(cos a, sin a),
+    // half-angle shootWin/2 about the heading a and its far edge perpendicular to the heading at
+    // shootRad*cos(shootWin/2).  With d = target - apex, u = d.(cos a, sin a), v = d x (cos a, sin a):
+    //     inside  <=>  u <= shootRad*cos(w/2)  and  |v| cos(w/2) <= u sin(w/2)
+    // -- the same predicate as the barycentric test of fa_step_kernel / the oracle, evaluated
+    // from (apex, cos a, sin a) instead of three vertices: no triangle staging, 10 flops per test.
+    // It can differ from the vertex form only for a target within rounding (1e-16) of an edge.
+    // A target lane needs apex and sin/cos of its opponents: the apex goes through LDS inside this
+    // wave, sin/cos of the next heading comes from the last wave (constants after a reset).
+    constexpr int KT = TG > TA ? TG : TA;
+    const int n_opp = is_att ? G : A, opp0 = is_att ? 0 : G;
+    const int team_idx = is_att ? i - G : i;
+    const unsigned long long opp_mask = is_att ? ((1ull << G) - 1ull) : (((1ull << A) - 1ull) << G);
+    double sn, cs, sn_g = 0.0, cs_g = 0.0, sn_a = 0.0, cs_a = 0.0;
     sincos_heading(ang, sn, cs);
-    if (ns > 1) sincos_heading(is_att ? c.ang_attacker : c.ang_guard, sn_r, cs_r);
+    if (ns > 1) { // headings after a reset (fortattack_env_v1.py:59)
+        sincos_heading(c.ang_guard, sn_g, cs_g);
+        sincos_heading(c.ang_attacker, sn_a, cs_a);
+    }
+    const double cs_ro = is_att ? cs_g : cs_a, sn_ro = is_att ? sn_g : sn_a;   // the opponents
+    double oqx[KT], oqy[KT], ocs[KT], osn[KT]; // the opponents' position and heading at the step's start
+    s_trig[0][0][lane] = cs;
+    s_trig[0][1][lane] = sn;
     int act = av[0];
 #pragma unroll
     for (int k = 0; k < FA_ACT_BATCH; ++k) s_act[k][lane] = av[k];
@@ -996,7 +1121,20 @@ __global__ __launch_bounds__((NPW + 2) * FA_WAVE, MINW) void fa_step_pipe_kernel
         const unsigned long long b0 = __ballot(alive);
         if (lane == 0) s_mask[0][0] = b0;
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int k = 0; k < KT; ++k) {
+        const int j = gbase + opp0 + (k < n_opp ? k : 0);
+        oqx[k] = s_px[0][j]; oqy[k] = s_py[0][j];
+        ocs[k] = s_trig[0][0][j]; osn[k] = s_trig[0][1][j];
+    }
+    bool reset_prev = false;
     FA_WG_BARRIER(); // P(-1)
+#ifdef FA_TIMING
+    const unsigned long long tk0 = clock64(), tw0 = wall_clock64();
+#endif
 
     FA_TICK_INIT
     for (int s = 0; s < ns; ++s) {
@@ -1014,47 +1152,34 @@ __global__ __launch_bounds__((NPW + 2) * FA_WAVE, MINW) void fa_step_pipe_kernel
         u0 *= c.accel;
         u1 *= c.accel;
         const bool shooter = alive0 && shoot;
-        // ---- laser triangles (core.py:373-382) from the published sin/cos ---------------------
-        // cos/sin(ang +- shootWin/2) by the angle-addition identities with host-evaluated
-        // cos/sin(shootWin/2) (see fa_step_kernel)
-        if (shooter) {
-            const double x1 = px + c.agent_size * cs, y1 = py + c.agent_size * sn;
-            const double cp = cs * c.cos_hw - sn * c.sin_hw, sp = sn * c.cos_hw + cs * c.sin_hw;
-            const double cm = cs * c.cos_hw + sn * c.sin_hw, sm = sn * c.cos_hw - cs * c.sin_hw;
-            const double x2 = x1 + c.shoot_rad * cp, y2 = y1 + c.shoot_rad * sp;
-            const double x3 = x1 + c.shoot_rad * cm, y3 = y1 + c.shoot_rad * sm;
-            s_tri[0][lane] = x1; s_tri[1][lane] = y1; s_tri[2][lane] = x2;
-            s_tri[3][lane] = y2; s_tri[4][lane] = x3; s_tri[5][lane] = y3;
-        }
         const unsigned long long shooters_b = __ballot(shooter);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        FA_TICK(0)
-
-        // ---- core.py:254-302 apply_laser_effect ------------------------------------------------
-        // iteration k: every lane tests the triangle of its k-th opponent; the ballot of the
-        // results gives shooter k of either team its hit list.
-        bool was_hit = false;
-        int hit_cnt = 0, was_hit_cnt = 0;
-        if (shooters_b != 0ull) {
-            const int n_opp = is_att ? G : A, opp0 = is_att ? 0 : G;
-            const int team_idx = is_att ? i - G : i;
-            const unsigned long long opp_mask = is_att ? ((1ull << G) - 1ull) : (((1ull << A) - 1ull) << G);
-            constexpr int KT = TG > TA ? TG : TA;
-            double tr[KT][6];
-            bool hk[KT];
+        if (s > 0) { // sin/cos of the opponents' headings: the last wave's, constants after a reset
 #pragma unroll
             for (int k = 0; k < KT; ++k) {
                 const int j = gbase + opp0 + (k < n_opp ? k : 0);
-#pragma unroll
-                for (int q = 0; q < 6; ++q) tr[k][q] = s_tri[q][j];
+                const double cn = s_trig[s & 1][0][j], sn_ = s_trig[s & 1][1][j];
+                ocs[k] = reset_prev ? cs_ro : cn;
+                osn[k] = reset_prev ? sn_ro : sn_;
             }
+        }
+        FA_TICK(0)
+
+        // ---- core.py:254-302 apply_laser_effect ------------------------------------------------
+        // test k: every lane against its k-th opponent; the ballot of the results gives shooter k
+        // of either team its hit list.
+        bool was_hit = false;
+        int hit_cnt = 0, was_hit_cnt = 0;
+        if (!(FA_ABL & 2) && shooters_b != 0ull) {
+            bool hk[KT];
 #pragma unroll
             for (int k = 0; k < KT; ++k) {
                 const int j = gbase + opp0 + k;
                 const bool cand = alive0 && k < n_opp && ((shooters_b >> j) & 1ull);
-                hk[k] = cand & laser_hit(tr[k][0], tr[k][1], tr[k][2], tr[k][3], tr[k][4], tr[k][5], px, py);
+                const double ax = oqx[k] + c.agent_size * ocs[k], ay = oqy[k] + c.agent_size * osn[k];
+                const double dx = px - ax, dy = py - ay;
+                const double u = dx * ocs[k] + dy * osn[k];
+                const double v = dy * ocs[k] - dx * osn[k];
+                hk[k] = cand & (u <= c.shoot_far) & (fabs(v) * c.cos_hw <= u * c.sin_hw);
             }
             unsigned long long my_hb = 0ull;
 #pragma unroll
@@ -1082,7 +1207,7 @@ __global__ __launch_bounds__((NPW + 2) * FA_WAVE, MINW) void fa_step_pipe_kernel
 #pragma unroll
         for (int j = 0; j < N; ++j) { fmx[j] = s_fmx[j][lane]; fmy[j] = s_fmy[j][lane]; }
         const double wx = s_W[0][lane], wy = s_W[1][lane];
-        const double cs_n = s_trig[0][lane], sn_n = s_trig[1][lane]; // heading of step s+1 (survivor)
+        const double rpx = s_rp[0][lane], rpy = s_rp[1][lane];      // position after a reset
         const bool restage = ((s + 1) & (FA_ACT_BATCH - 1)) == 0;
         const int act_lds = s_act[(s + 1) & (FA_ACT_BATCH - 1)][lane];
         int act_next = restage ? av[0] : act_lds;
@@ -1090,7 +1215,7 @@ __global__ __launch_bounds__((NPW + 2) * FA_WAVE, MINW) void fa_step_pipe_kernel
             double Fx = u0 + 0.0, Fy = u1 + 0.0;
 #pragma unroll
             for (int j = 0; j < N; ++j)
-                if (j != i && ((grp_alive1 >> j) & 1ull)) {
+                if (!(FA_ABL & 64) && j != i && ((grp_alive1 >> j) & 1ull)) {
                     Fx = fmx[j] + Fx;
                     Fy = fmy[j] + Fy;
                 }
@@ -1111,6 +1236,10 @@ __global__ __launch_bounds__((NPW + 2) * FA_WAVE, MINW) void fa_step_pipe_kernel
             px += vx * c.dt;
             py += vy * c.dt;
         }
+        // (pinned here: selected after the barrier P, av[0] would still be live when the next batch
+        // is loaded and the loop would carry a copy of a pending load -- a vmcnt(0) every step;
+        // selected after the reset, its vmcnt(0) would wait for the reset's MT prefetch)
+        asm volatile("" : "+v"(act_next));
         FA_TICK(3)
         // ---- what the next state needs of the reward / done logic ------------------------------
         // (`dist_door < fort_dim` decided on the squared distance, see FaDerived::fort2_max; the
@@ -1130,34 +1259,25 @@ __global__ __launch_bounds__((NPW + 2) * FA_WAVE, MINW) void fa_step_pipe_kernel
         dirty = dirty || alive0;
         FA_TICK(4)
         // ---- fortattack_env_v1.py:47-75 reset_world (prevDist is NOT reset: quirk Q1) ----------
-        if (__ballot(do_reset) != 0ull) {
-            double npx = px, npy = py;
-            reset_agent(a, e, i, N, is_att, do_reset, mt_base, npx, npy);
-            if (do_reset) {
-                px = npx; py = npy; vx = 0.0; vy = 0.0;
-                ang = is_att ? c.ang_attacker : c.ang_guard;
-                alive = true;
-                t = 0;
-                nh = 0; nwh = 0;
-                dirty = true;
-                if (i == 0) reset_advance(a, e, mt_base);
-            }
+        // (the positions were drawn ahead by wave 1, see ResetDraw)
+        if (do_reset) {
+            px = rpx; py = rpy; vx = 0.0; vy = 0.0;
+            ang = is_att ? c.ang_attacker : c.ang_guard;
+            alive = true;
+            t = 0;
+            nh = 0; nwh = 0;
+            dirty = true;
         }
+        reset_prev = do_reset;
         FA_TICK(5)
-        // ---- publish state(s+1) and the by-products of step s ----------------------------------
+        // ---- publish state(s+1): what the helper waves need to start on step s+1 ----------------
         s_px[nb][lane] = px;
         s_py[nb][lane] = py;
         s_ang[nb][lane] = ang;
-        s_vx[nb][lane] = vx;
-        s_vy[nb][lane] = vy;
-        s_dd[nb][lane] = dd2;
         {
             const unsigned long long alive_b = __ballot(alive);
             if (lane == 0) {
                 s_mask[nb][0] = alive_b;
-                s_mask[nb][1] = alive1_b;
-                s_mask[nb][2] = hit_b;
-                s_mask[nb][3] = was_hit_b;
                 s_mask[nb][4] = done_b;
             }
         }
@@ -1165,23 +1285,42 @@ __global__ __launch_bounds__((NPW + 2) * FA_WAVE, MINW) void fa_step_pipe_kernel
 #pragma unroll
             for (int k = 0; k < FA_ACT_BATCH; ++k) s_act[k][lane] = av[k];
         }
-        // (pinned here: selected after the barrier, av[0] would still be live when the next batch
-        // is loaded and the loop would carry a copy of a pending load -- a vmcnt(0) every step)
-        asm volatile("" : "+v"(act_next));
+        // the by-products of step s are only read by the output wave after B2(s+1): they are written
+        // behind the barrier, while the helpers already work on step s+1 (last step: before it)
+        auto publish_byproducts = [&]() {
+            s_vx[nb][lane] = vx;
+            s_vy[nb][lane] = vy;
+            s_dd[nb][lane] = dd2;
+            if (lane == 0) {
+                s_mask[nb][1] = alive1_b;
+                s_mask[nb][2] = hit_b;
+                s_mask[nb][3] = was_hit_b;
+            }
+        };
+        const bool last = s + 1 == ns;
+        if (last) publish_byproducts();
         FA_TICK(6)
         FA_WG_BARRIER(); // P(s)
         FA_TICK(7)
+        if (!last) publish_byproducts();
         if (restage) {
 #pragma unroll
             for (int k = 0; k < FA_ACT_BATCH; ++k)
                 av[k] = (s + 1 + FA_ACT_BATCH + k < ns) ? (int)act_ptr[(int64_t)(s + 1 + FA_ACT_BATCH + k) * a.as_t] : 0;
         }
-        // sin/cos of the next heading: the last wave's for a survivor, the constant pair after a reset
-        cs = do_reset ? cs_r : cs_n;
-        sn = do_reset ? sn_r : sn_n;
+        // the opponents' positions for the next step (this wave's own writes: in order)
+#pragma unroll
+        for (int k = 0; k < KT; ++k) {
+            const int j = gbase + opp0 + (k < n_opp ? k : 0);
+            oqx[k] = s_px[nb][j];
+            oqy[k] = s_py[nb][j];
+        }
         act = act_next;
     }
     FA_TICK_FLUSH(0, 8, 28)
+#ifdef FA_TIMING
+    if (lane == 0) { atomicAdd(&g_dbg[20], clock64() - tk0); atomicAdd(&g_dbg[21], wall_clock64() - tw0); }
+#endif
 
     if (dirty) {
         a.s.px[idx] = px; a.s.py[idx] = py; a.s.vx[idx] = vx; a.s.vy[idx] = vy;

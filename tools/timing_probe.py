@@ -27,7 +27,7 @@ lib.fa_dbg_read(buf, 0)
 names = {0: "w0 decode + triangles", 1: "w0 laser + ballots", 2: "w0 wait B2", 3: "w0 force sum + integrate",
          4: "w0 door distance + done", 5: "w0 reset", 6: "w0 publish", 7: "w0 wait P",
          10: "out wait P", 11: "out pair forces", 12: "out wait B2", 13: "out rewards + stores",
-         16: "last wait P", 17: "last walls", 18: "last sin/cos", 19: "last wait B2"}
+         16: "last wait P", 17: "last walls", 18: "last wait B2", 19: "last sin/cos"}
 for lo, hi, cnt in ((0, 8, 28), (10, 14, 29), (16, 20, 30)):
     waves = max(buf[cnt], 1)
     tot = 0.0
@@ -36,3 +36,5 @@ for lo, hi, cnt in ((0, 8, 28), (10, 14, 29), (16, 20, 30)):
         tot += v
         print("%-28s %8.1f cycles/step" % (names[k], v))
     print("%-28s %8.1f cycles/step\n" % ("  total", tot))
+print("wave 0 loop: %.1f shader-clock ticks per step, %.1f ns per step (100 MHz wall clock) -> %.3f ticks/ns" % (
+    buf[20] / max(buf[28], 1) / T, buf[21] / max(buf[28], 1) / T * 10.0, buf[20] / max(buf[21], 1) / 10.0))
