@@ -186,11 +186,13 @@ def main():
     # same command (tools/profile_gpu.sh -> tools/summarize_prof.py; FETCH_SIZE x2 + WRITE_SIZE,
     # MI355X_MICROARCH.md); only attached when the run uses the profiled configuration.
     traffic, traffic_src = None, None
+    kernel_name = eng.step_variant(T // launches_per_rollout)   # which step kernel these launches ran
     prof = os.path.join(ROOT, "profiles", "r01_%s_summary.json" % ("fused" if graph is None else "perstep"))
     if (E, G, A, T) == (4096, 3, 3, 128) and os.path.isfile(prof):
         try:
             ks = json.load(open(prof))["kernels"]
-            k = [v for n, v in ks.items() if "fa_step_kernel<3, 3, false" in n and "hbm_bytes_per_launch" in v]
+            k = [v for n, v in ks.items() if n.split("<")[0].endswith(kernel_name.split("/")[0]) and "<3, 3," in n
+                 and "hbm_bytes_per_launch" in v]
             if k:
                 traffic, traffic_src = k[0]["hbm_bytes_per_launch"], os.path.relpath(prof, ROOT)
         except Exception:
@@ -215,8 +217,8 @@ def main():
                 "max_time_steps": 100, "rng": "mt19937 (reference-parity reset stream)",
                 "launch": args.launch, "parallelism": "env shards, %d rank(s)" % world},
             "roofline": {
-                "bound": "hbm", "kernel": "fa_step_kernel<%d,%d>" % (G if (G, A) in ((3, 3), (5, 5)) else 0,
-                                                                   A if (G, A) in ((3, 3), (5, 5)) else 0),
+                "bound": "hbm", "kernel": "%s<%d,%d>" % (kernel_name, G if (G, A) in ((3, 3), (5, 5)) else 0,
+                                                       A if (G, A) in ((3, 3), (5, 5)) else 0),
                 "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                 "traffic": traffic, "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": bytes_per_launch,

@@ -11,6 +11,7 @@
 
 hipError_t fa_launch_step(const FaStepArgs &a, hipStream_t st);
 hipError_t fa_launch_reset(const FaStepArgs &a, hipStream_t st);
+const char *fa_step_variant_name(int G, int A, int E, int nsteps);
 hipError_t fa_launch_seed(const FaState &s, int E, uint64_t base_seed, int64_t env_offset, int skip_words,
                           hipStream_t st);
 hipError_t fa_launch_selftest(unsigned long long n_per_thread, unsigned long long seed, unsigned long long *mismatch,
@@ -535,6 +536,11 @@ int fa_selftest_math(fa_env *env, uint64_t samples, uint64_t seed, uint64_t *mis
     FA_HIP(fa_launch_selftest(per, seed, d, nullptr));
     FA_HIP(hipMemcpy(mismatch_host, d, 24, hipMemcpyDeviceToHost));
     return FA_OK;
+}
+
+const char *fa_step_variant(fa_env *env, int32_t num_steps) {
+    if (!env) return "";
+    return fa_step_variant_name(env->cfg.num_guards, env->cfg.num_attackers, env->cfg.num_envs, num_steps);
 }
 
 int fa_rng_peek(fa_env *env, int32_t e, int32_t count, double *out_host) {

@@ -17,6 +17,8 @@
 #define FA_ACT_BATCH 16 // env-steps of actions staged in LDS per batch (power of two)
 #define FA_TWO_WAVE_MAX_GRID 1024  // workgroups up to which the two-wave step kernel is used
 #define FA_THREE_WAVE_MAX_GRID 680 // ... and the three-wave one (3 x 680 waves = 2 per SIMD)
+#define FA_PIPE_MAX_GRID 768       // pipelined kernel: 4 waves x 3 workgroups per CU x 256 CUs in one round
+#define FA_PIPE_MIN_STEPS 8        // ... and only for rollout launches
 
 // Host-derived constants (evaluated once in double, in the reference's expression order).
 struct FaDerived {

@@ -799,6 +799,7 @@ __global__ __launch_bounds__(NW * FA_WAVE) void fa_step_kernel(FaStepArgs a) {
 #endif
 #ifdef FA_TIMING
 __device__ unsigned long long g_dbg[32];
+__device__ unsigned g_hw[512];
 #define FA_TICK_INIT unsigned long long tacc[24] = {0}; unsigned long long tlast = clock64();
 #define FA_TICK(k) { const unsigned long long _n = clock64(); tacc[k] += _n - tlast; tlast = _n; }
 #define FA_TICK_FLUSH(lo, hi, cnt) if (lane == 0) { for (int k = lo; k < hi; ++k) atomicAdd(&g_dbg[k], tacc[k]); atomicAdd(&g_dbg[cnt], 1ull); }
@@ -825,6 +826,13 @@ __global__ __launch_bounds__((NPW + 2) * FA_WAVE, MINW) void fa_step_pipe_kernel
     constexpr unsigned long long grp_mask = (1ull << N) - 1ull;
     const FaDerived &c = a.c;
     const int ns = a.nsteps;
+#ifdef FA_TIMING
+    if (lane == 0 && blockIdx.x < 64) { // where the hardware put this wave (HW_ID: simd [5:4], cu [11:8], se [15:13])
+        unsigned hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        g_hw[blockIdx.x * 8 + wave_id] = hw | 0x80000000u;
+    }
+#endif
 
     // buffer s & 1: state at the start of step s (+ by-products of step s-1)
     __shared__ double s_px[2][FA_WAVE], s_py[2][FA_WAVE], s_ang[2][FA_WAVE];
@@ -832,6 +840,7 @@ __global__ __launch_bounds__((NPW + 2) * FA_WAVE, MINW) void fa_step_pipe_kernel
     __shared__ unsigned long long s_mask[2][8]; // ballots: 0 alive, 1 alive after laser, 2 hit, 3 was hit, 4 done
     __shared__ double s_trig[2][2][FA_WAVE]; // [step parity][cos, sin][lane]: heading of the step's start state
     __shared__ double s_W[2][FA_WAVE];
+    __shared__ double s_U[3][FA_WAVE]; // decoded action of the step: accel*u + 0.0 (x, y), rotation
     __shared__ double s_fmx[N][FA_WAVE], s_fmy[N][FA_WAVE]; // [partner j][lane]: pair force on the lane's agent
     __shared__ int s_act[FA_ACT_BATCH][FA_WAVE];
     __shared__ double s_rp[2][FA_WAVE]; // positions of the lane's next reset (drawn ahead by wave 1)
@@ -847,6 +856,17 @@ __global__ __launch_bounds__((NPW + 2) * FA_WAVE, MINW) void fa_step_pipe_kernel
             const double ang = s_ang[b][lane];
             const bool alive0 = (s_mask[b][0] >> lane) & 1ull;
             const double px = s_px[b][lane], py = s_py[b][lane];
+            // fortattack.py:253-263,:289 _set_action, for wave 0 (F starts as u + 0.0, core.py:221-228)
+            double u0 = 0.0, u1 = 0.0, rot = 0.0;
+            if (act == 1) u0 = +1.0;
+            if (act == 2) u0 = -1.0;
+            if (act == 3) u1 = +1.0;
+            if (act == 4) u1 = -1.0;
+            if (act == 5) rot = c.rot_pos;
+            if (act == 6) rot = c.rot_neg;
+            s_U[0][lane] = u0 * c.accel + 0.0;
+            s_U[1][lane] = u1 * c.accel + 0.0;
+            s_U[2][lane] = rot;
             double wx = 0.0, wy = 0.0;
             if (!(FA_ABL & 16) && alive0) { // core.py:246-252 + :459-472; exactly +0.0 off the walls
                 const double k = c.contact_margin, size = c.agent_size;
@@ -870,9 +890,6 @@ __global__ __launch_bounds__((NPW + 2) * FA_WAVE, MINW) void fa_step_pipe_kernel
             FA_WG_BARRIER(); // B2(s)
             FA_TICK(18)
             if (!(FA_ABL & 32) && s + 1 < ns) {
-                double rot = 0.0;
-                if (act == 5) rot = c.rot_pos;
-                if (act == 6) rot = c.rot_neg;
                 double sn, cs;
                 sincos_heading(ang + rot, sn, cs); // == wave 0's `ang += rot` for a survivor
                 s_trig[(s + 1) & 1][0][lane] = cs;
@@ -1131,6 +1148,8 @@ __global__ __launch_bounds__((NPW + 2) * FA_WAVE, MINW) void fa_step_pipe_kernel
         ocs[k] = s_trig[0][0][j]; osn[k] = s_trig[0][1][j];
     }
     bool reset_prev = false;
+    s_fmx[i][lane] = 0.0; // an agent exerts no force on itself: the pair waves never write the diagonal
+    s_fmy[i][lane] = 0.0;
     FA_WG_BARRIER(); // P(-1)
 #ifdef FA_TIMING
     const unsigned long long tk0 = clock64(), tw0 = wall_clock64();
@@ -1140,26 +1159,23 @@ __global__ __launch_bounds__((NPW + 2) * FA_WAVE, MINW) void fa_step_pipe_kernel
     for (int s = 0; s < ns; ++s) {
         const int nb = (s + 1) & 1;
         const bool alive0 = alive;
-        // ---- fortattack.py:253-263,:289 _set_action ----------------------------------------
-        double u0 = 0.0, u1 = 0.0, rot = 0.0;
-        if (act == 1) u0 = +1.0;
-        if (act == 2) u0 = -1.0;
-        if (act == 3) u1 = +1.0;
-        if (act == 4) u1 = -1.0;
-        if (act == 5) rot = c.rot_pos;
-        if (act == 6) rot = c.rot_neg;
+        // (the action is decoded by the last wave, fortattack.py:253-263; only `shoot` is needed here)
         const bool shoot = act == 7;
-        u0 *= c.accel;
-        u1 *= c.accel;
         const bool shooter = alive0 && shoot;
         const unsigned long long shooters_b = __ballot(shooter);
         if (s > 0) { // sin/cos of the opponents' headings: the last wave's, constants after a reset
 #pragma unroll
             for (int k = 0; k < KT; ++k) {
                 const int j = gbase + opp0 + (k < n_opp ? k : 0);
-                const double cn = s_trig[s & 1][0][j], sn_ = s_trig[s & 1][1][j];
-                ocs[k] = reset_prev ? cs_ro : cn;
-                osn[k] = reset_prev ? sn_ro : sn_;
+                ocs[k] = s_trig[s & 1][0][j];
+                osn[k] = s_trig[s & 1][1][j];
+            }
+            if (__ballot(reset_prev) != 0ull) {
+#pragma unroll
+                for (int k = 0; k < KT; ++k) {
+                    ocs[k] = reset_prev ? cs_ro : ocs[k];
+                    osn[k] = reset_prev ? sn_ro : osn[k];
+                }
             }
         }
         FA_TICK(0)
@@ -1207,17 +1223,21 @@ __global__ __launch_bounds__((NPW + 2) * FA_WAVE, MINW) void fa_step_pipe_kernel
 #pragma unroll
         for (int j = 0; j < N; ++j) { fmx[j] = s_fmx[j][lane]; fmy[j] = s_fmy[j][lane]; }
         const double wx = s_W[0][lane], wy = s_W[1][lane];
-        const double rpx = s_rp[0][lane], rpy = s_rp[1][lane];      // position after a reset
+        const double u0 = s_U[0][lane], u1 = s_U[1][lane], rot = s_U[2][lane];
         const bool restage = ((s + 1) & (FA_ACT_BATCH - 1)) == 0;
         const int act_lds = s_act[(s + 1) & (FA_ACT_BATCH - 1)][lane];
         int act_next = restage ? av[0] : act_lds;
         if (alive1) {
-            double Fx = u0 + 0.0, Fy = u1 + 0.0;
+            // masked by the survivors with one FMA per term: fma(f, 1, F) == f + F and fma(f, 0, F) == F
+            // bit for bit (F is never -0.0; f is finite unless two agents coincide exactly)
+            double Fx = u0, Fy = u1;
+            const unsigned ga1 = (unsigned)grp_alive1;
 #pragma unroll
             for (int j = 0; j < N; ++j)
-                if (!(FA_ABL & 64) && j != i && ((grp_alive1 >> j) & 1ull)) {
-                    Fx = fmx[j] + Fx;
-                    Fy = fmy[j] + Fy;
+                if (!(FA_ABL & 64)) {
+                    const double m = (double)((ga1 >> j) & 1u);
+                    Fx = __fma_rn(fmx[j], m, Fx);
+                    Fy = __fma_rn(fmy[j], m, Fy);
                 }
             Fx = wx + Fx;
             Fy = wy + Fy;
@@ -1260,13 +1280,16 @@ __global__ __launch_bounds__((NPW + 2) * FA_WAVE, MINW) void fa_step_pipe_kernel
         FA_TICK(4)
         // ---- fortattack_env_v1.py:47-75 reset_world (prevDist is NOT reset: quirk Q1) ----------
         // (the positions were drawn ahead by wave 1, see ResetDraw)
-        if (do_reset) {
-            px = rpx; py = rpy; vx = 0.0; vy = 0.0;
-            ang = is_att ? c.ang_attacker : c.ang_guard;
-            alive = true;
-            t = 0;
-            nh = 0; nwh = 0;
-            dirty = true;
+        if (done_b != 0ull && a.auto_reset != 0) { // wave-uniform: most steps reset no env of the wave
+            const double rpx = s_rp[0][lane], rpy = s_rp[1][lane];
+            if (do_reset) {
+                px = rpx; py = rpy; vx = 0.0; vy = 0.0;
+                ang = is_att ? c.ang_attacker : c.ang_guard;
+                alive = true;
+                t = 0;
+                nh = 0; nwh = 0;
+                dirty = true;
+            }
         }
         reset_prev = do_reset;
         FA_TICK(5)
@@ -1337,6 +1360,7 @@ extern "C" int fa_dbg_read(unsigned long long *out, int reset) {
     if (reset) { unsigned long long z[32] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_dbg), z, sizeof(z)); }
     return 0;
 }
+extern "C" int fa_dbg_hw(unsigned *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_hw), sizeof(unsigned) * 512); }
 #endif
 
 // ---- np.random.seed(int): init_genrand, then discard the construction draws ----------
@@ -1360,27 +1384,54 @@ __global__ void fa_seed_kernel(FaState s, int E, uint64_t base_seed, int64_t env
 }
 
 // ---- launchers --------------------------------------------------------------------------
+// which step kernel a launch of `nsteps` env-steps uses: 0 = pipelined, 1/2/3 = fa_step_kernel
+// with that many cooperating waves
+static int step_variant(int G, int A, int E, int nsteps, bool reset_only) {
+    const int epw = FA_WAVE / (G + A);
+    const int grid = (E + epw - 1) / epw;
+    static const char *force = getenv("FA_STEP_KERNEL");
+    const bool sized = (G == 3 && A == 3) || (G == 5 && A == 5);
+    if (reset_only || !sized) return 1;
+    bool pipe = nsteps >= FA_PIPE_MIN_STEPS && grid <= FA_PIPE_MAX_GRID;
+    if (force) pipe = force[0] == 'p';
+    if (pipe) return 0;
+    return grid <= FA_THREE_WAVE_MAX_GRID ? 3 : (grid <= FA_TWO_WAVE_MAX_GRID ? 2 : 1);
+}
+const char *fa_step_variant_name(int G, int A, int E, int nsteps) {
+    switch (step_variant(G, A, E, nsteps, false)) {
+    case 0: return "fa_step_pipe_kernel";
+    case 3: return "fa_step_kernel/3 waves";
+    case 2: return "fa_step_kernel/2 waves";
+    default: return "fa_step_kernel/1 wave";
+    }
+}
+
 template <bool RESET_ONLY, bool COLLECT>
 static hipError_t launch_step_t(const FaStepArgs &a, hipStream_t st) {
     const int N = a.G + a.A;
     const int epw = FA_WAVE / N;
     const int grid = (a.E + epw - 1) / epw;
-    // two cooperating waves per workgroup while that still leaves at most ~2 waves per SIMD
-    // (latency regime); beyond, one wave per workgroup uses the SIMDs better
-    // cooperating waves per workgroup while the launch is in the latency regime
-    static const int max3 = getenv("FA_MAX3") ? atoi(getenv("FA_MAX3")) : FA_THREE_WAVE_MAX_GRID;
-    const int nw = RESET_ONLY ? 1 : (grid <= max3 ? 3 : (grid <= FA_TWO_WAVE_MAX_GRID ? 2 : 1));
+    // Latency regime (few workgroups per CU): cooperating waves per workgroup.  Rollout launches of
+    // compile-time team sizes that fit the GPU in one round of 3 workgroups per CU use the
+    // pipelined kernel; short launches (its prologue draws two resets ahead and evaluates three
+    // sin/cos) and everything else use fa_step_kernel with 3 / 2 / 1 waves by grid size.
+    // FA_STEP_KERNEL=classic|pipe overrides the choice (experiments).
+    const int nw = step_variant(a.G, a.A, a.E, a.nsteps, RESET_ONLY);
+    const bool pipe = nw == 0;
 #define FA_LAUNCH(TG_, TA_, NW_) \
     hipLaunchKernelGGL((fa_step_kernel<TG_, TA_, RESET_ONLY, COLLECT, RESET_ONLY ? 1 : NW_>), dim3(grid), \
                        dim3((RESET_ONLY ? 1 : NW_) * FA_WAVE), 0, st, a)
 #define FA_LAUNCH_PIPE(TG_, TA_, NPW_, MINW_) \
     hipLaunchKernelGGL((fa_step_pipe_kernel<TG_, TA_, COLLECT, NPW_, MINW_>), dim3(grid), dim3((NPW_ + 2) * FA_WAVE), 0, st, a)
-    static const int pipe_mode = getenv("FA_PIPE") ? atoi(getenv("FA_PIPE")) : 2;
     if (a.G == 3 && a.A == 3) {
-        if (nw == 3 && pipe_mode == 1) FA_LAUNCH_PIPE(3, 3, 1, 2); else if (nw == 3 && pipe_mode == 2) FA_LAUNCH_PIPE(3, 3, 2, 2); else if (nw == 3 && pipe_mode == 3) FA_LAUNCH_PIPE(3, 3, 3, 3); else if (nw == 3 && pipe_mode == 4) FA_LAUNCH_PIPE(3, 3, 3, 4);
+#ifdef FA_EXP_NPW
+        if (pipe) FA_LAUNCH_PIPE(3, 3, FA_EXP_NPW, FA_EXP_MINW);
+#else
+        if (pipe) FA_LAUNCH_PIPE(3, 3, 2, 2);
+#endif
         else if (nw == 3) FA_LAUNCH(3, 3, 3); else if (nw == 2) FA_LAUNCH(3, 3, 2); else FA_LAUNCH(3, 3, 1);
     } else if (a.G == 5 && a.A == 5) {
-        if (nw == 3 && pipe_mode == 1) FA_LAUNCH_PIPE(5, 5, 1, 3); else if (nw == 3 && pipe_mode == 2) FA_LAUNCH_PIPE(5, 5, 2, 3); else if (nw == 3 && pipe_mode == 3) FA_LAUNCH_PIPE(5, 5, 3, 4); else if (nw == 3 && pipe_mode == 5) FA_LAUNCH_PIPE(5, 5, 5, 2);
+        if (pipe) FA_LAUNCH_PIPE(5, 5, 2, 3);
         else if (nw == 3) FA_LAUNCH(5, 5, 3); else if (nw == 2) FA_LAUNCH(5, 5, 2); else FA_LAUNCH(5, 5, 1);
     } else {
         FA_LAUNCH(0, 0, 1);

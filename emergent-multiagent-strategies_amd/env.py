@@ -106,6 +106,26 @@ class BatchedFortAttack(object):
         _lib.check(self._lib.fa_step(self._h, C.byref(io), _stream()), "fa_step")
         return out
 
+    def step_many(self, actions, auto_reset=True, want=("obs_f32", "reward_f32", "mask_f32", "done")):
+        """fa_step with fa_step_io.num_steps = T: T env-steps in ONE launch, open loop.  actions: int64
+        device tensor (T, E, N) (any strides); every output gets a leading T dimension."""
+        assert actions.dtype == torch.int64 and actions.is_cuda and tuple(actions.shape[1:]) == (self.E, self.N)
+        T = actions.shape[0]
+        shapes = dict(obs_f32=((T, self.E, self.N, 6), torch.float32), reward_f32=((T, self.E, self.N), torch.float32),
+                      mask_f32=((T, self.E, self.N), torch.float32), done=((T, self.E), torch.uint8),
+                      obs_f64=((T, self.E, self.N, 6), torch.float64), reward_f64=((T, self.E, self.N), torch.float64),
+                      hit=((T, self.E, self.N), torch.uint8), was_hit=((T, self.E, self.N), torch.uint8))
+        out = {k: self._new(*shapes[k]) for k in want}
+        io = _lib.StepIO()
+        io.actions = _ptr(actions)
+        io.act_stride_step, io.act_stride_env, io.act_stride_agent = actions.stride(0), actions.stride(1), actions.stride(2)
+        for k in shapes:
+            setattr(io, k, _ptr(out.get(k)))
+        io.auto_reset = int(bool(auto_reset))
+        io.num_steps = T
+        _lib.check(self._lib.fa_step(self._h, C.byref(io), _stream()), "fa_step")
+        return out
+
     # -- collector -------------------------------------------------------------------
     def bind_storage(self, storage):
         """Attach a JointRolloutStorage (storage.py) -- fa_bind_storage."""
@@ -229,6 +249,10 @@ class BatchedFortAttack(object):
         _lib.check(self._lib.fa_selftest_math(self._h, int(samples), int(seed), out.ctypes.data_as(C.c_void_p)),
                    "fa_selftest_math")
         return int(out[0]), int(out[1]), float(out[2]) / 1000.0
+
+    def step_variant(self, num_steps=1):
+        """fa_step_variant: name of the step kernel a launch of `num_steps` env-steps uses."""
+        return self._lib.fa_step_variant(self._h, int(num_steps)).decode()
 
     def rng_peek(self, e, count):
         out = np.empty(count, np.float64)

@@ -215,6 +215,9 @@ int fa_set_state(fa_env *env, const fa_state_host *in); /* pos/vel/ang/prev_dist
  * [2] = largest deviation of the heading sin/cos from the device libm, in 1/1000 ulp
  * (mismatch_host holds 3 values). */
 int fa_selftest_math(fa_env *env, uint64_t samples, uint64_t seed, uint64_t *mismatch_host);
+/* Name of the step kernel variant a fa_step / fa_collect_rollout launch of `num_steps` env-steps
+ * uses on this env (reporting only: bench.py labels its roofline line with it). */
+const char *fa_step_variant(fa_env *env, int32_t num_steps);
 /* next `count` random_sample() doubles env e would draw (does not advance the stream) */
 int fa_rng_peek(fa_env *env, int32_t e, int32_t count, double *out_host);
 

@@ -147,6 +147,54 @@ def test_env_vs_oracle_random(fa, G, A, E, T, max_t):
     assert worst <= FLOAT_TOL
 
 
+@pytest.mark.parametrize("G,A,E,T,max_t", [(3, 3, 333, 96, 30), (5, 5, 100, 64, 25),
+                                           (3, 3, 41, 40, 1),      # every step ends an episode: a reset draw per step
+                                           (5, 5, 13, 33, 2),
+                                           (3, 3, 1, 50, 9),       # one env, 54 idle lanes
+                                           (4, 2, 60, 24, 10)])    # run-time team sizes: the generic kernel
+def test_fused_launch_vs_oracle(fa, G, A, E, T, max_t):
+    """T env-steps in ONE fa_step launch (3v3 / 5v5: the pipelined multi-wave kernel, whose helper
+    waves draw resets ahead, emit the rows one step late and test the laser in the shooter's frame)
+    against the CPU oracle stepped T times: flags bit-exact, fp64 values within FLOAT_TOL, and the
+    world + RNG state after the launch."""
+    from fa_oracle import OracleEnv
+    N = G + A
+    rng = np.random.RandomState(7 * G + A)
+    orc = OracleEnv(E, G, A, max_t, base_seed=2024)
+    eng = fa.BatchedFortAttack(E, G, A, max_t, base_seed=2024)
+    if (G, A) in ((3, 3), (5, 5)):
+        assert eng.step_variant(T) == "fa_step_pipe_kernel"
+    o0 = torch.empty((E, N, 6), dtype=torch.float64, device="cuda")
+    eng.reset(obs_f64=o0)
+    assert np.array_equal(o0.cpu().numpy(), orc.reset())
+    acts = rng.randint(0, 8, size=(T, E, N))
+    acts = np.where(rng.rand(T, E, N) < 0.25, 7, acts)
+    out = {k: v.cpu().numpy() for k, v in eng.step_many(
+        _dev(acts, torch.int64), auto_reset=True,
+        want=("obs_f64", "reward_f64", "mask_f32", "done", "hit", "was_hit", "obs_f32", "reward_f32")).items()}
+    worst, ends = 0.0, 0
+    for t in range(T):
+        ref = orc.step(acts[t], auto_reset=True)
+        assert np.array_equal(out["done"][t], ref["done"]), t
+        want_mask = np.where(ref["done"][:, None] != 0, 1, ref["alive_before"]).astype(np.float32)
+        assert np.array_equal(out["mask_f32"][t], want_mask), t
+        assert np.array_equal(out["hit"][t], ref["hit"]), t
+        assert np.array_equal(out["was_hit"][t], ref["was_hit"]), t
+        assert np.array_equal(out["obs_f64"][t][:, :, 0], ref["obs"][:, :, 0]), t
+        worst = max(worst, np.abs(out["obs_f64"][t] - ref["obs"]).max(), np.abs(out["reward_f64"][t] - ref["reward"]).max())
+        assert np.array_equal(out["obs_f32"][t], out["obs_f64"][t].astype(np.float32)), t
+        assert np.array_equal(out["reward_f32"][t], out["reward_f64"][t].astype(np.float32)), t
+        ends += int(ref["done"].sum())
+    assert ends > 0 and worst <= FLOAT_TOL
+    so, sg = orc.get_state(), eng.get_state()
+    for k in ("alive", "time_step", "num_hit", "num_was_hit"):
+        assert np.array_equal(so[k], sg[k]), k
+    for k in ("pos_x", "pos_y", "vel_x", "vel_y", "ang"):
+        assert np.abs(so[k] - sg[k]).max() <= FLOAT_TOL, k
+    # the reset stream is where the oracle's is: the next reset draws the same positions
+    assert np.array_equal(eng.rng_peek(E - 1, 2 * N), orc.rng_doubles(E - 1, 2 * N))
+
+
 def test_shards_equal_one_big_batch(fa):
     """Multi-GPU sharding by env_offset: two half handles == one full handle, bit for bit."""
     E, G, A, T = 512, 3, 3, 80

@@ -38,3 +38,13 @@ for lo, hi, cnt in ((0, 8, 28), (10, 14, 29), (16, 20, 30)):
     print("%-28s %8.1f cycles/step\n" % ("  total", tot))
 print("wave 0 loop: %.1f shader-clock ticks per step, %.1f ns per step (100 MHz wall clock) -> %.3f ticks/ns" % (
     buf[20] / max(buf[28], 1) / T, buf[21] / max(buf[28], 1) / T * 10.0, buf[20] / max(buf[21], 1) / 10.0))
+hw = (C.c_uint * 512)()
+lib.fa_dbg_hw(hw)
+print("wave placement (workgroup: wave->simd@cu.se):")
+for b in list(range(6)) + list(range(58, 64)):
+    row = []
+    for w in range(8):
+        v = hw[b * 8 + w]
+        if v & 0x80000000:
+            row.append("w%d->simd%d@cu%d.se%d" % (w, (v >> 4) & 3, (v >> 8) & 15, (v >> 13) & 7))
+    print("  wg %3d: %s" % (b, "  ".join(row)))
