@@ -1155,6 +1155,15 @@ __global__ __launch_bounds__((NPW + 2) * FA_WAVE, MINW) void fa_step_pipe_kernel
     const unsigned long long tk0 = clock64(), tw0 = wall_clock64();
 #endif
 
+    // The loop's fp64 constants live in VGPRs: as SGPR pairs they (with the lane masks and the
+    // write-back pointers) overflow the scalar file, and every spilled SGPR costs the lone wave a
+    // v_readlane issue slot per use.
+    double k_size = c.agent_size, k_far = c.shoot_far, k_chw = c.cos_hw, k_shw = c.sin_hw;
+    double k_damp = c.one_minus_damping, k_dt = c.dt, k_sp2 = c.speed2_max, k_vmax = c.max_speed;
+    double k_doorx = c.door_x, k_doory = c.door_y, k_fort2 = c.fort2_max;
+    double k_ang_r = is_att ? c.ang_attacker : c.ang_guard;
+    asm volatile("" : "+v"(k_size), "+v"(k_far), "+v"(k_chw), "+v"(k_shw), "+v"(k_damp), "+v"(k_dt));
+    asm volatile("" : "+v"(k_sp2), "+v"(k_vmax), "+v"(k_doorx), "+v"(k_doory), "+v"(k_fort2), "+v"(k_ang_r));
     FA_TICK_INIT
     for (int s = 0; s < ns; ++s) {
         const int nb = (s + 1) & 1;
@@ -1191,17 +1200,19 @@ __global__ __launch_bounds__((NPW + 2) * FA_WAVE, MINW) void fa_step_pipe_kernel
             for (int k = 0; k < KT; ++k) {
                 const int j = gbase + opp0 + k;
                 const bool cand = alive0 && k < n_opp && ((shooters_b >> j) & 1ull);
-                const double ax = oqx[k] + c.agent_size * ocs[k], ay = oqy[k] + c.agent_size * osn[k];
+                const double ax = oqx[k] + k_size * ocs[k], ay = oqy[k] + k_size * osn[k];
                 const double dx = px - ax, dy = py - ay;
                 const double u = dx * ocs[k] + dy * osn[k];
                 const double v = dy * ocs[k] - dx * osn[k];
-                hk[k] = cand & (u <= c.shoot_far) & (fabs(v) * c.cos_hw <= u * c.sin_hw);
+                hk[k] = cand & (u <= k_far) & (fabs(v) * k_chw <= u * k_shw);
             }
             unsigned long long my_hb = 0ull;
+            int tix = team_idx;
+            asm volatile("" : "+v"(tix)); // compare in the loop: KT hoisted lane masks cost 2 SGPRs each
 #pragma unroll
             for (int k = 0; k < KT; ++k) {
                 const unsigned long long hb = __ballot(hk[k]);
-                my_hb = (k == team_idx) ? hb : my_hb;
+                my_hb = (k == tix) ? hb : my_hb;
                 was_hit = was_hit | hk[k];
                 was_hit_cnt += hk[k] ? 1 : 0;
             }
@@ -1242,19 +1253,19 @@ __global__ __launch_bounds__((NPW + 2) * FA_WAVE, MINW) void fa_step_pipe_kernel
             Fx = wx + Fx;
             Fy = wy + Fy;
             // core.py:324-338 integrate_state (mass == 1.0: F/1.0 is exact)
-            vx = vx * c.one_minus_damping;
-            vy = vy * c.one_minus_damping;
-            vx += Fx * c.dt;
-            vy += Fy * c.dt;
+            vx = vx * k_damp;
+            vy = vy * k_damp;
+            vx += Fx * k_dt;
+            vy += Fy * k_dt;
             const double speed2 = vx * vx + vy * vy;
-            if (speed2 > c.speed2_max) { // == sqrt(v.v) > max_speed, see fa_step_kernel
+            if (speed2 > k_sp2) { // == sqrt(v.v) > max_speed, see fa_step_kernel
                 const double speed = sqrt_rn(speed2);
-                vx = div_rn(vx, speed) * c.max_speed;
-                vy = div_rn(vy, speed) * c.max_speed;
+                vx = div_rn(vx, speed) * k_vmax;
+                vy = div_rn(vy, speed) * k_vmax;
             }
             ang += rot;
-            px += vx * c.dt;
-            py += vy * c.dt;
+            px += vx * k_dt;
+            py += vy * k_dt;
         }
         // (pinned here: selected after the barrier P, av[0] would still be live when the next batch
         // is loaded and the loop would carry a copy of a pending load -- a vmcnt(0) every step;
@@ -1264,9 +1275,9 @@ __global__ __launch_bounds__((NPW + 2) * FA_WAVE, MINW) void fa_step_pipe_kernel
         // ---- what the next state needs of the reward / done logic ------------------------------
         // (`dist_door < fort_dim` decided on the squared distance, see FaDerived::fort2_max; the
         // square root itself is only needed by the rewards and is taken by the output wave)
-        const double ddx = px - c.door_x, ddy = py - c.door_y;
+        const double ddx = px - k_doorx, ddy = py - k_doory;
         const double dd2 = ddx * ddx + ddy * ddy;
-        const unsigned long long in_fort_b = __ballot(is_att && alive1 && dd2 <= c.fort2_max);
+        const unsigned long long in_fort_b = __ballot(is_att && alive1 && dd2 <= k_fort2);
         const bool any_in_fort = ((in_fort_b >> gbase) & grp_mask) != 0ull;
         const bool timeout = t == a.max_t - 1;
         const bool done = any_in_fort || n_alive_att == 0 || timeout; // fortattack.py:202-225
@@ -1284,7 +1295,7 @@ __global__ __launch_bounds__((NPW + 2) * FA_WAVE, MINW) void fa_step_pipe_kernel
             const double rpx = s_rp[0][lane], rpy = s_rp[1][lane];
             if (do_reset) {
                 px = rpx; py = rpy; vx = 0.0; vy = 0.0;
-                ang = is_att ? c.ang_attacker : c.ang_guard;
+                ang = k_ang_r;
                 alive = true;
                 t = 0;
                 nh = 0; nwh = 0;
