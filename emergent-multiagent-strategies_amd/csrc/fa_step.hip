@@ -904,9 +904,11 @@ __global__ __launch_bounds__((NPW + 2) * FA_WAVE, MINW) void fa_step_pipe_kernel
     if (wave_id >= 1) {
         // ---- pair waves: soft contact (core.py:231-243, :440-456), once per unordered pair; the
         // last of them also emits the rewards and rollout rows of the previous step ---------------
-        const bool out_wave = wave_id == NPW;
+        // the rows of a finished step are emitted by two waves: rewards / masks / done and the
+        // episode bookkeeping by wave 1, the observation rows by the last pair wave
+        const bool rew_wave = wave_id == 1, out_wave = wave_id == NPW;
         double prev = 0.0, ep_rew = 0.0;
-        if (out_wave) {
+        if (rew_wave) {
             prev = a.s.prev[idx];
             if (a.track_counters) ep_rew = a.s.ep_rew[idx];
             // complete the loads here: first used inside the loop, they would put a vmcnt(0) --
@@ -915,21 +917,27 @@ __global__ __launch_bounds__((NPW + 2) * FA_WAVE, MINW) void fa_step_pipe_kernel
         }
         int act_prev = 0;
         bool alive0_prev = false;
-        // step `so` finished: buffer bo holds state(so+1) and the by-products of step so
-        auto emit = [&](int so, int bo) {
+        // the output rows are walked with per-lane pointers and the reward constants sit in VGPRs:
+        // base pointers, strides and fp64 literals as SGPRs overflow the scalar file (see wave 0)
+        float *p_rew = a.rew32 ? a.rew32 + idx : nullptr, *p_mask = a.mask32 ? a.mask32 + idx : nullptr;
+        uint8_t *p_done = a.done ? a.done + e : nullptr;
+        long long row = (long long)idx; // row of the step being emitted in the optional (E, N) outputs
+        double k_fort = c.fort_dim, k_03 = 0.3, k_10 = 10.0, k_3 = 3.0, k_01 = 0.1;
+        asm volatile("" : "+v"(p_rew), "+v"(p_mask), "+v"(p_done), "+v"(row));
+        asm volatile("" : "+v"(k_fort), "+v"(k_03), "+v"(k_10), "+v"(k_3), "+v"(k_01));
+        // a step finished: buffer bo holds the state after it and its by-products
+        // (called once per step, in order)
+        auto emit_rew = [&](int bo) {
             const unsigned long long m1 = s_mask[bo][1];
-            const bool alive_new = (s_mask[bo][0] >> lane) & 1ull;
             const bool alive1 = (m1 >> lane) & 1ull;
             const bool hit = (s_mask[bo][2] >> lane) & 1ull;
             const bool was_hit = (s_mask[bo][3] >> lane) & 1ull;
             const bool done = (s_mask[bo][4] >> lane) & 1ull;
-            const double px = s_px[bo][lane], py = s_py[bo][lane], ang = s_ang[bo][lane];
-            const double vx = s_vx[bo][lane], vy = s_vy[bo][lane];
             const double dist_door = sqrt_rn(s_dd[bo][lane]);
             const bool alive0 = alive0_prev;
             const bool shoot = act_prev == 7;
             const int n_alive_att = __popcll(((m1 >> gbase) & grp_mask) >> G);
-            const unsigned long long in_fort_b = __ballot(is_att && alive1 && dist_door < c.fort_dim);
+            const unsigned long long in_fort_b = __ballot(is_att && alive1 && dist_door < k_fort);
             const bool any_in_fort = ((in_fort_b >> gbase) & grp_mask) != 0ull;
             const bool do_reset = done && a.auto_reset != 0;
             // ---- rewards (fortattack_env_v1.py:87-188), after World.step ----------------------
@@ -940,14 +948,14 @@ __global__ __launch_bounds__((NPW + 2) * FA_WAVE, MINW) void fa_step_pipe_kernel
             const bool just_died = alive0 && was_hit;
             const bool rewarded = (alive1 || just_died);
             const bool has_prev = !(prev != prev); // NaN encodes prevDist None
-            const double g0 = ((dist_door > 0.3) & (prev <= 0.3)) ? -1.0 : (((dist_door <= 0.3) & (prev > 0.3)) ? 1.0 : 0.0);
+            const double g0 = ((dist_door > k_03) & (prev <= k_03)) ? -1.0 : (((dist_door <= k_03) & (prev > k_03)) ? 1.0 : 0.0);
             const double t0 = has_prev ? (is_att ? 2 * (prev - dist_door) : g0) : 0.0;
-            const bool c1 = is_att ? (dist_door < c.fort_dim) : ((n_alive_att != 0) & any_in_fort);
-            const double t1 = c1 ? (is_att ? 10.0 : -10.0) : 0.0;
-            const double t2 = shoot ? (is_att ? -1.0 : -0.1) : 0.0;
-            const double t3 = hit ? 3.0 : 0.0;
-            const double t4 = was_hit ? -3.0 : 0.0;
-            const double t5 = (n_alive_att == 0) ? (is_att ? -10.0 : 10.0) : 0.0;
+            const bool c1 = is_att ? (dist_door < k_fort) : ((n_alive_att != 0) & any_in_fort);
+            const double t1 = c1 ? (is_att ? k_10 : -k_10) : 0.0;
+            const double t2 = shoot ? (is_att ? -1.0 : -k_01) : 0.0;
+            const double t3 = hit ? k_3 : 0.0;
+            const double t4 = was_hit ? -k_3 : 0.0;
+            const double t5 = (n_alive_att == 0) ? (is_att ? -k_10 : k_10) : 0.0;
             const double rew = rewarded ? (t0 + t1 + t2 + t3 + t4 + t5) : 0.0;
             prev = rewarded ? dist_door : prev;
             // ---- fortattack.py:202-225 _get_done bookkeeping --------------------------------------
@@ -958,7 +966,7 @@ __global__ __launch_bounds__((NPW + 2) * FA_WAVE, MINW) void fa_step_pipe_kernel
                     gr[0] = which == 0; gr[1] = which == 1; gr[2] = which == 2;
                     atomicAdd(a.s.result_count + (size_t)e * 3 + which, 1u);
                 }
-                if (COLLECT || a.done) a.done[(size_t)so * a.E + e] = done ? 1 : 0;
+                if (COLLECT || a.done) *p_done = done ? 1 : 0;
             }
             // evaluation statistics (test_fortattack_v2.py:88-101)
             if (a.track_counters) {
@@ -969,35 +977,43 @@ __global__ __launch_bounds__((NPW + 2) * FA_WAVE, MINW) void fa_step_pipe_kernel
                     ep_rew = 0.0;
                 }
             }
-            const size_t o = (size_t)so * EN + idx;
             // trainer mask (train_fortattack.py:53,87): alive BEFORE the step; an env that is
             // reset here gets the post-reset mask 1 (initialize_new_episode, rlagent.py:31)
             const float mk = (alive0 || do_reset) ? 1.0f : 0.0f;
             if (COLLECT) {
-                a.rew32[o] = (float)rew;
-                a.mask32[o] = mk;
+                *p_rew = (float)rew;
+                *p_mask = mk;
             } else {
-                if (a.rew32) a.rew32[o] = (float)rew;
-                if (a.rew64) a.rew64[o] = rew;
-                if (a.mask32) a.mask32[o] = mk;
-                if (a.hit) a.hit[o] = hit ? 1 : 0;
-                if (a.was_hit) a.was_hit[o] = was_hit ? 1 : 0;
+                if (a.rew32) *p_rew = (float)rew;
+                if (a.rew64) a.rew64[row] = rew;
+                if (a.mask32) *p_mask = mk;
+                if (a.hit) a.hit[row] = hit ? 1 : 0;
+                if (a.was_hit) a.was_hit[row] = was_hit ? 1 : 0;
             }
+            p_rew += EN; p_mask += EN; p_done += a.E; row += (long long)EN;
+        };
+        float *p_obs = a.obs32 ? a.obs32 + idx * 6 : nullptr;
+        long long row6 = (long long)idx * 6;
+        asm volatile("" : "+v"(p_obs), "+v"(row6));
+        auto emit_obs = [&](int bo) {
             // observation row (fortattack_env_v1.py:238): the state after the step / reset
+            const bool alive_new = (s_mask[bo][0] >> lane) & 1ull;
+            const double px = s_px[bo][lane], py = s_py[bo][lane], ang = s_ang[bo][lane];
+            const double vx = s_vx[bo][lane], vy = s_vy[bo][lane];
             const double al = alive_new ? 1.0 : 0.0;
-            const size_t o6 = o * 6;
             if (COLLECT || a.obs32) {
-                float2 *ob = reinterpret_cast<float2 *>(a.obs32 + o6);
+                float2 *ob = reinterpret_cast<float2 *>(p_obs);
                 ob[0] = make_float2((float)al, (float)px);
                 ob[1] = make_float2((float)py, (float)ang);
                 ob[2] = make_float2((float)vx, (float)vy);
             }
             if (!COLLECT && a.obs64) {
-                double2 *ob = reinterpret_cast<double2 *>(a.obs64 + o6);
+                double2 *ob = reinterpret_cast<double2 *>(a.obs64 + row6);
                 ob[0] = make_double2(al, px);
                 ob[1] = make_double2(py, ang);
                 ob[2] = make_double2(vx, vy);
             }
+            p_obs += EN * 6; row6 += (long long)EN * 6;
         };
         // wave 1 owns the env's reset stream during the launch (see ResetDraw)
         const bool rng_wave = wave_id == 1;
@@ -1074,18 +1090,20 @@ __global__ __launch_bounds__((NPW + 2) * FA_WAVE, MINW) void fa_step_pipe_kernel
                 draw_load(a, e, draw_next_base(a, rdB.base, i, N), mw);
             }
             need_b = false;
-            if (!(FA_ABL & 1) && out_wave && s > 0) emit(s - 1, b);
+            if (!(FA_ABL & 1) && rew_wave && s > 0) emit_rew(b);
+            if (!(FA_ABL & 1) && out_wave && s > 0) emit_obs(b);
             act_prev = act_cur;
             alive0_prev = alive0;
             FA_TICK(13)
             FA_WG_BARRIER(); // P(s)
         }
         if (rng_wave && a.auto_reset != 0 && ((s_mask[ns & 1][4] >> lane) & 1ull)) draw_commit(a, e, i, N, rdA);
-        if (out_wave) {
-            emit(ns - 1, ns & 1);
+        if (rew_wave) {
+            emit_rew(ns & 1);
             a.s.prev[idx] = prev;
             if (a.track_counters) a.s.ep_rew[idx] = ep_rew;
         }
+        if (out_wave) emit_obs(ns & 1);
         if (out_wave) { FA_TICK_FLUSH(10, 14, 29) }
         return;
     }

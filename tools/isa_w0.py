@@ -25,6 +25,13 @@ for h in heads:
     endk = next((k for k in range(last_blk + 1, len(body)) if re.match(r"^\.LBB", body[k])), len(body))
     seg = body[h:endk]
     text = "\n".join(seg)
+    if "--all" in sys.argv:
+        ins = [l.split()[0] for l in seg if l.startswith("\t") and not l.strip().startswith(";") and not l.strip().startswith(".")]
+        hh = collections.Counter(re.sub(r"_e(32|64)$", "", x) for x in ins)
+        role = "wave 0" if ("ds_write2st64_b32" in text and "v_rcp_f64" in text) else "pair/output waves" if "global_store" in text else "last wave"
+        print("loop @%s (%s): %d instructions; v_readlane %d, s_nop %d, global_store %d, ds %d" % (
+            body[h].split(":")[0], role, len(ins), hh["v_readlane_b32"], hh["s_nop"],
+            sum(v for k, v in hh.items() if k.startswith("global_store")), sum(v for k, v in hh.items() if k.startswith("ds_"))))
     if "ds_write2st64_b32" in text and "v_rcp_f64" in text:   # wave 0: restages actions and integrates
         best = seg
 assert best is not None
