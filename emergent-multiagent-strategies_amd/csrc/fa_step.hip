@@ -274,6 +274,16 @@ __device__ __forceinline__ bool laser_hit(double x1, double y1, double x2, doubl
 // and its order are unchanged.  (A two-barrier variant in which wave 0 sums the candidates itself
 // measured 4 % slower: wave 0 is the critical path, the force wave has slack.)  Three workgroup barriers per step (raw s_barrier behind an LDS
 // wait -- __syncthreads() would also drain the global stores).
+// the lane mask of a condition as it already sits in an SGPR pair (HIP's __ballot() goes through an
+// int: v_cndmask 0/1 + v_cmp_ne, two issue slots per ballot)
+__device__ __forceinline__ unsigned long long fa_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+// Lane conditions as 64-bit wave masks: a VALU compare delivers its lane mask (zero in inactive lanes)
+// in an SGPR pair, mask algebra is scalar, and fa_lanes() hands a mask back as a lane predicate without
+// an instruction.  (A `bool` that is ANDed / ORed and then balloted goes through v_cndmask + v_cmp.)
+#define FA_M_EQ_U(a, b) __builtin_amdgcn_uicmp((unsigned)(a), (unsigned)(b), 32)  /* ICMP_EQ */
+#define FA_M_NE_U(a, b) __builtin_amdgcn_uicmp((unsigned)(a), (unsigned)(b), 33)  /* ICMP_NE */
+#define FA_M_LE_D(a, b) __builtin_amdgcn_fcmp((double)(a), (double)(b), 5)        /* FCMP_OLE */
+__device__ __forceinline__ bool fa_lanes(unsigned long long m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
 #define FA_WG_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 template <int TG, int TA, bool RESET_ONLY, bool COLLECT, int NW>
 __global__ __launch_bounds__(NW * FA_WAVE) void fa_step_kernel(FaStepArgs a) {
@@ -937,7 +947,7 @@ __global__ __launch_bounds__((NPW + 2) * FA_WAVE, MINW) void fa_step_pipe_kernel
             const bool alive0 = alive0_prev;
             const bool shoot = act_prev == 7;
             const int n_alive_att = __popcll(((m1 >> gbase) & grp_mask) >> G);
-            const unsigned long long in_fort_b = __ballot(is_att && alive1 && dist_door < k_fort);
+            const unsigned long long in_fort_b = fa_ballot(is_att && alive1 && dist_door < k_fort);
             const bool any_in_fort = ((in_fort_b >> gbase) & grp_mask) != 0ull;
             const bool do_reset = done && a.auto_reset != 0;
             // ---- rewards (fortattack_env_v1.py:87-188), after World.step ----------------------
@@ -1111,10 +1121,11 @@ __global__ __launch_bounds__((NPW + 2) * FA_WAVE, MINW) void fa_step_pipe_kernel
     // ---- wave 0 ----------------------------------------------------------------------------------
     double px = a.s.px[idx], py = a.s.py[idx], vx = a.s.vx[idx], vy = a.s.vy[idx];
     double ang = a.s.ang[idx];
-    bool alive = a.s.alive[idx] != 0;
+    unsigned long long alive_m = FA_M_NE_U(a.s.alive[idx], 0); // wave mask of the living (see FA_M_*)
     int t = a.s.tstep[e], nh = 0, nwh = 0;
     if (a.track_counters) { nh = a.s.num_hit[idx]; nwh = a.s.num_was_hit[idx]; }
-    bool dirty = false;
+    unsigned long long dirty_m = 0ull;
+    const unsigned long long is_att_m = FA_M_NE_U(is_att ? 1u : 0u, 0), lane0_m = FA_M_EQ_U(lane, 0);
     const int64_t *act_ptr = a.actions + (int64_t)e * a.as_e + (int64_t)i * a.as_i;
     int av[FA_ACT_BATCH];
 #pragma unroll
@@ -1132,7 +1143,8 @@ __global__ __launch_bounds__((NPW + 2) * FA_WAVE, MINW) void fa_step_pipe_kernel
     constexpr int KT = TG > TA ? TG : TA;
     const int n_opp = is_att ? G : A, opp0 = is_att ? 0 : G;
     const int team_idx = is_att ? i - G : i;
-    const unsigned long long opp_mask = is_att ? ((1ull << G) - 1ull) : (((1ull << A) - 1ull) << G);
+    const unsigned opp_bits = is_att ? ((1u << G) - 1u) : (((1u << A) - 1u) << G); // the opponents in the group word
+    constexpr unsigned grp_bits = (1u << N) - 1u;
     double sn, cs, sn_g = 0.0, cs_g = 0.0, sn_a = 0.0, cs_a = 0.0;
     sincos_heading(ang, sn, cs);
     if (ns > 1) { // headings after a reset (fortattack_env_v1.py:59)
@@ -1152,10 +1164,7 @@ __global__ __launch_bounds__((NPW + 2) * FA_WAVE, MINW) void fa_step_pipe_kernel
     s_px[0][lane] = px;
     s_py[0][lane] = py;
     s_ang[0][lane] = ang;
-    {
-        const unsigned long long b0 = __ballot(alive);
-        if (lane == 0) s_mask[0][0] = b0;
-    }
+    if (fa_lanes(lane0_m)) s_mask[0][0] = alive_m;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -1165,7 +1174,7 @@ __global__ __launch_bounds__((NPW + 2) * FA_WAVE, MINW) void fa_step_pipe_kernel
         oqx[k] = s_px[0][j]; oqy[k] = s_py[0][j];
         ocs[k] = s_trig[0][0][j]; osn[k] = s_trig[0][1][j];
     }
-    bool reset_prev = false;
+    unsigned long long reset_prev_m = 0ull;
     s_fmx[i][lane] = 0.0; // an agent exerts no force on itself: the pair waves never write the diagonal
     s_fmy[i][lane] = 0.0;
     FA_WG_BARRIER(); // P(-1)
@@ -1185,11 +1194,9 @@ __global__ __launch_bounds__((NPW + 2) * FA_WAVE, MINW) void fa_step_pipe_kernel
     FA_TICK_INIT
     for (int s = 0; s < ns; ++s) {
         const int nb = (s + 1) & 1;
-        const bool alive0 = alive;
+        const unsigned long long alive0_m = alive_m;
         // (the action is decoded by the last wave, fortattack.py:253-263; only `shoot` is needed here)
-        const bool shoot = act == 7;
-        const bool shooter = alive0 && shoot;
-        const unsigned long long shooters_b = __ballot(shooter);
+        const unsigned long long shooters_m = FA_M_EQ_U(act, 7) & alive0_m;
         if (s > 0) { // sin/cos of the opponents' headings: the last wave's, constants after a reset
 #pragma unroll
             for (int k = 0; k < KT; ++k) {
@@ -1197,51 +1204,52 @@ __global__ __launch_bounds__((NPW + 2) * FA_WAVE, MINW) void fa_step_pipe_kernel
                 ocs[k] = s_trig[s & 1][0][j];
                 osn[k] = s_trig[s & 1][1][j];
             }
-            if (__ballot(reset_prev) != 0ull) {
+            if (reset_prev_m != 0ull) {
+                const bool rp = fa_lanes(reset_prev_m);
 #pragma unroll
                 for (int k = 0; k < KT; ++k) {
-                    ocs[k] = reset_prev ? cs_ro : ocs[k];
-                    osn[k] = reset_prev ? sn_ro : osn[k];
+                    ocs[k] = rp ? cs_ro : ocs[k];
+                    osn[k] = rp ? sn_ro : osn[k];
                 }
             }
         }
         FA_TICK(0)
 
         // ---- core.py:254-302 apply_laser_effect ------------------------------------------------
-        // test k: every lane against its k-th opponent; the ballot of the results gives shooter k
-        // of either team its hit list.
-        bool was_hit = false;
+        // test k: every lane against its k-th opponent; hb[k] = the lanes hit by shooter k of either
+        // team.  "Group word" = a wave mask shifted down to the lane's own env (bit j = agent j).
+        unsigned long long hb[KT];
+#pragma unroll
+        for (int k = 0; k < KT; ++k) hb[k] = 0ull;
         int hit_cnt = 0, was_hit_cnt = 0;
-        if (!(FA_ABL & 2) && shooters_b != 0ull) {
-            bool hk[KT];
+        if (!(FA_ABL & 2) && shooters_m != 0ull) {
+            const unsigned gw_sh = (unsigned)(shooters_m >> gbase);
 #pragma unroll
             for (int k = 0; k < KT; ++k) {
-                const int j = gbase + opp0 + k;
-                const bool cand = alive0 && k < n_opp && ((shooters_b >> j) & 1ull);
+                const unsigned long long cand_m = (k < n_opp ? FA_M_NE_U(gw_sh & (1u << (opp0 + k)), 0) : 0ull) & alive0_m;
                 const double ax = oqx[k] + k_size * ocs[k], ay = oqy[k] + k_size * osn[k];
                 const double dx = px - ax, dy = py - ay;
                 const double u = dx * ocs[k] + dy * osn[k];
                 const double v = dy * ocs[k] - dx * osn[k];
-                hk[k] = cand & (u <= k_far) & (fabs(v) * k_chw <= u * k_shw);
+                hb[k] = cand_m & FA_M_LE_D(u, k_far) & FA_M_LE_D(fabs(v) * k_chw, u * k_shw);
             }
-            unsigned long long my_hb = 0ull;
+            // a shooter's hit list is the ballot of its team index, restricted to the opponents of its env
             int tix = team_idx;
             asm volatile("" : "+v"(tix)); // compare in the loop: KT hoisted lane masks cost 2 SGPRs each
+            unsigned sel = (unsigned)(hb[0] >> gbase);
 #pragma unroll
-            for (int k = 0; k < KT; ++k) {
-                const unsigned long long hb = __ballot(hk[k]);
-                my_hb = (k == tix) ? hb : my_hb;
-                was_hit = was_hit | hk[k];
-                was_hit_cnt += hk[k] ? 1 : 0;
-            }
-            hit_cnt = __popcll((my_hb >> gbase) & opp_mask);
+            for (int k = 1; k < KT; ++k) sel = (k == tix) ? (unsigned)(hb[k] >> gbase) : sel;
+            hit_cnt = __popc(sel & opp_bits);
+#pragma unroll
+            for (int k = 0; k < KT; ++k) was_hit_cnt += fa_lanes(hb[k]) ? 1 : 0;
         }
-        const bool hit = shooter && hit_cnt > 0;
-        const bool alive1 = alive0 && !was_hit;       // :293-302 one shot kills
-        const unsigned long long alive1_b = __ballot(alive1);
-        const unsigned long long hit_b = __ballot(hit), was_hit_b = __ballot(was_hit);
-        const unsigned long long grp_alive1 = (alive1_b >> gbase) & grp_mask;
-        const int n_alive_att = __popcll(grp_alive1 >> G);
+        unsigned long long was_hit_m = hb[0];
+#pragma unroll
+        for (int k = 1; k < KT; ++k) was_hit_m |= hb[k];
+        const unsigned long long hit_m = FA_M_NE_U(hit_cnt, 0) & shooters_m;
+        const unsigned long long alive1_m = alive0_m & ~was_hit_m;        // :293-302 one shot kills
+        const unsigned ga1 = (unsigned)(alive1_m >> gbase) & grp_bits;     // survivors of the lane's env
+        const int n_alive_att = __popc(ga1 >> G);
         FA_TICK(1)
         FA_WG_BARRIER(); // B2(s): pair and wall forces of this step are in LDS
         FA_TICK(2)
@@ -1256,11 +1264,10 @@ __global__ __launch_bounds__((NPW + 2) * FA_WAVE, MINW) void fa_step_pipe_kernel
         const bool restage = ((s + 1) & (FA_ACT_BATCH - 1)) == 0;
         const int act_lds = s_act[(s + 1) & (FA_ACT_BATCH - 1)][lane];
         int act_next = restage ? av[0] : act_lds;
-        if (alive1) {
+        if (fa_lanes(alive1_m)) {
             // masked by the survivors with one FMA per term: fma(f, 1, F) == f + F and fma(f, 0, F) == F
             // bit for bit (F is never -0.0; f is finite unless two agents coincide exactly)
             double Fx = u0, Fy = u1;
-            const unsigned ga1 = (unsigned)grp_alive1;
 #pragma unroll
             for (int j = 0; j < N; ++j)
                 if (!(FA_ABL & 64)) {
@@ -1286,8 +1293,7 @@ __global__ __launch_bounds__((NPW + 2) * FA_WAVE, MINW) void fa_step_pipe_kernel
             py += vy * k_dt;
         }
         // (pinned here: selected after the barrier P, av[0] would still be live when the next batch
-        // is loaded and the loop would carry a copy of a pending load -- a vmcnt(0) every step;
-        // selected after the reset, its vmcnt(0) would wait for the reset's MT prefetch)
+        // is loaded and the loop would carry a copy of a pending load -- a vmcnt(0) every step)
         asm volatile("" : "+v"(act_next));
         FA_TICK(3)
         // ---- what the next state needs of the reward / done logic ------------------------------
@@ -1295,43 +1301,39 @@ __global__ __launch_bounds__((NPW + 2) * FA_WAVE, MINW) void fa_step_pipe_kernel
         // square root itself is only needed by the rewards and is taken by the output wave)
         const double ddx = px - k_doorx, ddy = py - k_doory;
         const double dd2 = ddx * ddx + ddy * ddy;
-        const unsigned long long in_fort_b = __ballot(is_att && alive1 && dd2 <= k_fort2);
-        const bool any_in_fort = ((in_fort_b >> gbase) & grp_mask) != 0ull;
-        const bool timeout = t == a.max_t - 1;
-        const bool done = any_in_fort || n_alive_att == 0 || timeout; // fortattack.py:202-225
-        const bool do_reset = done && a.auto_reset != 0;
-        const unsigned long long done_b = __ballot(done);
+        const unsigned long long in_fort_m = FA_M_LE_D(dd2, k_fort2) & is_att_m & alive1_m;
+        const unsigned gw_fort = (unsigned)(in_fort_m >> gbase) & grp_bits;
+        // fortattack.py:202-225: an attacker in the fort, no attacker left, or the time limit
+        const unsigned long long done_m = FA_M_NE_U(gw_fort, 0) | FA_M_EQ_U(n_alive_att, 0) | FA_M_EQ_U(t, a.max_t - 1);
+        const unsigned long long reset_m = a.auto_reset != 0 ? done_m : 0ull;
         t += 1;                                                        // fortattack.py:171
-        alive = alive1;
+        alive_m = alive1_m;
         nh += hit_cnt;
         nwh += was_hit_cnt; // one per shooter that hit (core.py:283)
-        dirty = dirty || alive0;
+        dirty_m |= alive0_m;
         FA_TICK(4)
         // ---- fortattack_env_v1.py:47-75 reset_world (prevDist is NOT reset: quirk Q1) ----------
         // (the positions were drawn ahead by wave 1, see ResetDraw)
-        if (done_b != 0ull && a.auto_reset != 0) { // wave-uniform: most steps reset no env of the wave
+        if (reset_m != 0ull) { // wave-uniform: most steps reset no env of the wave
             const double rpx = s_rp[0][lane], rpy = s_rp[1][lane];
-            if (do_reset) {
+            if (fa_lanes(reset_m)) {
                 px = rpx; py = rpy; vx = 0.0; vy = 0.0;
                 ang = k_ang_r;
-                alive = true;
                 t = 0;
                 nh = 0; nwh = 0;
-                dirty = true;
             }
+            alive_m |= reset_m;
+            dirty_m |= reset_m;
         }
-        reset_prev = do_reset;
+        reset_prev_m = reset_m;
         FA_TICK(5)
         // ---- publish state(s+1): what the helper waves need to start on step s+1 ----------------
         s_px[nb][lane] = px;
         s_py[nb][lane] = py;
         s_ang[nb][lane] = ang;
-        {
-            const unsigned long long alive_b = __ballot(alive);
-            if (lane == 0) {
-                s_mask[nb][0] = alive_b;
-                s_mask[nb][4] = done_b;
-            }
+        if (fa_lanes(lane0_m)) {
+            s_mask[nb][0] = alive_m;
+            s_mask[nb][4] = done_m;
         }
         if (restage) {
 #pragma unroll
@@ -1343,10 +1345,10 @@ __global__ __launch_bounds__((NPW + 2) * FA_WAVE, MINW) void fa_step_pipe_kernel
             s_vx[nb][lane] = vx;
             s_vy[nb][lane] = vy;
             s_dd[nb][lane] = dd2;
-            if (lane == 0) {
-                s_mask[nb][1] = alive1_b;
-                s_mask[nb][2] = hit_b;
-                s_mask[nb][3] = was_hit_b;
+            if (fa_lanes(lane0_m)) {
+                s_mask[nb][1] = alive1_m;
+                s_mask[nb][2] = hit_m;
+                s_mask[nb][3] = was_hit_m;
             }
         };
         const bool last = s + 1 == ns;
@@ -1374,10 +1376,10 @@ __global__ __launch_bounds__((NPW + 2) * FA_WAVE, MINW) void fa_step_pipe_kernel
     if (lane == 0) { atomicAdd(&g_dbg[20], clock64() - tk0); atomicAdd(&g_dbg[21], wall_clock64() - tw0); }
 #endif
 
-    if (dirty) {
+    if (fa_lanes(dirty_m)) {
         a.s.px[idx] = px; a.s.py[idx] = py; a.s.vx[idx] = vx; a.s.vy[idx] = vy;
         a.s.ang[idx] = ang;
-        a.s.alive[idx] = alive ? 1 : 0;
+        a.s.alive[idx] = fa_lanes(alive_m) ? 1 : 0;
         if (a.track_counters) { a.s.num_hit[idx] = nh; a.s.num_was_hit[idx] = nwh; }
     }
     if (i == 0) a.s.tstep[e] = t;
