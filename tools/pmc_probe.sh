@@ -12,14 +12,29 @@ for grp in "SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_D
 done
 cd $R
 python - <<'PY'
-import csv, glob, collections
+import csv, glob, collections, json
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("gpurun_out/pmc_probe/g*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         if "fa_step" in r["Kernel_Name"]:
-            acc[r["Kernel_Name"][:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+out = {}
 for k, d in acc.items():
-    print(k)
-    for n, v in sorted(d.items()):
-        print("   %-32s %16.1f  (n=%d)" % (n, sum(v) / len(v), len(v)))
+    print(k[:70])
+    avg = {n: sum(v) / len(v) for n, v in d.items()}
+    for n, v in sorted(avg.items()):
+        print("   %-32s %16.1f" % (n, v))
+    out[k] = avg
+# per workgroup per env-step for the headline launch (410 workgroups x 128 steps), if present
+E, N, T = 4096, 6, 128
+wgs = (E + (64 // N) - 1) // (64 // N)
+for k, avg in out.items():
+    if "pipe" in k and "<3, 3, true" in k:
+        rec = {"config": "3v3, E=4096, 128 env-steps per launch, %d workgroups x 4 waves (wave 0 + 3 helper waves)" % wgs,
+               "kernel": k,
+               "note": "sums over the 4 waves of a workgroup, per env-step of the workgroup (10 envs); SQ_WAVE_CYCLES / SQ_WAIT_* / "
+                       "SQ_ACTIVE_INST_* / SQ_BUSY_CYCLES count quad-cycles (x4 for shader cycles); one --pmc pass per group of 4",
+               "per_workgroup_per_env_step": {n: round(v / (wgs * T), 2) for n, v in sorted(avg.items())},
+               "per_launch": {n: v for n, v in sorted(avg.items())}}
+        json.dump(rec, open("gpurun_out/pmc_probe/sq_counters.json", "w"), indent=1)
 PY
