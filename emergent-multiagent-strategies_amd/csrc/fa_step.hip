@@ -865,7 +865,8 @@ __global__ __launch_bounds__((NPW + 2) * FA_WAVE, MINW) void fa_step_pipe_kernel
             const int act = s_act[s & (FA_ACT_BATCH - 1)][lane];
             const double ang = s_ang[b][lane];
             const bool alive0 = (s_mask[b][0] >> lane) & 1ull;
-            const double px = s_px[b][lane], py = s_py[b][lane];
+            double px = s_px[b][lane], py = s_py[b][lane];
+            asm volatile("" : "+v"(px), "+v"(py)); // read with the rest: one LDS round trip, not two
             // fortattack.py:253-263,:289 _set_action, for wave 0 (F starts as u + 0.0, core.py:221-228)
             double u0 = 0.0, u1 = 0.0, rot = 0.0;
             if (act == 1) u0 = +1.0;
@@ -1064,6 +1065,20 @@ __global__ __launch_bounds__((NPW + 2) * FA_WAVE, MINW) void fa_step_pipe_kernel
             const bool alive0 = (grp_alive0 >> i) & 1ull;
             const double px = s_px[b][lane], py = s_py[b][lane];
             const int act_cur = s_act[s & (FA_ACT_BATCH - 1)][lane];
+            // the partners' positions of all this wave's offsets in one LDS round trip (small teams:
+            // at N = 10 the extra live registers push the 168-VGPR build into scratch)
+            constexpr bool HOISTQ = NOFF <= 3;
+            double qx[NOFF], qy[NOFF];
+            if constexpr (HOISTQ) {
+#pragma unroll
+                for (int d = 1; d <= NOFF; ++d) {
+                    if ((d - 1) % NPW != wave_id - 1) continue; // uniform per wave
+                    int j = i + d;
+                    j = j >= N ? j - N : j;
+                    qx[d - 1] = s_px[b][gbase + j];
+                    qy[d - 1] = s_py[b][gbase + j];
+                }
+            }
 #pragma unroll
             for (int d = 1; d <= NOFF; ++d) {
                 if ((d - 1) % NPW != wave_id - 1) continue; // uniform per wave
@@ -1072,7 +1087,11 @@ __global__ __launch_bounds__((NPW + 2) * FA_WAVE, MINW) void fa_step_pipe_kernel
                 const bool mine = (2 * d != N) || (i < N / 2); // the half offset: one side only
                 // candidate against a partner alive BEFORE the laser (one the laser kills this step
                 // is masked out in the sum); exactly +0.0 when out of range, so adding it is a no-op
-                const double dx = px - s_px[b][gbase + j], dy = py - s_py[b][gbase + j];
+                if constexpr (!HOISTQ) {
+                    qx[d - 1] = s_px[b][gbase + j];
+                    qy[d - 1] = s_py[b][gbase + j];
+                }
+                const double dx = px - qx[d - 1], dy = py - qy[d - 1];
                 const double d2 = dx * dx + dy * dy;
                 double fxv = 0.0, fyv = 0.0;
                 bool near = false;
@@ -1455,11 +1474,9 @@ static hipError_t launch_step_t(const FaStepArgs &a, hipStream_t st) {
 #define FA_LAUNCH_PIPE(TG_, TA_, NPW_, MINW_) \
     hipLaunchKernelGGL((fa_step_pipe_kernel<TG_, TA_, COLLECT, NPW_, MINW_>), dim3(grid), dim3((NPW_ + 2) * FA_WAVE), 0, st, a)
     if (a.G == 3 && a.A == 3) {
-#ifdef FA_EXP_NPW
-        if (pipe) FA_LAUNCH_PIPE(3, 3, FA_EXP_NPW, FA_EXP_MINW);
-#else
-        if (pipe) FA_LAUNCH_PIPE(3, 3, 2, 2);
-#endif
+        // up to two workgroups per CU the build may use 256 VGPRs; three per CU need <= 168
+        if (pipe && grid <= 2 * 256) FA_LAUNCH_PIPE(3, 3, 2, 2);
+        else if (pipe) FA_LAUNCH_PIPE(3, 3, 2, 3);
         else if (nw == 3) FA_LAUNCH(3, 3, 3); else if (nw == 2) FA_LAUNCH(3, 3, 2); else FA_LAUNCH(3, 3, 1);
     } else if (a.G == 5 && a.A == 5) {
         if (pipe) FA_LAUNCH_PIPE(5, 5, 2, 3);
