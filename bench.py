@@ -4,9 +4,9 @@
 One bench "step" = one pass of the hot path over one batch: a T=128-step rollout of
 E=4096 envs per GPU (FortAttack 3v3, open-loop uniform-random actions already resident in
 the rollout buffers) through the HIP step kernel with its fused collector write
-(obs / rewards / masks / done rows of the RolloutStorage layout), followed by the GAE scan
-and the two-pass advantage statistics + normalisation (the only cross-GPU exchange: an
-all-reduce of N x 3 doubles per pass when --gpus > 1).  Inputs are in HBM before the timed
+(obs / rewards / masks / done rows of the RolloutStorage layout), followed by the GAE scan, the
+one-pass fp64 advantage moments and the advantage normalisation (the only cross-GPU exchange: one
+all-gather of N x 3 doubles when --gpus > 1).  Inputs are in HBM before the timed
 region starts.  The MPNN policy forward is NOT part of this workload (BASELINE config 2:
 "random policy, step-kernel only"); bench_rollout_mpnn.py times config 3.
 
@@ -108,7 +108,7 @@ def main():
             dist.init_process_group(args.backend)
 
     import emergent_multiagent_strategies_amd as fa
-    from emergent_multiagent_strategies_amd.dist import adv_mean_std
+    from emergent_multiagent_strategies_amd.dist import gae_adv_mean_std
 
     E, G, A, T = args.envs, args.guards, args.attackers, args.rollout
     N = G + A
@@ -143,8 +143,8 @@ def main():
     def hot_path():
         env_rollout()
         if not args.no_collector:
-            eng.gae(0.99, 0.95)
-            mean, std = adv_mean_std(eng)      # two-pass fp64; all-reduce when world > 1
+            # GAE, one-pass fp64 advantage moments; one all-gather of N x 3 doubles when world > 1
+            mean, std = gae_adv_mean_std(eng, 0.99, 0.95)
             eng.adv_normalize(mean, std, out=adv)
 
     def barrier():
@@ -163,8 +163,7 @@ def main():
         env_rollout()
         ev[k][1].record()
         if not args.no_collector:
-            eng.gae(0.99, 0.95)
-            mean, std = adv_mean_std(eng)
+            mean, std = gae_adv_mean_std(eng, 0.99, 0.95)
             eng.adv_normalize(mean, std, out=adv)
     torch.cuda.synchronize()
     barrier()
@@ -211,8 +210,8 @@ def main():
                                 "fa_step fused over the rollout in one launch" if graph is None else
                                 "one fa_step launch per env-step replayed from a hipGraph",
                                 "step kernel only" if args.no_collector else
-                                "+ fused RolloutStorage write, GAE scan, 2-pass advantage statistics "
-                                "(all-reduce of N x 3 f64 when n_gpus > 1) and normalisation"),
+                                "+ fused RolloutStorage write, GAE scan, one-pass fp64 advantage moments "
+                                "(all-gather of N x 3 f64 when n_gpus > 1) and normalisation"),
                 "envs_per_gpu": E, "rollout_steps": T, "num_guards": G, "num_attackers": A,
                 "max_time_steps": 100, "rng": "mt19937 (reference-parity reset stream)",
                 "launch": args.launch, "parallelism": "env shards, %d rank(s)" % world},

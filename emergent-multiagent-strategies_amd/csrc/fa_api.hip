@@ -18,6 +18,8 @@ hipError_t fa_launch_selftest(unsigned long long n_per_thread, unsigned long lon
                               hipStream_t st);
 hipError_t fa_launch_gae(const float *rewards, const float *value_preds, const float *masks, float *returns,
                          const uint8_t *done, int T, int E, int N, double gamma, double tau, hipStream_t st);
+hipError_t fa_launch_adv_onepass(const float *returns, const float *value_preds, long long rows, int N, double *partial,
+                                 int nblocks, double *moments_out, double *mean_out, double *std_out, hipStream_t st);
 hipError_t fa_launch_adv_stats(int pass, const float *returns, const float *value_preds, const double *mean,
                                long long rows, int N, double *partial, int nblocks, double *stats,
                                double *derived, hipStream_t st);
@@ -225,7 +227,7 @@ int fa_create(const fa_config *cfg, fa_env **out) {
     const size_t o_cnt = carve(E * sizeof(uint32_t));
     const size_t o_epr = carve(2 * EN * sizeof(double));
     const size_t o_ale = carve(EN * sizeof(uint32_t));
-    const size_t o_adv = carve((size_t)env->adv_blocks * FA_MAX_AGENTS * sizeof(double));
+    const size_t o_adv = carve((size_t)env->adv_blocks * FA_MAX_AGENTS * 2 * sizeof(double));
     const size_t o_advs = carve((size_t)FA_MAX_AGENTS * 4 * sizeof(double));
     env->slab_bytes = off;
     hipError_t he = hipMalloc(&env->slab, env->slab_bytes);
@@ -380,6 +382,24 @@ int fa_gae(fa_env *env, double gamma, double tau, void *stream) {
     const fa_storage &st = env->st;
     FA_HIP(fa_launch_gae(st.rewards, st.value_preds, st.masks, st.returns, st.done, st.num_steps,
                          env->cfg.num_envs, env->N, gamma, tau, static_cast<hipStream_t>(stream)));
+    return FA_OK;
+}
+
+int fa_gae_moments(fa_env *env, double gamma, double tau, double *moments_out, double *mean_out, double *std_out,
+                   void *stream) {
+    if (!env) return fail(FA_ERR_INVALID, "fa_gae_moments: null env");
+    if (!env->bound) return fail(FA_ERR_STATE, "fa_gae_moments: no storage bound");
+    DeviceGuard guard(env->cfg.device_id);
+    const fa_storage &st = env->st;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    FA_HIP(fa_launch_gae(st.rewards, st.value_preds, st.masks, st.returns, st.done, st.num_steps,
+                         env->cfg.num_envs, env->N, gamma, tau, s));
+    const long long rows = (long long)st.num_steps * env->cfg.num_envs;
+    // a lane takes 2 rows x 4 per trip: one workgroup per 2048 rows, at most two per CU
+    long long want = (rows + 2047) / 2048;
+    const int nblocks = (int)(want < 512 ? (want < 1 ? 1 : want) : 512);
+    FA_HIP(fa_launch_adv_onepass(st.returns, st.value_preds, rows, env->N, env->adv_partial, nblocks, moments_out,
+                                 mean_out, std_out, s));
     return FA_OK;
 }
 

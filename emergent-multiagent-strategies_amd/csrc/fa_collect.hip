@@ -225,6 +225,137 @@ __global__ __launch_bounds__(256) void fa_adv_partial_vec_kernel(const float *__
     }
 }
 
+// ---- advantage moments in ONE pass ---------------------------------------------------------------
+// (n, mean, M2) per agent from a single sweep over returns / value_preds: every lane accumulates
+// S = sum(A - P) and Q = sum((A - P)^2) in fp64 around a pivot P_i common to the whole grid -- agent
+// i's advantage in row 0, an actual sample, so that S*S/n does not cancel against Q -- the workgroup
+// folds its lanes into partial[block][i] = {S, Q}, and a one-workgroup kernel folds the workgroups in
+// a fixed order: mean = P + S/n, M2 = Q - S*S/n.  Bitwise reproducible; relative error of M2 ~
+// 1e-16 * (1 + ((P - mean)/std)^2) times the accumulation factor.  (Folding in the same launch by
+// the last workgroup to finish -- ticket counter + device-scope fences -- measured 10x slower: an
+// agent-scope release / acquire is an L2 write-back / invalidate on this multi-XCD part.)
+__device__ __forceinline__ void fa_adv_onepass_finish(double (&acc_s)[FA_MAX_AGENTS_DEV], double (&acc_q)[FA_MAX_AGENTS_DEV],
+                                                      int N, double *__restrict__ partial) {
+    __shared__ double red[4][FA_MAX_AGENTS_DEV][2];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < FA_MAX_AGENTS_DEV; ++i) {
+        if (i < N) {
+            double s = acc_s[i], q = acc_q[i];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) { s += __shfl_down(s, off, 64); q += __shfl_down(q, off, 64); }
+            if (lane == 0) { red[wave][i][0] = s; red[wave][i][1] = q; }
+        }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < 2 * N) {
+        const int i = threadIdx.x >> 1, c = threadIdx.x & 1;
+        partial[((long long)blockIdx.x * N + i) * 2 + c] = ((red[0][i][c] + red[1][i][c]) + red[2][i][c]) + red[3][i][c];
+    }
+}
+
+// one wave per agent: lane l takes workgroups l, l+64, ... in order (loads issued together), then a
+// fixed shuffle tree
+#define FA_ADV_FOLD 16 // partial workgroups per lane of the final fold: nblocks <= 64 * FA_ADV_FOLD
+__global__ void fa_adv_onepass_final_kernel(const double *__restrict__ partial, int nblocks, int N,
+                                            const float *__restrict__ returns, const float *__restrict__ value_preds,
+                                            double n_rows, double *__restrict__ moments_out,
+                                            double *__restrict__ mean_out, double *__restrict__ std_out) {
+    const int i = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (i >= N) return;
+    double ps[FA_ADV_FOLD], pq[FA_ADV_FOLD];
+#pragma unroll
+    for (int k = 0; k < FA_ADV_FOLD; ++k) {
+        const int b = lane + 64 * k;
+        const bool in = b < nblocks;
+        const double *p = partial + ((long long)(in ? b : 0) * N + i) * 2;
+        ps[k] = in ? p[0] : 0.0;
+        pq[k] = in ? p[1] : 0.0;
+    }
+    double s = 0.0, q = 0.0;
+#pragma unroll
+    for (int k = 0; k < FA_ADV_FOLD; ++k) { s += ps[k]; q += pq[k]; }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { s += __shfl_down(s, off, 64); q += __shfl_down(q, off, 64); }
+    if (lane == 0) {
+        const double piv = (double)(returns[i] - value_preds[i]); // the pivot of the sweep: row 0
+        const double mean = piv + s / n_rows, m2 = q - s * (s / n_rows);
+        if (moments_out) { moments_out[i * 3 + 0] = n_rows; moments_out[i * 3 + 1] = mean; moments_out[i * 3 + 2] = m2; }
+        if (mean_out) mean_out[i] = mean;
+        if (std_out) std_out[i] = sqrt(m2 / (n_rows - 1.0));
+    }
+}
+
+__global__ __launch_bounds__(256) void fa_adv_onepass_kernel(const float *__restrict__ returns,
+                                                             const float *__restrict__ value_preds, long long rows, int N,
+                                                             double *__restrict__ partial) {
+    double acc_s[FA_MAX_AGENTS_DEV], acc_q[FA_MAX_AGENTS_DEV], piv[FA_MAX_AGENTS_DEV];
+#pragma unroll
+    for (int i = 0; i < FA_MAX_AGENTS_DEV; ++i) {
+        acc_s[i] = 0.0; acc_q[i] = 0.0;
+        piv[i] = i < N ? (double)(returns[i] - value_preds[i]) : 0.0;
+    }
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += stride) {
+        const float *ret = returns + r * N, *vp = value_preds + r * N;
+#pragma unroll
+        for (int i = 0; i < FA_MAX_AGENTS_DEV; ++i) {
+            if (i < N) {
+                const double d = (double)(ret[i] - vp[i]) - piv[i];
+                acc_s[i] += d;
+                acc_q[i] = __fma_rn(d, d, acc_q[i]);
+            }
+        }
+    }
+    fa_adv_onepass_finish(acc_s, acc_q, N, partial);
+}
+
+// compile-time even N with 16-byte loads: two whole rows per lane per trip (see fa_adv_partial_vec_kernel)
+template <int TN>
+__global__ __launch_bounds__(256) void fa_adv_onepass_vec_kernel(const float *__restrict__ returns,
+                                                                 const float *__restrict__ value_preds, long long row_pairs,
+                                                                 double *__restrict__ partial) {
+    constexpr int NV = TN / 2;
+    constexpr int UNR = 4; // row pairs in flight per lane
+    double acc_s[FA_MAX_AGENTS_DEV], acc_q[FA_MAX_AGENTS_DEV], piv[FA_MAX_AGENTS_DEV];
+#pragma unroll
+    for (int i = 0; i < FA_MAX_AGENTS_DEV; ++i) {
+        acc_s[i] = 0.0; acc_q[i] = 0.0;
+        piv[i] = i < TN ? (double)(returns[i] - value_preds[i]) : 0.0;
+    }
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long p0 = (long long)blockIdx.x * blockDim.x + threadIdx.x; p0 < row_pairs; p0 += stride * UNR) {
+        float4 rr[UNR][NV], vv[UNR][NV];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const long long p = p0 + u * stride;
+            const long long pc = p < row_pairs ? p : p0; // clamped: loaded, not accumulated
+            const float4 *r4 = reinterpret_cast<const float4 *>(returns + pc * 2 * TN);
+            const float4 *v4 = reinterpret_cast<const float4 *>(value_preds + pc * 2 * TN);
+#pragma unroll
+            for (int q = 0; q < NV; ++q) { rr[u][q] = r4[q]; vv[u][q] = v4[q]; }
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            if (p0 + u * stride < row_pairs) {
+#pragma unroll
+                for (int q = 0; q < NV; ++q) {
+                    const float a4[4] = {rr[u][q].x - vv[u][q].x, rr[u][q].y - vv[u][q].y, rr[u][q].z - vv[u][q].z,
+                                         rr[u][q].w - vv[u][q].w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int i = (4 * q + j) % TN; // folds to a constant after unrolling
+                        const double d = (double)a4[j] - piv[i];
+                        acc_s[i] += d;
+                        acc_q[i] = __fma_rn(d, d, acc_q[i]);
+                    }
+                }
+            }
+        }
+    }
+    fa_adv_onepass_finish(acc_s, acc_q, TN, partial);
+}
+
 // stats[i] = {n, sum, 0} (PASS 0) / stats[i][2] = ssd (PASS 1).  One wave per agent: lane l
 // folds partials l, l+64, ... in order, then a fixed shuffle tree => reproducible.
 template <int PASS>
@@ -315,6 +446,24 @@ hipError_t fa_launch_gae(const float *rewards, const float *value_preds, const f
         hipLaunchKernelGGL(fa_gae_kernel, dim3(grid), dim3(64), 0, st, rewards, value_preds, masks, returns,
                            done, T, E, N, (float)gamma, (float)(gamma * tau));
     }
+    return hipGetLastError();
+}
+
+// one-pass moments; `partial` must hold nblocks * N * 2 doubles, nblocks <= 64 * FA_ADV_FOLD
+hipError_t fa_launch_adv_onepass(const float *returns, const float *value_preds, long long rows, int N, double *partial,
+                                 int nblocks, double *moments_out, double *mean_out, double *std_out, hipStream_t st) {
+    const bool vec = (rows % 2 == 0) && ((((uintptr_t)returns | (uintptr_t)value_preds) & 15) == 0);
+    if (nblocks > 64 * FA_ADV_FOLD) nblocks = 64 * FA_ADV_FOLD;
+    if (vec && N == 6)
+        hipLaunchKernelGGL((fa_adv_onepass_vec_kernel<6>), dim3(nblocks), dim3(256), 0, st, returns, value_preds, rows / 2,
+                           partial);
+    else if (vec && N == 10)
+        hipLaunchKernelGGL((fa_adv_onepass_vec_kernel<10>), dim3(nblocks), dim3(256), 0, st, returns, value_preds, rows / 2,
+                           partial);
+    else
+        hipLaunchKernelGGL(fa_adv_onepass_kernel, dim3(nblocks), dim3(256), 0, st, returns, value_preds, rows, N, partial);
+    hipLaunchKernelGGL(fa_adv_onepass_final_kernel, dim3(1), dim3(64 * N), 0, st, partial, nblocks, N, returns, value_preds,
+                       (double)rows, moments_out, mean_out, std_out);
     return hipGetLastError();
 }
 

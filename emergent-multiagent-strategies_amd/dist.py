@@ -47,6 +47,21 @@ def adv_mean_std(eng, group=None):
     return eng.adv_merge(buf)
 
 
+def gae_adv_mean_std(eng, gamma=0.99, tau=0.95, group=None):
+    """compute_returns (GAE) + the global per-agent advantage mean / unbiased std in one pass over
+    the rollout buffers (fa_gae_moments: three launches); with several ranks additionally ONE all-gather
+    of the local (N,3) moments and the exact merge kernel."""
+    mom, mean, std = eng.gae_moments(gamma, tau)
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
+        return mean, std
+    world = dist.get_world_size(group)
+    buf = getattr(eng, "_adv_gather", None)
+    if buf is None or buf.shape[0] != world:
+        buf = eng._adv_gather = torch.zeros((world, eng.N, 3), dtype=torch.float64, device=eng.device)
+    dist.all_gather_into_tensor(buf.view(-1), mom.view(-1), group=group)
+    return eng.adv_merge(buf)
+
+
 def merge_moments(gathered):
     """Host/torch restatement of fa_adv_merge (tests): gathered (W, N, 3) -> mean, std."""
     W, N, _ = gathered.shape

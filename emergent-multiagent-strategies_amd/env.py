@@ -154,6 +154,17 @@ class BatchedFortAttack(object):
     def gae(self, gamma=0.99, tau=0.95):
         _lib.check(self._lib.fa_gae(self._h, float(gamma), float(tau), _stream()), "fa_gae")
 
+    def gae_moments(self, gamma=0.99, tau=0.95):
+        """fa_gae_moments: GAE, then the per-agent advantage moments in one pass.  Returns (moments (N,3)
+        {n, mean, M2}, mean (N,), std (N,)) of this handle's samples, float64 on device."""
+        if not hasattr(self, "_gae_mom"):
+            self._gae_mom = torch.zeros((self.N, 3), dtype=torch.float64, device=self.device)
+        if not hasattr(self, "_adv_ms"):
+            self._adv_ms = torch.zeros((2, self.N), dtype=torch.float64, device=self.device)
+        _lib.check(self._lib.fa_gae_moments(self._h, float(gamma), float(tau), _ptr(self._gae_mom),
+                                            _ptr(self._adv_ms[0]), _ptr(self._adv_ms[1]), _stream()), "fa_gae_moments")
+        return self._gae_mom, self._adv_ms[0], self._adv_ms[1]
+
     def adv_stats(self, pass_, mean=None, out=None):
         """fa_adv_stats.  pass 0 fills out[i] = {n, sum(A), 0}; pass 1 (needs `mean`) writes only
         out[i][2] = sum((A-mean)^2) -- hand it pass 0's buffer to get the full triple."""

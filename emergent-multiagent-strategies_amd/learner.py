@@ -20,7 +20,7 @@ import torch.distributed as dist
 import torch.nn as nn
 from torch._utils import _flatten_dense_tensors, _unflatten_dense_tensors
 
-from .dist import adv_mean_std
+from .dist import gae_adv_mean_std
 from .mpnn import MPNN, TwinMPNN
 from .storage import JointRolloutStorage
 
@@ -238,7 +238,8 @@ class BatchedLearner(object):
                                                                                    obs[:, opp_sl])
                     else:
                         st.value_preds[self.T, :, own_sl] = pol.get_value(obs[:, own_sl], obs[:, opp_sl])
-        self.eng.gae(self.gamma, self.tau)
+        # compute_returns + the advantage mean / std of ppo.py:121-123 (over ALL ranks) in one pass
+        self._adv_mean_std = gae_adv_mean_std(self.eng, self.gamma, self.tau, self.group)
         # train_fortattack.py:88: episode_rewards += reward * masks (alive before the step)
         self.episode_rewards = (st.rewards * st.masks[1:]).sum(0)[..., 0]
 
@@ -256,7 +257,7 @@ class BatchedLearner(object):
     def update(self, train_guards_only=False):
         """-> float tensor (n_trained_teams, 3) = mean (value_loss, action_loss, entropy)."""
         st, T, E = self.storage, self.T, self.E
-        mean, std = adv_mean_std(self.eng, self.group)          # ppo.py:121-123 over ALL ranks
+        mean, std = self._adv_mean_std                           # ppo.py:121-123, from collect()
         self.eng.adv_normalize(mean, std, out=self.adv)          # ppo.py:123
         flat = lambda t: t.view(T * E, *t.shape[2:])
         obs_f, act_f = flat(st.obs[:-1]), flat(st.actions)

@@ -183,6 +183,13 @@ int fa_collect_reset(fa_env *env, void *stream);
  * value_preds[T] must hold V(obs[T]).  Reproduces quirk Q7 (returns[end_pt] not
  * recomputed) exactly. */
 int fa_gae(fa_env *env, double gamma, double tau, void *stream);
+/* fa_gae followed by the advantage statistics of ppo.py:121-123 in ONE pass over the buffers
+ * (instead of the two passes + two folds of fa_adv_stats): per agent, fp64 sums of (A - P) and
+ * (A - P)^2 around a pivot P that is an actual sample (no cancellation), folded over the
+ * workgroups in a fixed order -- bitwise reproducible.  Three launches.  Writes
+ * moments[i] = {n, mean, M2} (the fa_adv_moments / fa_adv_merge format), mean[i] and the unbiased
+ * std[i] of THIS handle's samples; any of the three may be null.  Device pointers. */
+int fa_gae_moments(fa_env *env, double gamma, double tau, double *moments, double *mean, double *std_, void *stream);
 /* Advantage statistics of JointPPO.update (rlcore/algo/ppo.py:121-123), per agent, in
  * fp64: pass 0 writes stats[i] = {n, sum(A), 0}; pass 1 reads mean[i] and writes
  * only stats[i][2] = sum((A-mean)^2) (stats[i][0..1] are left as they are).  A = returns[:-1] - value_preds[:-1].

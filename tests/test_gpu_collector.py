@@ -166,6 +166,50 @@ def test_fused_rollout_equals_per_step_launches(fa, G, A, E, T, chunk):
     assert int(sa.done.sum()) > 0
 
 
+@pytest.mark.parametrize("E,G,A,T,shift", [(300, 3, 3, 64, 0.0), (64, 5, 5, 128, 0.0), (4096, 3, 3, 128, 0.0),
+                                             (37, 2, 5, 33, 0.0),           # ragged: 259 columns, N = 7
+                                             (500, 3, 3, 48, 1000.0)])      # |mean| >> std: no cancellation
+def test_gae_moments_one_pass_equals_gae_plus_two_pass(fa, E, G, A, T, shift):
+    """fa_gae_moments (GAE, then one-pass advantage moments) == fa_gae followed
+    by the two-pass statistics: returns bit for bit, moments to fp64 rounding, run-to-run identical."""
+    import collector_oracle as co
+    N = G + A
+    rng = np.random.RandomState(E + T)
+    eng = fa.BatchedFortAttack(E, G, A, 50)
+    st = fa.JointRolloutStorage(T, E, N, device="cuda")
+    eng.bind_storage(st)
+    data = dict(rewards=rng.randn(T, E, N, 1).astype(np.float32),
+                value_preds=(rng.randn(T + 1, E, N, 1) - shift).astype(np.float32),
+                masks=(rng.rand(T + 1, E, N, 1) > 0.2).astype(np.float32),
+                returns=rng.randn(T + 1, E, N, 1).astype(np.float32),   # stale entries of the previous update (Q7)
+                done=(rng.rand(T, E) < 0.05).astype(np.uint8))
+
+    def load():
+        for k, v in data.items():
+            getattr(st, k).copy_(_t(v))
+
+    load()
+    eng.gae(0.99, 0.95)
+    ret_ref = st.returns.clone()
+    mom_ref = eng.adv_moments().clone()
+    mean_ref, std_ref = [x.clone() for x in eng.adv_mean_std()]
+    load()
+    mom, mean, std = [x.clone() for x in eng.gae_moments(0.99, 0.95)]
+    assert torch.equal(st.returns, ret_ref)
+    assert torch.equal(mom[:, 0], mom_ref[:, 0]) and float(mom[0, 0]) == T * E
+    assert torch.allclose(mean, mean_ref, rtol=1e-12, atol=1e-13)
+    assert torch.allclose(std, std_ref, rtol=1e-12, atol=0)
+    assert torch.allclose(mom[:, 2], mom_ref[:, 2], rtol=1e-12, atol=0)
+    for i in range(N):                                                    # and against numpy in fp64
+        a = (ret_ref[:-1, :, i].cpu().numpy() - data["value_preds"][:-1, :, i]).astype(np.float32).astype(np.float64)
+        assert abs(float(mean[i]) - a.mean()) <= 1e-12 * max(1.0, abs(a.mean()))
+        assert abs(float(std[i]) - a.std(ddof=1)) <= 1e-11 * a.std(ddof=1)
+    for _ in range(3):
+        load()
+        m2, mean2, std2 = eng.gae_moments(0.99, 0.95)
+        assert torch.equal(m2, mom) and torch.equal(mean2, mean) and torch.equal(std2, std)   # reproducible
+
+
 def test_moments_and_merge_equal_global_two_pass(fa):
     """fa_adv_moments + fa_adv_merge (the one-collective multi-GPU form): three 'ranks' worth of
     data merged on the device == the two-pass statistics of the concatenation."""
