@@ -15,7 +15,8 @@
 // and the accumulator restarts at 0 for the segment below it.
 // float32 throughout, operation order of storage.py:63-66; gamma and gamma*tau are
 // rounded to float32 once (torch scalar * tensor).
-#define FA_GAE_CHUNK 32
+#define FA_GAE_CHUNK 16
+struct FaGaeChunk { float r[FA_GAE_CHUNK], v[FA_GAE_CHUNK], m[FA_GAE_CHUNK]; uint8_t d[FA_GAE_CHUNK]; };
 __global__ __launch_bounds__(64) void fa_gae_kernel(const float *__restrict__ rewards,
                                                     const float *__restrict__ value_preds,
                                                     const float *__restrict__ masks,
@@ -29,40 +30,47 @@ __global__ __launch_bounds__(64) void fa_gae_kernel(const float *__restrict__ re
     float gae = 0.0f;
     float v_next = value_preds[(long long)T * EN + col];
     float m_next = masks[(long long)T * EN + col];
-    // the scan is a 2-op dependent chain per step; the loads do not depend on it, so a
-    // chunk's 4 x 8 loads are issued together and the chain runs out of registers.
-    for (int t0 = T - 1; t0 >= 0; t0 -= FA_GAE_CHUNK) {
-        float r[FA_GAE_CHUNK], v[FA_GAE_CHUNK], m[FA_GAE_CHUNK];
-        bool skip[FA_GAE_CHUNK];
+    // The scan is a short dependent chain per step; the loads do not depend on it.  With one wave per
+    // SIMD (24 576 columns = 384 waves) the kernel is a sequence of load round trips, so the chunks are
+    // software-pipelined: chunk c+1's 4 x 16 loads are in flight while chunk c is scanned out of
+    // registers.  Loads are unconditional and clamped (a short-circuit on the done flag becomes a
+    // branch + vmcnt(0) per step and serialises the whole chunk).
+    auto load = [&](FaGaeChunk &c, int t0) {
 #pragma unroll
         for (int k = 0; k < FA_GAE_CHUNK; ++k) {
             const int t = t0 - k;
-            const bool in = t >= 0;
-            const long long o = (long long)(in ? t : 0) * EN + col;
-            r[k] = rewards[o];
-            v[k] = value_preds[o];
-            m[k] = masks[o];
-            // unconditional, clamped load (a short-circuit here becomes a branch + vmcnt(0) per
-            // step and serialises the whole chunk)
-            const uint8_t dflag = done[(long long)(t > 0 ? t - 1 : 0) * E + e];
-            skip[k] = (t > 0) & (dflag != 0);
+            const long long o = (long long)(t >= 0 ? t : 0) * EN + col;
+            c.r[k] = rewards[o];
+            c.v[k] = value_preds[o];
+            c.m[k] = masks[o];
+            c.d[k] = done[(long long)(t > 0 ? t - 1 : 0) * E + e];
         }
+    };
+    auto scan = [&](const FaGaeChunk &c, int t0) {
 #pragma unroll
         for (int k = 0; k < FA_GAE_CHUNK; ++k) {
             const int t = t0 - k;
             if (t >= 0) {
-                const float delta = r[k] + g32 * v_next * m_next - v[k];
+                const float delta = c.r[k] + g32 * v_next * m_next - c.v[k];
                 const float g = delta + gt32 * m_next * gae;
-                if (skip[k]) {
+                if ((t > 0) & (c.d[k] != 0)) {
                     gae = 0.0f;
                 } else {
                     gae = g;
-                    returns[(long long)t * EN + col] = g + v[k];
+                    returns[(long long)t * EN + col] = g + c.v[k];
                 }
-                v_next = v[k];
-                m_next = m[k];
+                v_next = c.v[k];
+                m_next = c.m[k];
             }
         }
+    };
+    FaGaeChunk ca, cb;
+    load(ca, T - 1);
+    for (int t0 = T - 1; t0 >= 0; t0 -= 2 * FA_GAE_CHUNK) {
+        load(cb, t0 - FA_GAE_CHUNK);
+        scan(ca, t0);
+        load(ca, t0 - 2 * FA_GAE_CHUNK);
+        scan(cb, t0 - FA_GAE_CHUNK);
     }
 }
 
