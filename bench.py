@@ -31,6 +31,18 @@ import torch.distributed as dist  # noqa: E402
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s measured copy
 
 
+def measured_stream():
+    """What plain streaming kernels sustain on the box (tools/ubench_hbm.hip, committed record):
+    context for `peak` (the 8 TB/s vendor figure the roofline is priced against)."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r01_hbm_stream.json")))
+        return {"copy": max(v for k, v in d.items() if k.startswith("copy")),
+                "triad": max(v for k, v in d.items() if k.startswith("triad")),
+                "read": max(v for k, v in d.items() if k.startswith("read"))}
+    except Exception:
+        return None
+
+
 def algorithmic_bytes_per_env_step(n_agents):
     """SURVEY.md 8(d) / BASELINE.md section 5: per agent 2*(6 f64 + 1 B alive) state r+w
     + 8 B action + 24 B obs + 4 B reward + 4 B mask = 138 B; per env 9 B."""
@@ -220,6 +232,7 @@ def main():
                                                        A if (G, A) in ((3, 3), (5, 5)) else 0),
                 "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                 "traffic": traffic, "traffic_source": traffic_src,
+                "measured_stream_GBps": measured_stream(),
                 "algorithmic_bytes_per_launch": bytes_per_launch,
                 "algorithmic_bytes_per_env_step": algorithmic_bytes_per_env_step(N),
                 "env_steps_per_launch": E * (T // launches_per_rollout),
