@@ -262,6 +262,75 @@ __device__ __forceinline__ bool laser_hit(double x1, double y1, double x2, doubl
     return ((mn >= 0) | (mx <= 0)) & (det != 0);
 }
 
+// ---- pieces of World.step shared by the step kernels -----------------------------------------
+// core.py:440-456 get_collision_force for one pair within range (d2 = dx*dx + dy*dy of the pair):
+// force on the agent at the +delta end; the partner's is its exact negative.
+__device__ __forceinline__ void fa_contact_force(const FaDerived &c, double dx, double dy, double d2, double &fx, double &fy) {
+    const double dist = sqrt_rn(d2);
+    const double pen = softplus_pen(div_rn(-(dist - c.dist_min), c.contact_margin), c.contact_margin);
+    fx = div_rn(c.contact_force * dx, dist) * pen;
+    fy = div_rn(c.contact_force * dy, dist) * pen;
+}
+// core.py:246-252 + :459-472 wall force of a living agent: (fx1 - fx2, fy1 - fy2), exactly +0.0 off the
+// walls.  A wall whose clearance is > 1000*margin contributes exactly +0.0 and its division is skipped;
+// measured: per-wall branches beat four unconditional ILP divisions (typically only one or two walls are
+// touched by some lane of the wave).
+__device__ __forceinline__ void fa_wall_force(const FaDerived &c, double px, double py, double &wx, double &wy) {
+    wx = 0.0;
+    wy = 0.0;
+    const double k = c.contact_margin, size = c.agent_size;
+    const double d0 = px - size - c.wall_xmin, d1 = c.wall_xmax - px - size;
+    const double d2 = py - size - c.wall_ymin, d3 = c.wall_ymax - py - size;
+    const bool w0 = !(d0 > c.wall_skip), w1 = !(d1 > c.wall_skip);
+    const bool w2 = !(d2 > c.wall_skip), w3 = !(d3 > c.wall_skip);
+    if (w0 || w1 || w2 || w3) {
+        double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0;
+        if (w0) p0 = softplus_pen(div_rn(-d0, k), k);
+        if (w1) p1 = softplus_pen(div_rn(-d1, k), k);
+        if (w2) p2 = softplus_pen(div_rn(-d2, k), k);
+        if (w3) p3 = softplus_pen(div_rn(-d3, k), k);
+        wx = c.contact_force * p0 - c.contact_force * p1;
+        wy = c.contact_force * p2 - c.contact_force * p3;
+    }
+}
+// fortattack_env_v1.py:87-188 reward of one agent after World.step.  attacker_reward (:94-128) and
+// guard_reward (:130-188) as one select chain: both are a sum of six terms added left to right --
+// attacker r0..r5; guard r0, r3..r7 (its r1, r2, r8 are literal zeros and x + 0.0 == x) -- so the
+// per-team terms are selected and the additions are shared.  No divergent team branch.
+// `prev`: prevDist (NaN == None).  The literals come in as arguments so that a caller can keep them in
+// VGPRs (fort_dim, 0.3, 10, 3, 0.1).
+__device__ __forceinline__ double fa_reward(bool is_att, bool rewarded, double prev, double dist_door, bool shoot, bool hit,
+                                            bool was_hit, int n_alive_att, bool any_in_fort, double k_fort, double k_03,
+                                            double k_10, double k_3, double k_01) {
+    const bool has_prev = !(prev != prev);
+    const double g0 = ((dist_door > k_03) & (prev <= k_03)) ? -1.0 : (((dist_door <= k_03) & (prev > k_03)) ? 1.0 : 0.0);
+    const double t0 = has_prev ? (is_att ? 2 * (prev - dist_door) : g0) : 0.0;
+    const bool c1 = is_att ? (dist_door < k_fort) : ((n_alive_att != 0) & any_in_fort);
+    const double t1 = c1 ? (is_att ? k_10 : -k_10) : 0.0;
+    const double t2 = shoot ? (is_att ? -1.0 : -k_01) : 0.0;
+    const double t3 = hit ? k_3 : 0.0;
+    const double t4 = was_hit ? -k_3 : 0.0;
+    const double t5 = (n_alive_att == 0) ? (is_att ? -k_10 : k_10) : 0.0;
+    return rewarded ? (t0 + t1 + t2 + t3 + t4 + t5) : 0.0;
+}
+// observation row (fortattack_env_v1.py:238): [alive, px, py, ang, vx, vy]
+__device__ __forceinline__ void fa_store_obs(float *o32, double *o64, bool alive, double px, double py, double ang, double vx,
+                                             double vy) {
+    const double al = alive ? 1.0 : 0.0;
+    if (o32) {
+        float2 *o = reinterpret_cast<float2 *>(o32);
+        o[0] = make_float2((float)al, (float)px);
+        o[1] = make_float2((float)py, (float)ang);
+        o[2] = make_float2((float)vx, (float)vy);
+    }
+    if (o64) {
+        double2 *o = reinterpret_cast<double2 *>(o64);
+        o[0] = make_double2(al, px);
+        o[1] = make_double2(py, ang);
+        o[2] = make_double2(vx, vy);
+    }
+}
+
 // COLLECT: the four trainer rows (obs32, rew32, mask32, done) are all present and nothing
 // else is: their stores are then unconditional, which lets the compiler wait for the
 // prefetched action with vmcnt(#stores) instead of draining the store queue every step.
@@ -316,27 +385,10 @@ __global__ __launch_bounds__(NW * FA_WAVE) void fa_step_kernel(FaStepArgs a) {
         if (force_wave) {
             constexpr int NT = TG + TA;
             const int ns = a.nsteps;
-            // wall force of the lane's agent (core.py:246-252 + :459-472): (fx1 - fx2, fy1 - fy2),
-            // exactly +0.0 off the walls
             auto wall_force = [&](bool alive0, double px, double py, double &wx, double &wy) {
                 wx = 0.0;
                 wy = 0.0;
-                if (alive0) {
-                    const double k = c.contact_margin, size = c.agent_size;
-                    const double d0 = px - size - c.wall_xmin, d1 = c.wall_xmax - px - size;
-                    const double d2 = py - size - c.wall_ymin, d3 = c.wall_ymax - py - size;
-                    const bool w0 = !(d0 > c.wall_skip), w1 = !(d1 > c.wall_skip);
-                    const bool w2 = !(d2 > c.wall_skip), w3 = !(d3 > c.wall_skip);
-                    if (w0 || w1 || w2 || w3) {
-                        double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0;
-                        if (w0) p0 = softplus_pen(div_rn(-d0, k), k);
-                        if (w1) p1 = softplus_pen(div_rn(-d1, k), k);
-                        if (w2) p2 = softplus_pen(div_rn(-d2, k), k);
-                        if (w3) p3 = softplus_pen(div_rn(-d3, k), k);
-                        wx = c.contact_force * p0 - c.contact_force * p1;
-                        wy = c.contact_force * p2 - c.contact_force * p3;
-                    }
-                }
+                if (alive0) fa_wall_force(c, px, py, wx, wy);
             };
             if (THREE && wave_id == 2) {
                 // ---- the wall wave ---------------------------------------------------------------
@@ -377,10 +429,7 @@ __global__ __launch_bounds__(NW * FA_WAVE) void fa_step_kernel(FaStepArgs a) {
                     fxj[j] = 0.0;
                     fyj[j] = 0.0;
                     if (alive0 && j != i && ((grp_alive0 >> j) & 1ull) && !(d2 > c.contact_skip_d2)) {
-                        const double dist = sqrt_rn(d2);
-                        const double pen = softplus_pen(div_rn(-(dist - c.dist_min), c.contact_margin), c.contact_margin);
-                        fxj[j] = div_rn(c.contact_force * dx, dist) * pen;
-                        fyj[j] = div_rn(c.contact_force * dy, dist) * pen;
+                        fa_contact_force(c, dx, dy, d2, fxj[j], fyj[j]);
                     }
                 }
                 double wx = 0.0, wy = 0.0;
@@ -599,10 +648,10 @@ __global__ __launch_bounds__(NW * FA_WAVE) void fa_step_kernel(FaStepArgs a) {
                         // exp(t) == +0 => penetration == +0.0 => force == +-0.0, and F (never
                         // -0.0) is unchanged by adding it.
                         if (j == i || !((grp_alive1 >> j) & 1ull) || d2s[j] > c.contact_skip_d2) continue;
-                        const double dist = sqrt_rn(d2s[j]);
-                        const double pen = softplus_pen(div_rn(-(dist - c.dist_min), c.contact_margin), c.contact_margin);
-                        Fx = div_rn(c.contact_force * dxs[j], dist) * pen + Fx;
-                        Fy = div_rn(c.contact_force * dys[j], dist) * pen + Fy;
+                        double fx, fy;
+                        fa_contact_force(c, dxs[j], dys[j], d2s[j], fx, fy);
+                        Fx = fx + Fx;
+                        Fy = fy + Fy;
                     }
                 } else {
                     for (int j = 0; j < N; ++j) {
@@ -610,33 +659,18 @@ __global__ __launch_bounds__(NW * FA_WAVE) void fa_step_kernel(FaStepArgs a) {
                         const double dx = px - s_px[gbase + j], dy = py - s_py[gbase + j];
                         const double d2 = dx * dx + dy * dy;
                         if (d2 > c.contact_skip_d2) continue; // exact skip, see above
-                        const double dist = sqrt_rn(d2);
-                        const double pen = softplus_pen(div_rn(-(dist - c.dist_min), c.contact_margin), c.contact_margin);
-                        Fx = div_rn(c.contact_force * dx, dist) * pen + Fx;
-                        Fy = div_rn(c.contact_force * dy, dist) * pen + Fy;
+                        double fx, fy;
+                        fa_contact_force(c, dx, dy, d2, fx, fy);
+                        Fx = fx + Fx;
+                        Fy = fy + Fy;
                     }
                 }
                 // core.py:246-252 + :459-472 walls
                 {
-                    const double k = c.contact_margin, size = c.agent_size;
-                    const double d0 = px - size - c.wall_xmin, d1 = c.wall_xmax - px - size;
-                    const double d2 = py - size - c.wall_ymin, d3 = c.wall_ymax - py - size;
-                    // a wall whose clearance is > 1000*margin contributes exactly +0.0 and its division
-                    // is skipped; measured: per-wall branches beat four unconditional ILP divisions
-                    // (typically only one or two walls are touched by some lane of the wave)
-                    const bool w0 = !(d0 > c.wall_skip), w1 = !(d1 > c.wall_skip);
-                    const bool w2 = !(d2 > c.wall_skip), w3 = !(d3 > c.wall_skip);
-                    if (w0 || w1 || w2 || w3) {
-                        double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0;
-                        if (w0) p0 = softplus_pen(div_rn(-d0, k), k);
-                        if (w1) p1 = softplus_pen(div_rn(-d1, k), k);
-                        if (w2) p2 = softplus_pen(div_rn(-d2, k), k);
-                        if (w3) p3 = softplus_pen(div_rn(-d3, k), k);
-                        const double fx1 = c.contact_force * p0, fx2 = c.contact_force * p1;
-                        const double fy1 = c.contact_force * p2, fy2 = c.contact_force * p3;
-                        Fx = (fx1 - fx2) + Fx;
-                        Fy = (fy1 - fy2) + Fy;
-                    }
+                    double wx, wy;
+                    fa_wall_force(c, px, py, wx, wy);
+                    Fx = wx + Fx;
+                    Fy = wy + Fy;
                 }
                 } // !TWO
                 // core.py:324-338 integrate_state (mass == 1.0: F/1.0 is exact)
@@ -665,20 +699,8 @@ __global__ __launch_bounds__(NW * FA_WAVE) void fa_step_kernel(FaStepArgs a) {
                 __ballot(is_att && alive1 && dist_door < c.fort_dim);
             const bool any_in_fort = ((in_fort_b >> gbase) & grp_mask) != 0ull;
             const bool rewarded = (alive1 || just_died);
-            const bool has_prev = !(prev != prev); // NaN encodes prevDist None
-            // attacker_reward (:94-128) and guard_reward (:130-188) as one select chain: both are
-            // a sum of six terms added left to right -- attacker r0..r5; guard r0, r3..r7 (its r1,
-            // r2, r8 are literal zeros and x + 0.0 == x) -- so the per-team terms are selected and
-            // the additions are shared.  No divergent team branch.
-            const double g0 = ((dist_door > 0.3) & (prev <= 0.3)) ? -1.0 : (((dist_door <= 0.3) & (prev > 0.3)) ? 1.0 : 0.0);
-            const double t0 = has_prev ? (is_att ? 2 * (prev - dist_door) : g0) : 0.0;
-            const bool c1 = is_att ? (dist_door < c.fort_dim) : ((n_alive_att != 0) & any_in_fort);
-            const double t1 = c1 ? (is_att ? 10.0 : -10.0) : 0.0;
-            const double t2 = shoot ? (is_att ? -1.0 : -0.1) : 0.0;
-            const double t3 = hit ? 3.0 : 0.0;
-            const double t4 = was_hit ? -3.0 : 0.0;
-            const double t5 = (n_alive_att == 0) ? (is_att ? -10.0 : 10.0) : 0.0;
-            const double rew = rewarded ? (t0 + t1 + t2 + t3 + t4 + t5) : 0.0;
+            const double rew = fa_reward(is_att, rewarded, prev, dist_door, shoot, hit, was_hit, n_alive_att, any_in_fort,
+                                         c.fort_dim, 0.3, 10.0, 3.0, 0.1);
             prev = rewarded ? dist_door : prev;
 
             // ---- fortattack.py:202-225 _get_done, :171 time_step += 1 ------------------
@@ -751,20 +773,9 @@ __global__ __launch_bounds__(NW * FA_WAVE) void fa_step_kernel(FaStepArgs a) {
 
         // ---- observation row (fortattack_env_v1.py:238) ------------------------------------
         if ((!RESET_ONLY || do_reset)) {
-            const double al = alive ? 1.0 : 0.0;
             const size_t o6 = ((size_t)s * EN + idx) * 6;
-            if (COLLECT || a.obs32) {
-                float2 *o = reinterpret_cast<float2 *>(a.obs32 + o6);
-                o[0] = make_float2((float)al, (float)px);
-                o[1] = make_float2((float)py, (float)ang);
-                o[2] = make_float2((float)vx, (float)vy);
-            }
-            if (!COLLECT && a.obs64) {
-                double2 *o = reinterpret_cast<double2 *>(a.obs64 + o6);
-                o[0] = make_double2(al, px);
-                o[1] = make_double2(py, ang);
-                o[2] = make_double2(vx, vy);
-            }
+            fa_store_obs((COLLECT || a.obs32) ? a.obs32 + o6 : nullptr, (!COLLECT && a.obs64) ? a.obs64 + o6 : nullptr,
+                         alive, px, py, ang, vx, vy);
         }
         // next iteration restages LDS: keep its writes behind this iteration's reads
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -879,22 +890,7 @@ __global__ __launch_bounds__((NPW + 2) * FA_WAVE, MINW) void fa_step_pipe_kernel
             s_U[1][lane] = u1 * c.accel + 0.0;
             s_U[2][lane] = rot;
             double wx = 0.0, wy = 0.0;
-            if (!(FA_ABL & 16) && alive0) { // core.py:246-252 + :459-472; exactly +0.0 off the walls
-                const double k = c.contact_margin, size = c.agent_size;
-                const double d0 = px - size - c.wall_xmin, d1 = c.wall_xmax - px - size;
-                const double d2 = py - size - c.wall_ymin, d3 = c.wall_ymax - py - size;
-                const bool w0 = !(d0 > c.wall_skip), w1 = !(d1 > c.wall_skip);
-                const bool w2 = !(d2 > c.wall_skip), w3 = !(d3 > c.wall_skip);
-                if (w0 || w1 || w2 || w3) {
-                    double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0;
-                    if (w0) p0 = softplus_pen(div_rn(-d0, k), k);
-                    if (w1) p1 = softplus_pen(div_rn(-d1, k), k);
-                    if (w2) p2 = softplus_pen(div_rn(-d2, k), k);
-                    if (w3) p3 = softplus_pen(div_rn(-d3, k), k);
-                    wx = c.contact_force * p0 - c.contact_force * p1;
-                    wy = c.contact_force * p2 - c.contact_force * p3;
-                }
-            }
+            if (!(FA_ABL & 16) && alive0) fa_wall_force(c, px, py, wx, wy); // core.py:246-252 + :459-472
             s_W[0][lane] = wx;
             s_W[1][lane] = wy;
             FA_TICK(17)
@@ -952,22 +948,10 @@ __global__ __launch_bounds__((NPW + 2) * FA_WAVE, MINW) void fa_step_pipe_kernel
             const bool any_in_fort = ((in_fort_b >> gbase) & grp_mask) != 0ull;
             const bool do_reset = done && a.auto_reset != 0;
             // ---- rewards (fortattack_env_v1.py:87-188), after World.step ----------------------
-            // attacker_reward (:94-128) and guard_reward (:130-188) as one select chain: both are
-            // a sum of six terms added left to right -- attacker r0..r5; guard r0, r3..r7 (its r1,
-            // r2, r8 are literal zeros and x + 0.0 == x) -- so the per-team terms are selected and
-            // the additions are shared.
             const bool just_died = alive0 && was_hit;
             const bool rewarded = (alive1 || just_died);
-            const bool has_prev = !(prev != prev); // NaN encodes prevDist None
-            const double g0 = ((dist_door > k_03) & (prev <= k_03)) ? -1.0 : (((dist_door <= k_03) & (prev > k_03)) ? 1.0 : 0.0);
-            const double t0 = has_prev ? (is_att ? 2 * (prev - dist_door) : g0) : 0.0;
-            const bool c1 = is_att ? (dist_door < k_fort) : ((n_alive_att != 0) & any_in_fort);
-            const double t1 = c1 ? (is_att ? k_10 : -k_10) : 0.0;
-            const double t2 = shoot ? (is_att ? -1.0 : -k_01) : 0.0;
-            const double t3 = hit ? k_3 : 0.0;
-            const double t4 = was_hit ? -k_3 : 0.0;
-            const double t5 = (n_alive_att == 0) ? (is_att ? -k_10 : k_10) : 0.0;
-            const double rew = rewarded ? (t0 + t1 + t2 + t3 + t4 + t5) : 0.0;
+            const double rew = fa_reward(is_att, rewarded, prev, dist_door, shoot, hit, was_hit, n_alive_att, any_in_fort,
+                                         k_fort, k_03, k_10, k_3, k_01);
             prev = rewarded ? dist_door : prev;
             // ---- fortattack.py:202-225 _get_done bookkeeping --------------------------------------
             if (i == 0) {
@@ -1011,19 +995,8 @@ __global__ __launch_bounds__((NPW + 2) * FA_WAVE, MINW) void fa_step_pipe_kernel
             const bool alive_new = (s_mask[bo][0] >> lane) & 1ull;
             const double px = s_px[bo][lane], py = s_py[bo][lane], ang = s_ang[bo][lane];
             const double vx = s_vx[bo][lane], vy = s_vy[bo][lane];
-            const double al = alive_new ? 1.0 : 0.0;
-            if (COLLECT || a.obs32) {
-                float2 *ob = reinterpret_cast<float2 *>(p_obs);
-                ob[0] = make_float2((float)al, (float)px);
-                ob[1] = make_float2((float)py, (float)ang);
-                ob[2] = make_float2((float)vx, (float)vy);
-            }
-            if (!COLLECT && a.obs64) {
-                double2 *ob = reinterpret_cast<double2 *>(a.obs64 + row6);
-                ob[0] = make_double2(al, px);
-                ob[1] = make_double2(py, ang);
-                ob[2] = make_double2(vx, vy);
-            }
+            fa_store_obs((COLLECT || a.obs32) ? p_obs : nullptr, (!COLLECT && a.obs64) ? a.obs64 + row6 : nullptr, alive_new,
+                         px, py, ang, vx, vy);
             p_obs += EN * 6; row6 += (long long)EN * 6;
         };
         // wave 1 owns the env's reset stream during the launch (see ResetDraw)
@@ -1096,10 +1069,7 @@ __global__ __launch_bounds__((NPW + 2) * FA_WAVE, MINW) void fa_step_pipe_kernel
                 double fxv = 0.0, fyv = 0.0;
                 bool near = false;
                 if (!(FA_ABL & 8) && mine && alive0 && ((grp_alive0 >> j) & 1ull) && !(d2 > c.contact_skip_d2)) {
-                    const double dist = sqrt_rn(d2);
-                    const double pen = softplus_pen(div_rn(-(dist - c.dist_min), c.contact_margin), c.contact_margin);
-                    fxv = div_rn(c.contact_force * dx, dist) * pen;
-                    fyv = div_rn(c.contact_force * dy, dist) * pen;
+                    fa_contact_force(c, dx, dy, d2, fxv, fyv);
                     near = true;
                 }
                 if (mine) {
