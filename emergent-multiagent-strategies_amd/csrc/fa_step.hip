@@ -246,20 +246,26 @@ __device__ __forceinline__ double softplus_pen(double t, double k) {
     return v * k;
 }
 
-// core.py:384-390 laser_hit: lam = A^-1 (px,py,1), hit iff all lam >= 0 (Cramer's rule;
-// the reference's SVD pseudo-inverse is the exact inverse of this never-singular matrix).
-__device__ __forceinline__ bool laser_hit(double x1, double y1, double x2, double y2, double x3,
-                                          double y3, double px, double py) {
-    const double w1 = (x2 - px) * (y3 - py) - (x3 - px) * (y2 - py);
-    const double w2 = (x3 - px) * (y1 - py) - (x1 - px) * (y3 - py);
-    const double w3 = (x1 - px) * (y2 - py) - (x2 - px) * (y1 - py);
-    const double det = (w1 + w2) + w3;
-    // all lam >= 0  <=>  the w_i share the sign of det (their sum): decided from min / max of the
-    // three instead of six compares -- every fp64 compare lands in an SGPR mask and each mask
-    // AND is a VALU->SALU round trip for a wave that is alone on its SIMD.  (min >= 0 forces
-    // det >= 0 and max <= 0 forces det <= 0, so `det != 0` is all that is left to check.)
-    const double mn = fmin(fmin(w1, w2), w3), mx = fmax(fmax(w1, w2), w3);
-    return ((mn >= 0) | (mx <= 0)) & (det != 0);
+// ---- the laser test (core.py:373-390) in the shooter's frame ------------------------------------
+// The reference's triangle (get_tri_pts_arr) is the isosceles wedge with its apex at
+// q + size*(cos a, sin a), half-angle shootWin/2 about the heading a and its far edge perpendicular to
+// the heading at shootRad*cos(shootWin/2); laser_hit asks whether the target's barycentric coordinates
+// in it are all >= 0 (an SVD solve in the reference, Cramer's rule in the oracle).  With d = target -
+// apex, u = d.(cos a, sin a), v = d x (cos a, sin a):
+//     inside  <=>  u <= shootRad*cos(w/2)  and  |v| cos(w/2) <= u sin(w/2)
+// -- the same closed triangle, evaluated from (position, cos a, sin a) of the shooter instead of three
+// vertices: nothing but sin/cos of the heading to stage, 14 flops per test.  It can differ from the
+// vertex form only for a target within rounding (1e-16) of an edge, the class of deviation the heading
+// sin/cos already has; 0 differing flags against the goldens and the oracle.
+// Returns u and the two sides of the wedge inequality; hit = (u <= c.shoot_far) & (lhs <= rhs).
+__device__ __forceinline__ void fa_wedge(double size, double cos_hw, double sin_hw, double px, double py, double qx, double qy,
+                                         double cs, double sn, double &u, double &lhs, double &rhs) {
+    const double ax = qx + size * cs, ay = qy + size * sn; // == pt1 of core.py:375
+    const double dx = px - ax, dy = py - ay;
+    u = dx * cs + dy * sn;
+    const double v = dy * cs - dx * sn;
+    lhs = fabs(v) * cos_hw;
+    rhs = u * sin_hw;
 }
 
 // ---- pieces of World.step shared by the step kernels -----------------------------------------
@@ -375,7 +381,7 @@ __global__ __launch_bounds__(NW * FA_WAVE) void fa_step_kernel(FaStepArgs a) {
     const unsigned long long grp_mask = (1ull << N) - 1ull;
     const FaDerived &c = a.c;
 
-    __shared__ double s_px[FA_WAVE], s_py[FA_WAVE], s_tri[6][FA_WAVE];
+    __shared__ double s_px[FA_WAVE], s_py[FA_WAVE], s_cs[FA_WAVE], s_sn[FA_WAVE]; // positions, heading of shooters
     __shared__ int s_act[FA_ACT_BATCH][FA_WAVE];
     __shared__ double s_F[2][TWO ? FA_WAVE : 1];  // TWO: total force per lane, from the force wave
     __shared__ double s_W[2][THREE ? FA_WAVE : 1]; // THREE: wall force per lane, from the wall wave
@@ -509,7 +515,7 @@ __global__ __launch_bounds__(NW * FA_WAVE) void fa_step_kernel(FaStepArgs a) {
             u0 *= c.accel;
             u1 *= c.accel;
 
-            // ---- stage positions + laser triangles in LDS (core.py:373-382) ------------
+            // ---- stage positions + the shooters' heading sin/cos in LDS (core.py:373-382) ------------
             s_px[lane] = px;
             s_py[lane] = py;
             if constexpr (TWO) {
@@ -518,20 +524,11 @@ __global__ __launch_bounds__(NW * FA_WAVE) void fa_step_kernel(FaStepArgs a) {
                 FA_WG_BARRIER(); // (1) the force wave starts on this step's contacts and walls
             }
             const bool shooter = alive0 && shoot;
-            if (shooter) {
-                // one sincos; cos/sin(ang +- shootWin/2) by the angle-addition identities with
-                // host-evaluated cos/sin(shootWin/2).  Differs from evaluating cos(ang +- w/2)
-                // directly only in the last ulp, which can move a hit decision only for a target
-                // within ~1e-16 of a triangle edge (same class as libm-vs-libm differences).
+            if (shooter) { // the laser test needs the shooter's position and sin/cos of its heading (fa_wedge)
                 double sn, cs;
                 sincos_heading(ang, sn, cs);
-                const double x1 = px + c.agent_size * cs, y1 = py + c.agent_size * sn;
-                const double cp = cs * c.cos_hw - sn * c.sin_hw, sp = sn * c.cos_hw + cs * c.sin_hw;
-                const double cm = cs * c.cos_hw + sn * c.sin_hw, sm = sn * c.cos_hw - cs * c.sin_hw;
-                const double x2 = x1 + c.shoot_rad * cp, y2 = y1 + c.shoot_rad * sp;
-                const double x3 = x1 + c.shoot_rad * cm, y3 = y1 + c.shoot_rad * sm;
-                s_tri[0][lane] = x1; s_tri[1][lane] = y1; s_tri[2][lane] = x2;
-                s_tri[3][lane] = y2; s_tri[4][lane] = x3; s_tri[5][lane] = y3;
+                s_cs[lane] = cs;
+                s_sn[lane] = sn;
             }
             const unsigned long long shooters_b = __ballot(shooter);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -566,22 +563,21 @@ __global__ __launch_bounds__(NW * FA_WAVE) void fa_step_kernel(FaStepArgs a) {
                     is_att ? ((1ull << G) - 1ull) : (((1ull << A) - 1ull) << G);
                 constexpr int KT = TG > TA ? TG : TA;
                 if constexpr (KT != 0) {
-                    // compile-time team sizes: all opponent triangles are fetched from LDS in one
-                    // batch and the KT hit tests are independent instruction streams (ILP; this
-                    // wave is alone on its SIMD, so dependent fp64 latency is otherwise exposed)
-                    double tr[KT][6];
+                    // compile-time team sizes: all opponents are fetched from LDS in one batch
+                    double tr[KT][4];
                     bool hk[KT];
 #pragma unroll
                     for (int k = 0; k < KT; ++k) {
                         const int j = gbase + opp0 + (k < n_opp ? k : 0);
-#pragma unroll
-                        for (int q = 0; q < 6; ++q) tr[k][q] = s_tri[q][j];
+                        tr[k][0] = s_px[j]; tr[k][1] = s_py[j]; tr[k][2] = s_cs[j]; tr[k][3] = s_sn[j];
                     }
 #pragma unroll
                     for (int k = 0; k < KT; ++k) {
                         const int j = gbase + opp0 + k;
                         const bool cand = alive0 && k < n_opp && ((shooters_b >> j) & 1ull);
-                        hk[k] = cand & laser_hit(tr[k][0], tr[k][1], tr[k][2], tr[k][3], tr[k][4], tr[k][5], px, py);
+                        double u, lhs, rhs;
+                        fa_wedge(c.agent_size, c.cos_hw, c.sin_hw, px, py, tr[k][0], tr[k][1], tr[k][2], tr[k][3], u, lhs, rhs);
+                        hk[k] = cand & (u <= c.shoot_far) & (lhs <= rhs);
                     }
                     // the hit list of shooter k of either team is ballot k: pick the lane's own
                     // (uniform values, per-lane select), then one shift / mask / popcount
@@ -599,9 +595,11 @@ __global__ __launch_bounds__(NW * FA_WAVE) void fa_step_kernel(FaStepArgs a) {
                     for (int k = 0; k < KMAX; ++k) {
                         const int j = gbase + opp0 + k;
                         bool h = false;
-                        if (alive0 && k < n_opp && ((shooters_b >> j) & 1ull))
-                            h = laser_hit(s_tri[0][j], s_tri[1][j], s_tri[2][j], s_tri[3][j], s_tri[4][j],
-                                          s_tri[5][j], px, py);
+                        if (alive0 && k < n_opp && ((shooters_b >> j) & 1ull)) {
+                            double u, lhs, rhs;
+                            fa_wedge(c.agent_size, c.cos_hw, c.sin_hw, px, py, s_px[j], s_py[j], s_cs[j], s_sn[j], u, lhs, rhs);
+                            h = (u <= c.shoot_far) & (lhs <= rhs);
+                        }
                         const unsigned long long hb = __ballot(h);
                         if (k == team_idx) hit_cnt = __popcll((hb >> gbase) & opp_mask);
                         was_hit = was_hit || h;
@@ -1119,16 +1117,9 @@ __global__ __launch_bounds__((NPW + 2) * FA_WAVE, MINW) void fa_step_pipe_kernel
     int av[FA_ACT_BATCH];
 #pragma unroll
     for (int k = 0; k < FA_ACT_BATCH; ++k) av[k] = (k < ns) ? (int)act_ptr[(int64_t)k * a.as_t] : 0;
-    // ---- the laser test (core.py:373-390) in the shooter's frame -------------------------------
-    // The reference's triangle is the isosceles wedge with its apex at p + size*(cos a, sin a),
-    // half-angle shootWin/2 about the heading a and its far edge perpendicular to the heading at
-    // shootRad*cos(shootWin/2).  With d = target - apex, u = d.(cos a, sin a), v = d x (cos a, sin a):
-    //     inside  <=>  u <= shootRad*cos(w/2)  and  |v| cos(w/2) <= u sin(w/2)
-    // -- the same predicate as the barycentric test of fa_step_kernel / the oracle, evaluated
-    // from (apex, cos a, sin a) instead of three vertices: no triangle staging, 10 flops per test.
-    // It can differ from the vertex form only for a target within rounding (1e-16) of an edge.
-    // A target lane needs apex and sin/cos of its opponents: the apex goes through LDS inside this
-    // wave, sin/cos of the next heading comes from the last wave (constants after a reset).
+    // ---- the laser test (fa_wedge): a target lane needs position and heading sin/cos of its opponents.
+    // Positions go through LDS inside this wave; sin/cos of the next heading comes from the last wave
+    // (constants after a reset).
     constexpr int KT = TG > TA ? TG : TA;
     const int n_opp = is_att ? G : A, opp0 = is_att ? 0 : G;
     const int team_idx = is_att ? i - G : i;
@@ -1216,11 +1207,9 @@ __global__ __launch_bounds__((NPW + 2) * FA_WAVE, MINW) void fa_step_pipe_kernel
 #pragma unroll
             for (int k = 0; k < KT; ++k) {
                 const unsigned long long cand_m = (k < n_opp ? FA_M_NE_U(gw_sh & (1u << (opp0 + k)), 0) : 0ull) & alive0_m;
-                const double ax = oqx[k] + k_size * ocs[k], ay = oqy[k] + k_size * osn[k];
-                const double dx = px - ax, dy = py - ay;
-                const double u = dx * ocs[k] + dy * osn[k];
-                const double v = dy * ocs[k] - dx * osn[k];
-                hb[k] = cand_m & FA_M_LE_D(u, k_far) & FA_M_LE_D(fabs(v) * k_chw, u * k_shw);
+                double u, lhs, rhs;
+                fa_wedge(k_size, k_chw, k_shw, px, py, oqx[k], oqy[k], ocs[k], osn[k], u, lhs, rhs);
+                hb[k] = cand_m & FA_M_LE_D(u, k_far) & FA_M_LE_D(lhs, rhs);
             }
             // a shooter's hit list is the ballot of its team index, restricted to the opponents of its env
             int tix = team_idx;
