@@ -136,16 +136,21 @@ def test_collect_step_matches_plain_step(fa):
     assert torch.equal(st.masks[1:, :, :, 0], want)
 
 
-@pytest.mark.parametrize("G,A,E,T,chunk", [(3, 3, 500, 64, 64), (5, 5, 100, 48, 16), (3, 3, 4096, 128, 128)])
-def test_fused_rollout_equals_per_step_launches(fa, G, A, E, T, chunk):
-    """fa_collect_rollout (K env-steps in one launch, state in registers) is bit-identical
-    to K fa_collect_step launches -- storage rows, world state and RNG cursor."""
+@pytest.mark.parametrize("G,A,E,T,chunk,rng,max_t", [(3, 3, 500, 64, 64, "mt19937", 25), (5, 5, 100, 48, 16, "mt19937", 25),
+                                                      (3, 3, 4096, 128, 128, "mt19937", 25),
+                                                      (3, 3, 300, 64, 32, "philox", 25),   # counter-based reset stream
+                                                      (5, 5, 50, 40, 8, "philox", 1),      # ... a reset every step
+                                                      (3, 3, 200, 48, 12, "mt19937", 3)])
+def test_fused_rollout_equals_per_step_launches(fa, G, A, E, T, chunk, rng, max_t):
+    """fa_collect_rollout (K env-steps in one launch, state in registers; the pipelined kernel for
+    K >= 8) is bit-identical to K fa_collect_step launches (the classic kernel) -- storage rows,
+    world state and RNG stream position."""
     N = G + A
     gen = torch.Generator(device="cuda").manual_seed(3)
     acts = torch.randint(0, 8, (T, E, N, 1), device="cuda", generator=gen)
     res = []
     for fused in (False, True):
-        eng = fa.BatchedFortAttack(E, G, A, 25, base_seed=99)
+        eng = fa.BatchedFortAttack(E, G, A, max_t, base_seed=99, rng=rng)
         st = fa.JointRolloutStorage(T, E, N, device="cuda")
         eng.bind_storage(st)
         eng.collect_reset()
@@ -156,12 +161,15 @@ def test_fused_rollout_equals_per_step_launches(fa, G, A, E, T, chunk):
         else:
             for s in range(T):
                 eng.collect_step(s)
-        res.append((st, eng.get_state(), eng.rng_peek(E - 1, 4)))
+        # the next reset must draw the same positions: reset once more and compare the observation
+        nxt = eng.rng_peek(E - 1, 4) if rng == "mt19937" else eng.reset().cpu().numpy()
+        res.append((st, eng.get_state() if rng == "mt19937" else None, nxt))
     (sa, xa, ra), (sb, xb, rb) = res
     for k in ("obs", "rewards", "masks", "done"):
         assert torch.equal(getattr(sa, k), getattr(sb, k)), k
-    for k in xa:
-        assert np.array_equal(xa[k], xb[k], equal_nan=True), k
+    if xa is not None:
+        for k in xa:
+            assert np.array_equal(xa[k], xb[k], equal_nan=True), k
     assert np.array_equal(ra, rb)
     assert int(sa.done.sum()) > 0
 

@@ -195,6 +195,32 @@ def test_fused_launch_vs_oracle(fa, G, A, E, T, max_t):
     assert np.array_equal(eng.rng_peek(E - 1, 2 * N), orc.rng_doubles(E - 1, 2 * N))
 
 
+def test_fused_launch_without_auto_reset_vs_oracle(fa):
+    """auto_reset = 0 through the pipelined kernel: finished envs keep stepping (dead agents frozen,
+    done raised every step after the first), nothing is drawn from the reset stream."""
+    from fa_oracle import OracleEnv
+    G, A, E, T, max_t = 3, 3, 97, 40, 12
+    N = G + A
+    rng = np.random.RandomState(3)
+    orc = OracleEnv(E, G, A, max_t, base_seed=5)
+    eng = fa.BatchedFortAttack(E, G, A, max_t, base_seed=5)
+    o0 = torch.empty((E, N, 6), dtype=torch.float64, device="cuda")
+    eng.reset(obs_f64=o0)
+    assert np.array_equal(o0.cpu().numpy(), orc.reset())
+    peek = eng.rng_peek(0, 4)
+    acts = np.where(rng.rand(T, E, N) < 0.3, 7, rng.randint(0, 8, size=(T, E, N)))
+    assert eng.step_variant(T) == "fa_step_pipe_kernel"
+    out = {k: v.cpu().numpy() for k, v in eng.step_many(_dev(acts, torch.int64), auto_reset=False,
+                                                        want=("obs_f64", "reward_f64", "mask_f32", "done", "hit", "was_hit")).items()}
+    for t in range(T):
+        ref = orc.step(acts[t], auto_reset=False)
+        assert np.array_equal(out["done"][t], ref["done"]), t
+        assert np.array_equal(out["mask_f32"][t], ref["alive_before"].astype(np.float32)), t
+        assert np.array_equal(out["hit"][t], ref["hit"]) and np.array_equal(out["was_hit"][t], ref["was_hit"]), t
+        assert np.abs(out["obs_f64"][t] - ref["obs"]).max() <= FLOAT_TOL and np.abs(out["reward_f64"][t] - ref["reward"]).max() <= FLOAT_TOL
+    assert np.array_equal(eng.rng_peek(0, 4), peek)
+
+
 def test_shards_equal_one_big_batch(fa):
     """Multi-GPU sharding by env_offset: two half handles == one full handle, bit for bit."""
     E, G, A, T = 512, 3, 3, 80
