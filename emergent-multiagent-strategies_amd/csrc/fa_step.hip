@@ -1438,7 +1438,8 @@ static hipError_t launch_step_t(const FaStepArgs &a, hipStream_t st) {
         else if (pipe) FA_LAUNCH_PIPE(3, 3, 2, 3);
         else if (nw == 3) FA_LAUNCH(3, 3, 3); else if (nw == 2) FA_LAUNCH(3, 3, 2); else FA_LAUNCH(3, 3, 1);
     } else if (a.G == 5 && a.A == 5) {
-        if (pipe) FA_LAUNCH_PIPE(5, 5, 2, 3);
+        if (pipe && grid <= 2 * 256) FA_LAUNCH_PIPE(5, 5, 2, 2);
+        else if (pipe) FA_LAUNCH_PIPE(5, 5, 2, 3);
         else if (nw == 3) FA_LAUNCH(5, 5, 3); else if (nw == 2) FA_LAUNCH(5, 5, 2); else FA_LAUNCH(5, 5, 1);
     } else {
         FA_LAUNCH(0, 0, 1);
