@@ -74,6 +74,97 @@ __global__ __launch_bounds__(64) void fa_gae_kernel(const float *__restrict__ re
     }
 }
 
+// Cooperative form for small batches: at E*N = 24 576 columns the one-wave kernel above has 384
+// waves, every wave can keep 63 vector-memory operations in flight (vmcnt), and Little's law pins
+// it at ~3 TB/s.  Here a workgroup of four waves shares 64 columns: waves 1..3 stream rewards /
+// value_preds / masks + done flags a 32-step chunk ahead into LDS (each with its own queue), wave 0
+// scans the previous chunk out of LDS and stores the returns.  Same arithmetic, same order.
+// (Keeping two chunks in flight per loader -- two register sets -- measured 3x slower.)
+#define FA_GAEC_CHUNK 32
+__global__ __launch_bounds__(256) void fa_gae_coop_kernel(const float *__restrict__ rewards,
+                                                          const float *__restrict__ value_preds,
+                                                          const float *__restrict__ masks,
+                                                          float *__restrict__ returns,
+                                                          const uint8_t *__restrict__ done, int T, int E,
+                                                          int N, float g32, float gt32) {
+    __shared__ float s_r[2][FA_GAEC_CHUNK][64], s_v[2][FA_GAEC_CHUNK][64], s_m[2][FA_GAEC_CHUNK][64];
+    __shared__ uint8_t s_d[2][FA_GAEC_CHUNK][64];
+    const long long EN = (long long)E * N;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long colv = (long long)blockIdx.x * 64 + lane;
+    const bool valid = colv < EN;
+    const long long col = valid ? colv : EN - 1; // idle lanes shadow the last column, store nothing
+    const int e = (int)(col / N);
+    const int nc = (T + FA_GAEC_CHUNK - 1) / FA_GAEC_CHUNK;
+    // chunk c holds steps t = T-1 - c*CHUNK - k, k = 0..CHUNK-1 (clamped loads below t = 0)
+    auto load_chunk = [&](int c) {
+        const int t0 = T - 1 - c * FA_GAEC_CHUNK, b = c & 1;
+        if (wave == 3) {
+            float x[FA_GAEC_CHUNK];
+            uint8_t d[FA_GAEC_CHUNK];
+#pragma unroll
+            for (int k = 0; k < FA_GAEC_CHUNK; ++k) {
+                const int t = t0 - k;
+                x[k] = masks[(long long)(t >= 0 ? t : 0) * EN + col];
+                d[k] = done[(long long)(t > 0 ? t - 1 : 0) * E + e];
+            }
+#pragma unroll
+            for (int k = 0; k < FA_GAEC_CHUNK; ++k) { s_m[b][k][lane] = x[k]; s_d[b][k][lane] = d[k]; }
+        } else {
+            const float *src = wave == 1 ? rewards : value_preds;
+            float x[FA_GAEC_CHUNK];
+#pragma unroll
+            for (int k = 0; k < FA_GAEC_CHUNK; ++k) {
+                const int t = t0 - k;
+                x[k] = src[(long long)(t >= 0 ? t : 0) * EN + col];
+            }
+            float(*dst)[64] = wave == 1 ? s_r[b] : s_v[b];
+#pragma unroll
+            for (int k = 0; k < FA_GAEC_CHUNK; ++k) dst[k][lane] = x[k];
+        }
+    };
+    float gae = 0.0f, v_next = 0.0f, m_next = 0.0f;
+    if (wave == 0) {
+        v_next = value_preds[(long long)T * EN + col];
+        m_next = masks[(long long)T * EN + col];
+    } else {
+        load_chunk(0);
+    }
+    __syncthreads();
+    for (int c = 0; c < nc; ++c) {
+        if (wave != 0) {
+            if (c + 1 < nc) load_chunk(c + 1);
+        } else {
+            const int t0 = T - 1 - c * FA_GAEC_CHUNK, b = c & 1;
+            // the chunk comes out of LDS in one batch (a read per scan step would put an LDS round
+            // trip on every step of the chain)
+            float r[FA_GAEC_CHUNK], v[FA_GAEC_CHUNK], m[FA_GAEC_CHUNK];
+            uint8_t d[FA_GAEC_CHUNK];
+#pragma unroll
+            for (int k = 0; k < FA_GAEC_CHUNK; ++k) {
+                r[k] = s_r[b][k][lane]; v[k] = s_v[b][k][lane]; m[k] = s_m[b][k][lane]; d[k] = s_d[b][k][lane];
+            }
+#pragma unroll
+            for (int k = 0; k < FA_GAEC_CHUNK; ++k) {
+                const int t = t0 - k;
+                if (t >= 0) {
+                    const float delta = r[k] + g32 * v_next * m_next - v[k];
+                    const float g = delta + gt32 * m_next * gae;
+                    if ((t > 0) & (d[k] != 0)) {
+                        gae = 0.0f;
+                    } else {
+                        gae = g;
+                        if (valid) returns[(long long)t * EN + col] = g + v[k];
+                    }
+                    v_next = v[k];
+                    m_next = m[k];
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // Four adjacent columns per lane: 16-byte loads (1 KiB per wave instruction instead of
 // 256 B) and four independent scan chains per lane.  Same arithmetic per column as above.
 #define FA_GAE4_CHUNK 16
@@ -445,6 +536,13 @@ hipError_t fa_launch_gae(const float *rewards, const float *value_preds, const f
     // 16-byte lanes; below that the one-column kernel has 4x the waves in flight
     const bool vec4 = (EN >= 4LL * 64 * 1024) && (EN % 4 == 0) && ((((uintptr_t)rewards | (uintptr_t)value_preds | (uintptr_t)masks |
                                           (uintptr_t)returns) & 15) == 0);
+    if (!vec4 && EN <= 64LL * 2048) {
+        // few columns: four cooperating waves per 64 columns (see fa_gae_coop_kernel)
+        const int grid = (int)((EN + 63) / 64);
+        hipLaunchKernelGGL(fa_gae_coop_kernel, dim3(grid), dim3(256), 0, st, rewards, value_preds, masks, returns,
+                           done, T, E, N, (float)gamma, (float)(gamma * tau));
+        return hipGetLastError();
+    }
     if (vec4) {
         const int grid = (int)((EN / 4 + 63) / 64);
         hipLaunchKernelGGL(fa_gae4_kernel, dim3(grid), dim3(64), 0, st, rewards, value_preds, masks, returns,
