@@ -4,10 +4,12 @@ Envs are independent, so rank r simply owns envs [r*E, (r+1)*E) (``env_offset`` 
 BatchedFortAttack) and nothing is exchanged during a rollout.  The only cross-rank
 quantity is the per-agent advantage mean / unbiased std of JointPPO.update
 (rlcore/algo/ppo.py:121-123), which the reference computes over one process's T*P samples
-and which must now cover every rank's samples: a two-pass reduction, each pass one
-all-reduce (RCCL over xGMI, backend "nccl") of N x 3 resp. N doubles -- latency bound,
-144 B at 3v3.  Two passes (mean first, then squared deviations) keep the result equal to
-the single-process two-pass value to fp64 rounding.
+and which must now cover every rank's samples.  What the learner and bench.py call is
+``gae_adv_mean_std``: every rank computes its local moments (n, mean, M2) per agent
+(fa_gae_moments), ONE all-gather (RCCL over xGMI, backend "nccl") moves N x 3 doubles per rank
+-- latency bound, 144 B at 3v3 -- and fa_adv_merge combines the triples exactly
+(Chan-Golub-LeVeque, in rank order: every rank gets the same bits).  ``two_pass_mean_std`` is the
+two-all-reduce formulation (mean first, then squared deviations), kept as the reference form.
 """
 import torch
 import torch.distributed as dist
