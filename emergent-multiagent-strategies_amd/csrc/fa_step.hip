@@ -1004,15 +1004,16 @@ __global__ __launch_bounds__((NPW + 2) * FA_WAVE, MINW) void fa_step_pipe_kernel
         bool need_b = false;
         auto wait_words = [&]() { if (a.rng_mode == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
         if (rng_wave) {
+            // one load round trip for the cursor, one for the words of all three draws
             rdA.base = a.rng_mode == 0 ? a.s.mt_pos[e] + 4 * i : (int)a.s.reset_count[e];
-            draw_load(a, e, rdA.base, mw);
-            wait_words();
-            draw_eval(a, e, i, is_att, mw, rdA);
             rdB.base = draw_next_base(a, rdA.base, i, N);
-            draw_load(a, e, rdB.base, mw);
-            wait_words();
-            draw_eval(a, e, i, is_att, mw, rdB);
+            MtWords mwa = {}, mwb = {};
+            draw_load(a, e, rdA.base, mwa);
+            draw_load(a, e, rdB.base, mwb);
             draw_load(a, e, draw_next_base(a, rdB.base, i, N), mw);
+            wait_words();
+            draw_eval(a, e, i, is_att, mwa, rdA);
+            draw_eval(a, e, i, is_att, mwb, rdB);
             s_rp[0][lane] = rdA.px;
             s_rp[1][lane] = rdA.py;
         }
