@@ -1,0 +1,39 @@
+#!/usr/bin/env python
+"""One-off soak (run on the GPU box): the fused pipelined step kernel against the CPU oracle over many
+rollouts of shoot-heavy random actions -- counts differing flags / fp64 values.  usage: soak_parity.py [rollouts] [E] [G] [A]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import numpy as np, torch
+import emergent_multiagent_strategies_amd as fa
+from fa_oracle import OracleEnv
+R = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+E = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
+G = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+A = int(sys.argv[4]) if len(sys.argv) > 4 else 3
+T, max_t = 128, 60
+N = G + A
+rng = np.random.RandomState(2026)
+orc = OracleEnv(E, G, A, max_t, base_seed=77)
+eng = fa.BatchedFortAttack(E, G, A, max_t, base_seed=77)
+o0 = torch.empty((E, N, 6), dtype=torch.float64, device="cuda")
+eng.reset(obs_f64=o0)
+assert np.array_equal(o0.cpu().numpy(), orc.reset())
+bad_flags = bad_f64 = deaths = ends = 0
+worst = 0.0
+t0 = time.time()
+for r in range(R):
+    acts = np.where(rng.rand(T, E, N) < 0.3, 7, rng.randint(0, 8, size=(T, E, N)))
+    out = {k: v.cpu().numpy() for k, v in eng.step_many(torch.from_numpy(acts).cuda(), auto_reset=True,
+           want=("obs_f64", "reward_f64", "done", "hit", "was_hit")).items()}
+    for t in range(T):
+        ref = orc.step(acts[t], auto_reset=True)
+        bad_flags += int((out["done"][t] != ref["done"]).sum() + (out["hit"][t] != ref["hit"]).sum() + (out["was_hit"][t] != ref["was_hit"]).sum())
+        d = np.abs(out["obs_f64"][t] - ref["obs"])
+        bad_f64 += int((out["obs_f64"][t] != ref["obs"]).sum() + (out["reward_f64"][t] != ref["reward"]).sum())
+        worst = max(worst, float(d.max()))
+        deaths += int(ref["was_hit"].sum()); ends += int(ref["done"].sum())
+    if bad_flags:   # resynchronise would hide nothing: stop at the first divergence
+        break
+print({"variant": eng.step_variant(T), "config": "%dv%d, E=%d, T=%d, max_time_steps=%d, P(shoot)=0.39" % (G, A, E, T, max_t), "env_steps": (r + 1) * T * E, "deaths": deaths, "episodes": ends, "differing_flags": bad_flags,
+       "differing_fp64_values": bad_f64, "worst_abs_diff": worst, "seconds": round(time.time() - t0, 1)})
