@@ -1107,6 +1107,9 @@ __global__ __launch_bounds__((NPW + 2) * FA_WAVE, MINW) void fa_step_pipe_kernel
     }
 
     // ---- wave 0 ----------------------------------------------------------------------------------
+#ifdef FA_TIMING
+    const unsigned long long tp0 = clock64();
+#endif
     double px = a.s.px[idx], py = a.s.py[idx], vx = a.s.vx[idx], vy = a.s.vy[idx];
     double ang = a.s.ang[idx];
     unsigned long long alive_m = FA_M_NE_U(a.s.alive[idx], 0); // wave mask of the living (see FA_M_*)
@@ -1161,6 +1164,7 @@ __global__ __launch_bounds__((NPW + 2) * FA_WAVE, MINW) void fa_step_pipe_kernel
     FA_WG_BARRIER(); // P(-1)
 #ifdef FA_TIMING
     const unsigned long long tk0 = clock64(), tw0 = wall_clock64();
+    if (lane == 0) atomicAdd(&g_dbg[22], tk0 - tp0); // prologue: launch of the wave -> P(-1) passed
 #endif
 
     // The loop's fp64 constants live in VGPRs: as SGPR pairs they (with the lane masks and the
@@ -1362,6 +1366,9 @@ __global__ __launch_bounds__((NPW + 2) * FA_WAVE, MINW) void fa_step_pipe_kernel
         if (a.track_counters) { a.s.num_hit[idx] = nh; a.s.num_was_hit[idx] = nwh; }
     }
     if (i == 0) a.s.tstep[e] = t;
+#ifdef FA_TIMING
+    if (lane == 0) atomicAdd(&g_dbg[23], clock64() - tk0); // P(-1) -> end of wave 0 (loop + write-back)
+#endif
 }
 
 #ifdef FA_TIMING

@@ -38,6 +38,7 @@ for lo, hi, cnt in ((0, 8, 28), (10, 14, 29), (16, 20, 30)):
     print("%-28s %8.1f cycles/step\n" % ("  total", tot))
 print("wave 0 loop: %.1f shader-clock ticks per step, %.1f ns per step (100 MHz wall clock) -> %.3f ticks/ns" % (
     buf[20] / max(buf[28], 1) / T, buf[21] / max(buf[28], 1) / T * 10.0, buf[20] / max(buf[21], 1) / 10.0))
+print("wave 0: prologue (wave start -> P(-1)) %.0f cycles, P(-1) -> end %.0f cycles" % (buf[22] / max(buf[28], 1), buf[23] / max(buf[28], 1)))
 hw = (C.c_uint * 512)()
 lib.fa_dbg_hw(hw)
 print("wave placement (workgroup: wave->simd@cu.se):")
