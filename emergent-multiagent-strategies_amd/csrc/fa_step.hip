@@ -299,6 +299,30 @@ __device__ __forceinline__ void fa_wall_force(const FaDerived &c, double px, dou
         wy = c.contact_force * p2 - c.contact_force * p3;
     }
 }
+// The same wall force without per-wall branches, for the helper wave whose B2 arrival it decides (a
+// taken branch costs a lone wave far more than the ~7 instructions it skips): the softplus of every
+// wall is selected from its two closed-form ends, t >= 40 -> t and t < -746 -> +0.0 (which covers
+// every wall farther than 1000*margin), and only if some lane sits in the band between them does the
+// wave take the libm path for those lanes.
+__device__ __forceinline__ void fa_wall_force_flat(const FaDerived &c, double px, double py, double &wx, double &wy) {
+    const double k = c.contact_margin, size = c.agent_size;
+    const double d[4] = {px - size - c.wall_xmin, c.wall_xmax - px - size, py - size - c.wall_ymin, c.wall_ymax - py - size};
+    double t[4], v[4];
+    bool band = false;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        t[q] = div_rn(-d[q], k);
+        v[q] = t[q] >= 40.0 ? t[q] : 0.0;
+        band = band | ((t[q] < 40.0) & !(t[q] < -746.0));
+    }
+    if (__builtin_amdgcn_ballot_w64(band) != 0ull) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if ((t[q] < 40.0) & !(t[q] < -746.0)) v[q] = softplus_band(t[q]);
+    }
+    wx = c.contact_force * (v[0] * k) - c.contact_force * (v[1] * k);
+    wy = c.contact_force * (v[2] * k) - c.contact_force * (v[3] * k);
+}
 // fortattack_env_v1.py:87-188 reward of one agent after World.step.  attacker_reward (:94-128) and
 // guard_reward (:130-188) as one select chain: both are a sum of six terms added left to right --
 // attacker r0..r5; guard r0, r3..r7 (its r1, r2, r8 are literal zeros and x + 0.0 == x) -- so the
@@ -888,7 +912,9 @@ __global__ __launch_bounds__((NPW + 2) * FA_WAVE, MINW) void fa_step_pipe_kernel
             s_U[1][lane] = u1 * c.accel + 0.0;
             s_U[2][lane] = rot;
             double wx = 0.0, wy = 0.0;
-            if (!(FA_ABL & 16) && alive0) fa_wall_force(c, px, py, wx, wy); // core.py:246-252 + :459-472
+            if (!(FA_ABL & 16)) fa_wall_force_flat(c, px, py, wx, wy); // core.py:246-252 + :459-472
+            wx = alive0 ? wx : 0.0;
+            wy = alive0 ? wy : 0.0;
             s_W[0][lane] = wx;
             s_W[1][lane] = wy;
             FA_TICK(17)
