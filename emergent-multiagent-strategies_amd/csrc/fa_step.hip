@@ -840,6 +840,9 @@ __global__ __launch_bounds__(NW * FA_WAVE) void fa_step_kernel(FaStepArgs a) {
 #ifndef FA_ABL
 #define FA_ABL 0
 #endif
+#ifndef FA_TICK_WAVE1
+#define FA_TICK_WAVE1 0 // timing build: report pair wave 1 instead of the last pair wave
+#endif
 #ifdef FA_TIMING
 __device__ unsigned long long g_dbg[32];
 __device__ unsigned g_hw[512];
@@ -1128,7 +1131,7 @@ __global__ __launch_bounds__((NPW + 2) * FA_WAVE, MINW) void fa_step_pipe_kernel
             if (a.track_counters) a.s.ep_rew[idx] = ep_rew;
         }
         if (out_wave) emit_obs(ns & 1);
-        if (out_wave) { FA_TICK_FLUSH(10, 14, 29) }
+        if (FA_TICK_WAVE1 ? rew_wave : out_wave) { FA_TICK_FLUSH(10, 14, 29) }
         return;
     }
 
