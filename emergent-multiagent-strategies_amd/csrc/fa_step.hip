@@ -932,6 +932,7 @@ __global__ __launch_bounds__((NPW + 2) * FA_WAVE, MINW) void fa_step_pipe_kernel
             FA_TICK(19)
             FA_WG_BARRIER(); // P(s)
         }
+        FA_WG_BARRIER(); // (wave 0 publishes the last step's by-products)
         FA_TICK_FLUSH(16, 20, 30)
         return;
     }
@@ -1124,6 +1125,7 @@ __global__ __launch_bounds__((NPW + 2) * FA_WAVE, MINW) void fa_step_pipe_kernel
             FA_TICK(13)
             FA_WG_BARRIER(); // P(s)
         }
+        FA_WG_BARRIER(); // wave 0 has published the last step's by-products
         if (rng_wave && a.auto_reset != 0 && ((s_mask[ns & 1][4] >> lane) & 1ull)) draw_commit(a, e, i, N, rdA);
         if (rew_wave) {
             emit_rew(ns & 1);
@@ -1218,7 +1220,7 @@ __global__ __launch_bounds__((NPW + 2) * FA_WAVE, MINW) void fa_step_pipe_kernel
                 ocs[k] = s_trig[s & 1][0][j];
                 osn[k] = s_trig[s & 1][1][j];
             }
-            if (reset_prev_m != 0ull) {
+            if (__builtin_expect(reset_prev_m != 0ull, 0)) { // rare blocks out of line: a taken skip costs ~27 cycles
                 const bool rp = fa_lanes(reset_prev_m);
 #pragma unroll
                 for (int k = 0; k < KT; ++k) {
@@ -1295,7 +1297,7 @@ __global__ __launch_bounds__((NPW + 2) * FA_WAVE, MINW) void fa_step_pipe_kernel
             vx += Fx * k_dt;
             vy += Fy * k_dt;
             const double speed2 = vx * vx + vy * vy;
-            if (speed2 > k_sp2) { // == sqrt(v.v) > max_speed, see fa_step_kernel
+            if (__builtin_expect(speed2 > k_sp2, 0)) { // == sqrt(v.v) > max_speed, see fa_step_kernel
                 const double speed = sqrt_rn(speed2);
                 vx = div_rn(vx, speed) * k_vmax;
                 vy = div_rn(vy, speed) * k_vmax;
@@ -1326,7 +1328,7 @@ __global__ __launch_bounds__((NPW + 2) * FA_WAVE, MINW) void fa_step_pipe_kernel
         FA_TICK(4)
         // ---- fortattack_env_v1.py:47-75 reset_world (prevDist is NOT reset: quirk Q1) ----------
         // (the positions were drawn ahead by wave 1, see ResetDraw)
-        if (reset_m != 0ull) { // wave-uniform: most steps reset no env of the wave
+        if (__builtin_expect(reset_m != 0ull, 0)) { // wave-uniform: most steps reset no env of the wave
             const double rpx = s_rp[0][lane], rpy = s_rp[1][lane];
             if (fa_lanes(reset_m)) {
                 px = rpx; py = rpy; vx = 0.0; vy = 0.0;
@@ -1347,12 +1349,13 @@ __global__ __launch_bounds__((NPW + 2) * FA_WAVE, MINW) void fa_step_pipe_kernel
             s_mask[nb][0] = alive_m;
             s_mask[nb][4] = done_m;
         }
-        if (restage) {
+        if (__builtin_expect(restage, 0)) {
 #pragma unroll
             for (int k = 0; k < FA_ACT_BATCH; ++k) s_act[k][lane] = av[k];
         }
-        // the by-products of step s are only read by the output wave after B2(s+1): they are written
-        // behind the barrier, while the helpers already work on step s+1 (last step: before it)
+        // the by-products of step s are only read by the emitting waves after B2(s+1): they are written
+        // behind the barrier, while the helpers already work on step s+1 (those of the last step are
+        // followed by one more barrier after the loop)
         auto publish_byproducts = [&]() {
             s_vx[nb][lane] = vx;
             s_vy[nb][lane] = vy;
@@ -1363,13 +1366,11 @@ __global__ __launch_bounds__((NPW + 2) * FA_WAVE, MINW) void fa_step_pipe_kernel
                 s_mask[nb][3] = was_hit_m;
             }
         };
-        const bool last = s + 1 == ns;
-        if (last) publish_byproducts();
         FA_TICK(6)
         FA_WG_BARRIER(); // P(s)
         FA_TICK(7)
-        if (!last) publish_byproducts();
-        if (restage) {
+        publish_byproducts();
+        if (__builtin_expect(restage, 0)) {
 #pragma unroll
             for (int k = 0; k < FA_ACT_BATCH; ++k)
                 av[k] = (s + 1 + FA_ACT_BATCH + k < ns) ? (int)act_ptr[(int64_t)(s + 1 + FA_ACT_BATCH + k) * a.as_t] : 0;
@@ -1383,6 +1384,7 @@ __global__ __launch_bounds__((NPW + 2) * FA_WAVE, MINW) void fa_step_pipe_kernel
         }
         act = act_next;
     }
+    FA_WG_BARRIER(); // the by-products of the last step are published
     FA_TICK_FLUSH(0, 8, 28)
 #ifdef FA_TIMING
     if (lane == 0) { atomicAdd(&g_dbg[20], clock64() - tk0); atomicAdd(&g_dbg[21], wall_clock64() - tw0); }

@@ -121,6 +121,25 @@ __global__ void k_lat(double *out, unsigned long long *cyc, double seed, int nwa
         asm volatile("" : "+v"(x));
     }
     END();
+    // 14/15: a wave-uniform forward branch per iteration, never / always jumping over 4 VALU ops
+    // (nwaves_active is 1 or 4 at run time, the compiler cannot fold the conditions)
+    for (int taken = 0; taken < 2; ++taken) {
+        const int thr = taken ? 0 : 100;   // skip when nwaves_active > thr
+        BEGIN();
+        for (int r = 0; r < R; ++r) {
+            x = __fma_rn(x, z, y);
+            asm volatile("s_cmp_gt_i32 %1, %2\n\ts_cbranch_scc1 1f\n\tv_add_f64 %0, %0, %0\n\tv_add_f64 %0, %0, %0\n\t"
+                         "v_add_f64 %0, %0, %0\n\tv_add_f64 %0, %0, %0\n1:" : "+v"(x) : "s"(nwaves_active), "s"(thr) : "scc");
+        }
+        END();
+    }
+    // 16: a divergent if (exec-masked, s_and_saveexec + s_cbranch_execz, never skipping) per iteration
+    BEGIN();
+    for (int r = 0; r < R; ++r) {
+        if (x > (double)lane - 1e300) x = __fma_rn(x, z, y);
+        asm volatile("" : "+v"(x));
+    }
+    END();
     out[threadIdx.x] = x;
 }
 
@@ -132,7 +151,8 @@ int main() {
                            "dep 32-bit valu (4R)", "cmp->ballot->select round trip (R)", "LDS write->read same wave (R)",
                            "s_barrier, 4 waves (R)", "LDS pointer chase (R)", "rsq+rcp f64 dep (R pairs)",
                            "LDS write, barrier, read, barrier (R)", "clock64 back to back (R)", "cmp->VCC->select dep (R)",
-                           "8 ds_read_b64 + sum (R)"};
+                           "8 ds_read_b64 + sum (R)", "fma + uniform branch NOT taken over 4 adds (R)",
+                           "fma + uniform branch TAKEN over 4 adds (R)", "divergent if, all lanes in (R)"};
     for (int waves = 1; waves <= 4; waves += 3) {
         hipLaunchKernelGGL(k_lat, dim3(1), dim3(64 * waves), 0, 0, out, cyc, 1.25, waves);
         hipDeviceSynchronize();
@@ -141,7 +161,7 @@ int main() {
         std::vector<unsigned long long> h(32);
         hipMemcpy(h.data(), cyc, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
         printf("== %d wave(s) in the workgroup\n", waves);
-        for (int k = 0; k < 14; ++k) printf("%-44s %8.1f cycles per R\n", names[k], (double)h[k] / R);
+        for (int k = 0; k < 17; ++k) printf("%-44s %8.1f cycles per R\n", names[k], (double)h[k] / R);
     }
     return 0;
 }
