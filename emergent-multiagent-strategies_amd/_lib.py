@@ -25,7 +25,7 @@ class Config(C.Structure):
     _fields_ = [("num_envs", C.c_int32), ("num_guards", C.c_int32), ("num_attackers", C.c_int32),
                 ("max_time_steps", C.c_int32), ("device_id", C.c_int32), ("rng_mode", C.c_int32),
                 ("base_seed", C.c_uint64), ("env_offset", C.c_int64), ("rng_skip_doubles", C.c_int32),
-                ("track_counters", C.c_int32), ("world", WorldConsts)]
+                ("track_counters", C.c_int32), ("step_kernel", C.c_int32), ("world", WorldConsts)]
 
 
 class StepIO(C.Structure):
@@ -48,6 +48,8 @@ class StateHost(C.Structure):
 
 
 FA_RNG_MT19937, FA_RNG_PHILOX = 0, 1
+# fa_config.step_kernel (include/fortattack.h FA_KERNEL_*)
+STEP_KERNELS = {"auto": 0, "pipe": 1, "pipe3": 2, "waves1": 3, "waves2": 4, "waves3": 5}
 
 # every symbol include/fortattack.h declares
 EXPORTS = {
@@ -82,8 +84,7 @@ _lib = None
 
 
 def lib_path():
-    # FA_LIB_OVERRIDE: load an alternative build of the same C ABI (kernel experiments)
-    return os.environ.get("FA_LIB_OVERRIDE") or _build.LIB
+    return _build.LIB
 
 
 def load():

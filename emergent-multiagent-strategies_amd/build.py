@@ -19,7 +19,7 @@ def hipcc():
 def needs_build():
     if not os.path.isfile(LIB):
         return True
-    deps = [os.path.join(CSRC, f) for f in SOURCES + ["fa_device.h"]]
+    deps = [os.path.join(CSRC, f) for f in SOURCES + ["fa_device.h", "fa_probe.h"]]
     deps.append(os.path.join(ROOT, "include", "fortattack.h"))
     return any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in deps)
 

@@ -11,7 +11,7 @@
 
 hipError_t fa_launch_step(const FaStepArgs &a, hipStream_t st);
 hipError_t fa_launch_reset(const FaStepArgs &a, hipStream_t st);
-const char *fa_step_variant_name(int G, int A, int E, int nsteps);
+const char *fa_step_variant_name(int G, int A, int E, int nsteps, int step_kernel);
 hipError_t fa_launch_seed(const FaState &s, int E, uint64_t base_seed, int64_t env_offset, int skip_words,
                           hipStream_t st);
 hipError_t fa_launch_selftest(unsigned long long n_per_thread, unsigned long long seed, unsigned long long *mismatch,
@@ -143,6 +143,7 @@ FaStepArgs base_args(const fa_env *env) {
     a.max_t = env->cfg.max_time_steps;
     a.rng_mode = env->cfg.rng_mode;
     a.track_counters = env->cfg.track_counters;
+    a.step_kernel = env->cfg.step_kernel;
     a.seed = env->cfg.base_seed;
     a.env_offset = env->cfg.env_offset;
     a.c = env->c;
@@ -168,6 +169,7 @@ int fa_config_default(fa_config *cfg) {
     cfg->env_offset = 0;
     cfg->rng_skip_doubles = -1;
     cfg->track_counters = 1;
+    cfg->step_kernel = FA_KERNEL_AUTO;
     fa_world_consts &w = cfg->world;
     w.agent_size = 0.05;
     w.accel = 3;
@@ -198,6 +200,11 @@ int fa_create(const fa_config *cfg, fa_env **out) {
     if (cfg->max_time_steps < 1) return fail(FA_ERR_INVALID, "fa_create: max_time_steps must be >= 1");
     if (cfg->rng_mode != FA_RNG_MT19937 && cfg->rng_mode != FA_RNG_PHILOX)
         return fail(FA_ERR_INVALID, "fa_create: unknown rng_mode");
+    if (cfg->step_kernel < FA_KERNEL_AUTO || cfg->step_kernel > FA_KERNEL_WAVES3)
+        return fail(FA_ERR_INVALID, "fa_create: unknown step_kernel");
+    if (cfg->step_kernel != FA_KERNEL_AUTO && cfg->step_kernel != FA_KERNEL_WAVES1 &&
+        !((cfg->num_guards == 3 && cfg->num_attackers == 3) || (cfg->num_guards == 5 && cfg->num_attackers == 5)))
+        return fail(FA_ERR_INVALID, "fa_create: the multi-wave step kernels exist for 3v3 and 5v5 only");
     if (!(cfg->world.contact_margin > 0) || !(cfg->world.agent_size > 0))
         return fail(FA_ERR_INVALID, "fa_create: contact_margin and agent_size must be > 0");
     int ndev = 0;
@@ -560,7 +567,8 @@ int fa_selftest_math(fa_env *env, uint64_t samples, uint64_t seed, uint64_t *mis
 
 const char *fa_step_variant(fa_env *env, int32_t num_steps) {
     if (!env) return "";
-    return fa_step_variant_name(env->cfg.num_guards, env->cfg.num_attackers, env->cfg.num_envs, num_steps);
+    return fa_step_variant_name(env->cfg.num_guards, env->cfg.num_attackers, env->cfg.num_envs, num_steps,
+                                env->cfg.step_kernel);
 }
 
 int fa_rng_peek(fa_env *env, int32_t e, int32_t count, double *out_host) {

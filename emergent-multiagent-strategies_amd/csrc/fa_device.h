@@ -63,6 +63,7 @@ struct FaStepArgs {
     const uint8_t *reset_mask; // fa_reset only
     int32_t E, G, A, max_t;
     int32_t auto_reset, rng_mode, track_counters, nsteps; // nsteps: env-steps per launch
+    int32_t step_kernel;                                  // FA_KERNEL_* of the handle (host side only)
     uint64_t seed;
     int64_t env_offset;
     FaDerived c;

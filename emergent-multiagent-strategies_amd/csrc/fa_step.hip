@@ -16,6 +16,7 @@
 // The exact shortcuts (skipping a contact whose soft penalty is exactly 0.0, sqrt-free speed
 // test, wrapper-free divide/sqrt) are argued where they are taken.
 #include "fa_device.h"
+#include "fa_probe.h" // FA_TICK* / FA_PROBE_*: no-ops in the product build (tools/make_timing_build.py)
 
 // ---- numpy legacy RandomState (MT19937), incremental form --------------------------
 // Matsumoto-Nishimura genrand regenerates all 624 words at once; word k of the new block
@@ -785,6 +786,7 @@ __global__ __launch_bounds__(NW * FA_WAVE) void fa_step_kernel(FaStepArgs a) {
                 alive = true;
                 t = 0;
                 nh = 0; nwh = 0;
+                ep_rew = 0.0; // a new episode starts: an explicit reset mid-episode must not leak its partial return
                 dirty = true;
                 if (i == 0) {
                     reset_advance(a, e, mt_base);
@@ -837,23 +839,6 @@ __global__ __launch_bounds__(NW * FA_WAVE) void fa_step_kernel(FaStepArgs a) {
 //     does not wait for this step's forces (a dead agent's value is never used; a reset agent
 //     takes the constant pair).
 // Two workgroup barriers per step: B2 (pair + wall forces of step s are in LDS) and P.
-#ifndef FA_ABL
-#define FA_ABL 0
-#endif
-#ifndef FA_TICK_WAVE1
-#define FA_TICK_WAVE1 0 // timing build: report pair wave 1 instead of the last pair wave
-#endif
-#ifdef FA_TIMING
-__device__ unsigned long long g_dbg[32];
-__device__ unsigned g_hw[512];
-#define FA_TICK_INIT unsigned long long tacc[24] = {0}; unsigned long long tlast = clock64();
-#define FA_TICK(k) { const unsigned long long _n = clock64(); tacc[k] += _n - tlast; tlast = _n; }
-#define FA_TICK_FLUSH(lo, hi, cnt) if (lane == 0) { for (int k = lo; k < hi; ++k) atomicAdd(&g_dbg[k], tacc[k]); atomicAdd(&g_dbg[cnt], 1ull); }
-#else
-#define FA_TICK_INIT
-#define FA_TICK(k)
-#define FA_TICK_FLUSH(lo, hi, cnt)
-#endif
 template <int TG, int TA, bool COLLECT, int NPW, int MINW>
 __global__ __launch_bounds__((NPW + 2) * FA_WAVE, MINW) void fa_step_pipe_kernel(FaStepArgs a) {
     constexpr int G = TG, A = TA, N = TG + TA;
@@ -872,13 +857,7 @@ __global__ __launch_bounds__((NPW + 2) * FA_WAVE, MINW) void fa_step_pipe_kernel
     constexpr unsigned long long grp_mask = (1ull << N) - 1ull;
     const FaDerived &c = a.c;
     const int ns = a.nsteps;
-#ifdef FA_TIMING
-    if (lane == 0 && blockIdx.x < 64) { // where the hardware put this wave (HW_ID: simd [5:4], cu [11:8], se [15:13])
-        unsigned hw;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-        g_hw[blockIdx.x * 8 + wave_id] = hw | 0x80000000u;
-    }
-#endif
+    FA_PROBE_HWID(lane, wave_id)
 
     // buffer s & 1: state at the start of step s (+ by-products of step s-1)
     __shared__ double s_px[2][FA_WAVE], s_py[2][FA_WAVE], s_ang[2][FA_WAVE];
@@ -915,7 +894,7 @@ __global__ __launch_bounds__((NPW + 2) * FA_WAVE, MINW) void fa_step_pipe_kernel
             s_U[1][lane] = u1 * c.accel + 0.0;
             s_U[2][lane] = rot;
             double wx = 0.0, wy = 0.0;
-            if (!(FA_ABL & 16)) fa_wall_force_flat(c, px, py, wx, wy); // core.py:246-252 + :459-472
+            fa_wall_force_flat(c, px, py, wx, wy); // core.py:246-252 + :459-472
             wx = alive0 ? wx : 0.0;
             wy = alive0 ? wy : 0.0;
             s_W[0][lane] = wx;
@@ -923,7 +902,7 @@ __global__ __launch_bounds__((NPW + 2) * FA_WAVE, MINW) void fa_step_pipe_kernel
             FA_TICK(17)
             FA_WG_BARRIER(); // B2(s)
             FA_TICK(18)
-            if (!(FA_ABL & 32) && s + 1 < ns) {
+            if (s + 1 < ns) {
                 double sn, cs;
                 sincos_heading(ang + rot, sn, cs); // == wave 0's `ang += rot` for a survivor
                 s_trig[(s + 1) & 1][0][lane] = cs;
@@ -1097,7 +1076,7 @@ __global__ __launch_bounds__((NPW + 2) * FA_WAVE, MINW) void fa_step_pipe_kernel
                 const double d2 = dx * dx + dy * dy;
                 double fxv = 0.0, fyv = 0.0;
                 bool near = false;
-                if (!(FA_ABL & 8) && mine && alive0 && ((grp_alive0 >> j) & 1ull) && !(d2 > c.contact_skip_d2)) {
+                if (mine && alive0 && ((grp_alive0 >> j) & 1ull) && !(d2 > c.contact_skip_d2)) {
                     fa_contact_force(c, dx, dy, d2, fxv, fyv);
                     near = true;
                 }
@@ -1118,8 +1097,8 @@ __global__ __launch_bounds__((NPW + 2) * FA_WAVE, MINW) void fa_step_pipe_kernel
                 draw_load(a, e, draw_next_base(a, rdB.base, i, N), mw);
             }
             need_b = false;
-            if (!(FA_ABL & 1) && rew_wave && s > 0) emit_rew(b);
-            if (!(FA_ABL & 1) && out_wave && s > 0) emit_obs(b);
+            if (rew_wave && s > 0) emit_rew(b);
+            if (out_wave && s > 0) emit_obs(b);
             act_prev = act_cur;
             alive0_prev = alive0;
             FA_TICK(13)
@@ -1138,9 +1117,7 @@ __global__ __launch_bounds__((NPW + 2) * FA_WAVE, MINW) void fa_step_pipe_kernel
     }
 
     // ---- wave 0 ----------------------------------------------------------------------------------
-#ifdef FA_TIMING
-    const unsigned long long tp0 = clock64();
-#endif
+    FA_PROBE_WAVE0_BEGIN
     double px = a.s.px[idx], py = a.s.py[idx], vx = a.s.vx[idx], vy = a.s.vy[idx];
     double ang = a.s.ang[idx];
     unsigned long long alive_m = FA_M_NE_U(a.s.alive[idx], 0); // wave mask of the living (see FA_M_*)
@@ -1193,10 +1170,7 @@ __global__ __launch_bounds__((NPW + 2) * FA_WAVE, MINW) void fa_step_pipe_kernel
     s_fmx[i][lane] = 0.0; // an agent exerts no force on itself: the pair waves never write the diagonal
     s_fmy[i][lane] = 0.0;
     FA_WG_BARRIER(); // P(-1)
-#ifdef FA_TIMING
-    const unsigned long long tk0 = clock64(), tw0 = wall_clock64();
-    if (lane == 0) atomicAdd(&g_dbg[22], tk0 - tp0); // prologue: launch of the wave -> P(-1) passed
-#endif
+    FA_PROBE_WAVE0_LOOP_BEGIN(lane)
 
     // The loop's fp64 constants live in VGPRs: as SGPR pairs they (with the lane masks and the
     // write-back pointers) overflow the scalar file, and every spilled SGPR costs the lone wave a
@@ -1238,7 +1212,7 @@ __global__ __launch_bounds__((NPW + 2) * FA_WAVE, MINW) void fa_step_pipe_kernel
 #pragma unroll
         for (int k = 0; k < KT; ++k) hb[k] = 0ull;
         int hit_cnt = 0, was_hit_cnt = 0;
-        if (!(FA_ABL & 2) && shooters_m != 0ull) {
+        if (shooters_m != 0ull) {
             const unsigned gw_sh = (unsigned)(shooters_m >> gbase);
 #pragma unroll
             for (int k = 0; k < KT; ++k) {
@@ -1283,12 +1257,11 @@ __global__ __launch_bounds__((NPW + 2) * FA_WAVE, MINW) void fa_step_pipe_kernel
             // bit for bit (F is never -0.0; f is finite unless two agents coincide exactly)
             double Fx = u0, Fy = u1;
 #pragma unroll
-            for (int j = 0; j < N; ++j)
-                if (!(FA_ABL & 64)) {
-                    const double m = (double)((ga1 >> j) & 1u);
-                    Fx = __fma_rn(fmx[j], m, Fx);
-                    Fy = __fma_rn(fmy[j], m, Fy);
-                }
+            for (int j = 0; j < N; ++j) {
+                const double m = (double)((ga1 >> j) & 1u);
+                Fx = __fma_rn(fmx[j], m, Fx);
+                Fy = __fma_rn(fmy[j], m, Fy);
+            }
             Fx = wx + Fx;
             Fy = wy + Fy;
             // core.py:324-338 integrate_state (mass == 1.0: F/1.0 is exact)
@@ -1386,9 +1359,7 @@ __global__ __launch_bounds__((NPW + 2) * FA_WAVE, MINW) void fa_step_pipe_kernel
     }
     FA_WG_BARRIER(); // the by-products of the last step are published
     FA_TICK_FLUSH(0, 8, 28)
-#ifdef FA_TIMING
-    if (lane == 0) { atomicAdd(&g_dbg[20], clock64() - tk0); atomicAdd(&g_dbg[21], wall_clock64() - tw0); }
-#endif
+    FA_PROBE_WAVE0_LOOP_END(lane)
 
     if (fa_lanes(dirty_m)) {
         a.s.px[idx] = px; a.s.py[idx] = py; a.s.vx[idx] = vx; a.s.vy[idx] = vy;
@@ -1397,19 +1368,8 @@ __global__ __launch_bounds__((NPW + 2) * FA_WAVE, MINW) void fa_step_pipe_kernel
         if (a.track_counters) { a.s.num_hit[idx] = nh; a.s.num_was_hit[idx] = nwh; }
     }
     if (i == 0) a.s.tstep[e] = t;
-#ifdef FA_TIMING
-    if (lane == 0) atomicAdd(&g_dbg[23], clock64() - tk0); // P(-1) -> end of wave 0 (loop + write-back)
-#endif
+    FA_PROBE_WAVE0_END(lane)
 }
-
-#ifdef FA_TIMING
-extern "C" int fa_dbg_read(unsigned long long *out, int reset) {
-    hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg), sizeof(unsigned long long) * 32);
-    if (reset) { unsigned long long z[32] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_dbg), z, sizeof(z)); }
-    return 0;
-}
-extern "C" int fa_dbg_hw(unsigned *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_hw), sizeof(unsigned) * 512); }
-#endif
 
 // ---- np.random.seed(int): init_genrand, then discard the construction draws ----------
 __global__ void fa_seed_kernel(FaState s, int E, uint64_t base_seed, int64_t env_offset, int skip_words) {
@@ -1432,22 +1392,29 @@ __global__ void fa_seed_kernel(FaState s, int E, uint64_t base_seed, int64_t env
 }
 
 // ---- launchers --------------------------------------------------------------------------
-// which step kernel a launch of `nsteps` env-steps uses: 0 = pipelined, 1/2/3 = fa_step_kernel
-// with that many cooperating waves
-static int step_variant(int G, int A, int E, int nsteps, bool reset_only) {
+// which step kernel a launch of `nsteps` env-steps uses: 0 = pipelined (two workgroups per CU build),
+// -3 = pipelined (three per CU build), 1/2/3 = fa_step_kernel with that many cooperating waves.
+// `forced` = the handle's fa_config.step_kernel (FA_KERNEL_*; tests pin every instantiation with it).
+static int step_variant(int G, int A, int E, int nsteps, bool reset_only, int forced) {
     const int epw = FA_WAVE / (G + A);
     const int grid = (E + epw - 1) / epw;
-    static const char *force = getenv("FA_STEP_KERNEL");
     const bool sized = (G == 3 && A == 3) || (G == 5 && A == 5);
     if (reset_only || !sized) return 1;
-    bool pipe = nsteps >= FA_PIPE_MIN_STEPS && grid <= FA_PIPE_MAX_GRID;
-    if (force) pipe = force[0] == 'p';
-    if (pipe) return 0;
+    switch (forced) {
+    case 1: if (nsteps >= 2) return 0; break;   // FA_KERNEL_PIPE (its prologue assumes a second step may follow)
+    case 2: if (nsteps >= 2) return -3; break;  // FA_KERNEL_PIPE3
+    case 3: return 1;
+    case 4: return 2;
+    case 5: return 3;
+    default: break;
+    }
+    if (nsteps >= FA_PIPE_MIN_STEPS && grid <= FA_PIPE_MAX_GRID) return grid <= 2 * 256 ? 0 : -3;
     return grid <= FA_THREE_WAVE_MAX_GRID ? 3 : (grid <= FA_TWO_WAVE_MAX_GRID ? 2 : 1);
 }
-const char *fa_step_variant_name(int G, int A, int E, int nsteps) {
-    switch (step_variant(G, A, E, nsteps, false)) {
+const char *fa_step_variant_name(int G, int A, int E, int nsteps, int forced) {
+    switch (step_variant(G, A, E, nsteps, false, forced)) {
     case 0: return "fa_step_pipe_kernel";
+    case -3: return "fa_step_pipe_kernel/3 per CU";
     case 3: return "fa_step_kernel/3 waves";
     case 2: return "fa_step_kernel/2 waves";
     default: return "fa_step_kernel/1 wave";
@@ -1463,9 +1430,7 @@ static hipError_t launch_step_t(const FaStepArgs &a, hipStream_t st) {
     // compile-time team sizes that fit the GPU in one round of 3 workgroups per CU use the
     // pipelined kernel; short launches (its prologue draws two resets ahead and evaluates three
     // sin/cos) and everything else use fa_step_kernel with 3 / 2 / 1 waves by grid size.
-    // FA_STEP_KERNEL=classic|pipe overrides the choice (experiments).
-    const int nw = step_variant(a.G, a.A, a.E, a.nsteps, RESET_ONLY);
-    const bool pipe = nw == 0;
+    const int nw = step_variant(a.G, a.A, a.E, a.nsteps, RESET_ONLY, a.step_kernel);
 #define FA_LAUNCH(TG_, TA_, NW_) \
     hipLaunchKernelGGL((fa_step_kernel<TG_, TA_, RESET_ONLY, COLLECT, RESET_ONLY ? 1 : NW_>), dim3(grid), \
                        dim3((RESET_ONLY ? 1 : NW_) * FA_WAVE), 0, st, a)
@@ -1473,12 +1438,12 @@ static hipError_t launch_step_t(const FaStepArgs &a, hipStream_t st) {
     hipLaunchKernelGGL((fa_step_pipe_kernel<TG_, TA_, COLLECT, NPW_, MINW_>), dim3(grid), dim3((NPW_ + 2) * FA_WAVE), 0, st, a)
     if (a.G == 3 && a.A == 3) {
         // up to two workgroups per CU the build may use 256 VGPRs; three per CU need <= 168
-        if (pipe && grid <= 2 * 256) FA_LAUNCH_PIPE(3, 3, 2, 2);
-        else if (pipe) FA_LAUNCH_PIPE(3, 3, 2, 3);
+        if (nw == 0) FA_LAUNCH_PIPE(3, 3, 2, 2);
+        else if (nw == -3) FA_LAUNCH_PIPE(3, 3, 2, 3);
         else if (nw == 3) FA_LAUNCH(3, 3, 3); else if (nw == 2) FA_LAUNCH(3, 3, 2); else FA_LAUNCH(3, 3, 1);
     } else if (a.G == 5 && a.A == 5) {
-        if (pipe && grid <= 2 * 256) FA_LAUNCH_PIPE(5, 5, 2, 2);
-        else if (pipe) FA_LAUNCH_PIPE(5, 5, 2, 3);
+        if (nw == 0) FA_LAUNCH_PIPE(5, 5, 2, 2);
+        else if (nw == -3) FA_LAUNCH_PIPE(5, 5, 2, 3);
         else if (nw == 3) FA_LAUNCH(5, 5, 3); else if (nw == 2) FA_LAUNCH(5, 5, 2); else FA_LAUNCH(5, 5, 1);
     } else {
         FA_LAUNCH(0, 0, 1);

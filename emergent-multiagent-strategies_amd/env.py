@@ -36,7 +36,8 @@ class BatchedFortAttack(object):
     """
 
     def __init__(self, num_envs, num_guards=3, num_attackers=3, max_time_steps=100, base_seed=0,
-                 env_offset=0, skip_doubles=None, rng="mt19937", device=0, track_counters=True):
+                 env_offset=0, skip_doubles=None, rng="mt19937", device=0, track_counters=True,
+                 step_kernel="auto"):
         lib = _lib.load()
         if not torch.cuda.is_available():
             raise _lib.FaError("BatchedFortAttack needs a ROCm GPU (torch.cuda.is_available() is False)")
@@ -49,6 +50,7 @@ class BatchedFortAttack(object):
         cfg.base_seed, cfg.env_offset = int(base_seed), int(env_offset)
         cfg.rng_skip_doubles = -1 if skip_doubles is None else int(skip_doubles)
         cfg.track_counters = int(bool(track_counters))
+        cfg.step_kernel = _lib.STEP_KERNELS[step_kernel]   # "auto" | "pipe" | "pipe3" | "waves1" | "waves2" | "waves3"
         self.cfg = cfg
         self.E, self.G, self.A = cfg.num_envs, cfg.num_guards, cfg.num_attackers
         self.N = self.G + self.A

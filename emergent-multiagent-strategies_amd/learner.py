@@ -43,7 +43,9 @@ def ppo_losses(pol, own, opp, actions, value_preds, returns, old_logp, adv, clip
         vclip = value_preds + (values - value_preds).clamp(-clip_param, clip_param)
         vl = 0.5 * torch.max((values - returns).pow(2), (vclip - returns).pow(2))
     else:
-        vl = 0.5 * (returns - values).pow(2)
+        # ppo.py:178-182: 0.5 * F.mse_loss is already a SCALAR over all samples (dead agents included);
+        # multiplying it by the mask, taking the mean and dividing by mask.mean() gives it back
+        vl = 0.5 * (returns - values).pow(2).mean()
     value_loss = (vl * mask).mean() / denom
     return value_loss, action_loss, dist_entropy
 
@@ -264,6 +266,9 @@ class BatchedLearner(object):
         vp_f, ret_f = flat(st.value_preds[:-1]), flat(st.returns[:-1])
         olp_f, adv_f = flat(st.action_log_probs), flat(self.adv)
         batch = T * E
+        assert batch >= self.num_mini_batch, (
+            "PPO requires the number of processes ({}) * number of steps ({}) = {} to be greater than "
+            "or equal to the number of PPO mini batches ({}).".format(E, T, batch, self.num_mini_batch))
         mb = int(batch / self.num_mini_batch)                    # ppo.py:210
         out = []
         teams = [0] if train_guards_only else [0, 1]             # learner.py:177
@@ -272,7 +277,6 @@ class BatchedLearner(object):
             own_sl, opp_sl = self.team_slices[ti], self.team_slices[1 - ti]
             params = [p for p in pol.parameters()]
             acc = torch.zeros(3, device=self.device)
-            n_upd = 0
             for _ in range(self.ppo_epoch):
                 perm = torch.randperm(batch, device=self.device)  # SubsetRandomSampler (ppo.py:213)
                 for k in range(0, batch, mb):                     # BatchSampler, drop_last=False
@@ -288,8 +292,7 @@ class BatchedLearner(object):
                     nn.utils.clip_grad_norm_(params, self.max_grad_norm)
                     opt.step()
                     acc += torch.stack([value_loss.detach(), action_loss.detach(), dist_entropy.detach()])
-                    n_upd += 1
-            out.append(acc / n_upd)
+            out.append(acc / (self.ppo_epoch * self.num_mini_batch))   # ppo.py:196-200 (not the batches actually drawn)
         return torch.stack(out)
 
     def after_update(self):

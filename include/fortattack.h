@@ -44,6 +44,12 @@ extern "C" {
 #define FA_NUM_ACTIONS 8
 
 enum { FA_OK = 0, FA_ERR_INVALID = -1, FA_ERR_HIP = -2, FA_ERR_STATE = -3 };
+enum { FA_KERNEL_AUTO = 0,
+       FA_KERNEL_PIPE = 1,    /* fa_step_pipe_kernel, two workgroups per CU build (3v3 / 5v5, num_steps >= 2) */
+       FA_KERNEL_PIPE3 = 2,   /* fa_step_pipe_kernel, three workgroups per CU build (<= 168 VGPRs) */
+       FA_KERNEL_WAVES1 = 3,  /* fa_step_kernel, one wave per workgroup */
+       FA_KERNEL_WAVES2 = 4,  /* ... with the force wave (3v3 / 5v5) */
+       FA_KERNEL_WAVES3 = 5 };/* ... with force and wall waves (3v3 / 5v5) */
 enum { FA_RNG_MT19937 = 0, /* numpy legacy RandomState stream: parity with the reference */
        FA_RNG_PHILOX = 1 }; /* counter based, stateless: perf mode */
 
@@ -80,6 +86,10 @@ typedef struct fa_config {
                                  (scenario __init__ -> reset_world, fortattack_env_v1.py:45);
                                  negative = 2*N */
     int32_t track_counters; /* maintain Agent.numHit / numWasHit (core.py:93-94) */
+    int32_t step_kernel;    /* FA_KERNEL_*: which step kernel this handle's launches use.  AUTO picks by
+                               team size, grid size and launch length (fa_step_variant reports it); the
+                               others pin one build so that tests can drive every instantiation at any
+                               size.  All variants produce identical bits. */
     fa_world_consts world;
 } fa_config;
 

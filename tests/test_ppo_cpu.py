@@ -17,7 +17,8 @@ class _Sp(object):
     shape = (8,)
 
 
-def test_losses_and_adam_step_match_reference_jointppo():
+@pytest.mark.parametrize("clipped", [True, False])   # False: the reference's scalar-MSE branch (ppo.py:178-182)
+def test_losses_and_adam_step_match_reference_jointppo(clipped):
     rh.import_reference()
     from mpnn import MPNN as RefMPNN
     from rlcore.algo.ppo import JointPPO
@@ -32,7 +33,7 @@ def test_losses_and_adam_step_match_reference_jointppo():
     ours = MPNN(num_agents=G, num_opp_agents=A, num_actions=8)
     ours.load_state_dict(copy.deepcopy(ref_pol.state_dict()))
     clip, vcoef, ecoef, lr, gnorm = 0.2, 0.5, 0.01, 1e-3, 0.5
-    ppo = JointPPO(ref_pol, clip, 1, 1, vcoef, ecoef, lr=lr, max_grad_norm=gnorm, use_clipped_value_loss=True)
+    ppo = JointPPO(ref_pol, clip, 1, 1, vcoef, ecoef, lr=lr, max_grad_norm=gnorm, use_clipped_value_loss=clipped)
 
     def storage():
         s = RefStorage(T, P, (6,), None, 1)
@@ -56,7 +57,7 @@ def test_losses_and_adam_step_match_reference_jointppo():
         advs.append(((a - a.mean()) / (a.std() + 1e-5)).reshape(T * P, 1))
     adv = torch.stack(advs, 1)
     opt = torch.optim.Adam(ours.parameters(), lr=lr)
-    vl, al, ent = ppo_losses(ours, own_obs, opp_obs, acts, vps, rets, olp, adv, clip, True)
+    vl, al, ent = ppo_losses(ours, own_obs, opp_obs, acts, vps, rets, olp, adv, clip, clipped)
     opt.zero_grad()
     (vl * vcoef + al - ent * ecoef).backward()
     torch.nn.utils.clip_grad_norm_(ours.parameters(), gnorm)

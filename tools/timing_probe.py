@@ -1,10 +1,12 @@
 """Experiment: per-section shader-clock breakdown of the pipelined step kernel, per wave role
-(needs exp_libs/libfa_timing.so from tools/make_timing_build.py; run with FA_LIB_OVERRIDE
-pointing at it).  usage: timing_probe.py [E] [G] [A]"""
+(needs tools/_build/libfa_timing.so from tools/make_timing_build.py, which this script loads in
+place of the product library).  usage: timing_probe.py [E] [G] [A]"""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import emergent_multiagent_strategies_amd as fa
+TIMING_LIB = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_build", "libfa_timing.so")
+fa._lib._build.LIB = TIMING_LIB   # same C ABI + fa_dbg_read / fa_dbg_hw
 E = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 G = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 A = int(sys.argv[3]) if len(sys.argv) > 3 else 3
@@ -14,7 +16,7 @@ st = fa.JointRolloutStorage(T, E, G + A, device="cuda")
 eng.bind_storage(st)
 st.actions.copy_(torch.randint(0, 8, st.actions.shape, device="cuda"))
 eng.collect_reset()
-lib = C.CDLL(os.environ["FA_LIB_OVERRIDE"])
+lib = C.CDLL(TIMING_LIB)
 buf = (C.c_ulonglong * 32)()
 for _ in range(3):
     eng.collect_rollout(0, T)

@@ -45,6 +45,8 @@ def get_args():
     p.add_argument("--log-interval", type=int, default=1)
     p.add_argument("--continue-training", action="store_true")
     p.add_argument("--load-dir", default=None, help="checkpoint file to continue from")
+    p.add_argument("--ckpt", type=int, default=0, help="update index of --load-dir; training resumes at ckpt+1 "
+                                                         "(train_fortattack.py:42)")
     p.add_argument("--train-guards-only", action="store_true")
     p.add_argument("--attacker-load-dir", default="tmp")
     p.add_argument("-l", "--attacker-ckpts", nargs="+", type=int, default=[220, 650, 1240, 1600, 2520])
@@ -72,7 +74,9 @@ def main():
                           max_grad_norm=args.max_grad_norm, gamma=args.gamma, tau=args.tau,
                           clipped_value_loss=not args.no_clipped_value_loss, use_graph=not args.no_graph)
     torch.manual_seed(args.seed + 1 + rank)            # different action sampling per rank
-    if args.continue_training and args.load_dir:
+    if args.continue_training:
+        if not args.load_dir:
+            raise SystemExit("--continue-training needs --load-dir (the checkpoint file to resume from)")
         L.load(args.load_dir)
     if args.guard_load_dir:
         L.policies[0].load_state_dict(torch.load(args.guard_load_dir, map_location="cpu", weights_only=False)["models"][0])
@@ -83,14 +87,15 @@ def main():
     num_updates = args.num_frames // args.num_steps // (E * world)   # train_fortattack.py:197
     L.reset()
     start = time.time()
-    for j in range(num_updates):
+    shift = args.ckpt + 1 if args.continue_training else 0           # train_fortattack.py:42-43
+    for j in range(shift, num_updates + shift):
         L.collect()
         vals = L.update(train_guards_only=args.train_guards_only)
         L.after_update()
         if rank == 0 and j % args.save_interval == 0:
             L.save(os.path.join(args.save_dir, "ep%d.pt" % j))       # train_fortattack.py:121-128
         if rank == 0 and j % args.log_interval == 0:
-            total = (j + 1) * E * world * args.num_steps
+            total = (j + 1 - shift) * E * world * args.num_steps
             row, n_ep = eng.eval_stats()
             print(json.dumps({"update": j, "num_timesteps": total, "fps": int(total / (time.time() - start)),
                               "value_loss": float(vals[0, 0]), "action_loss": float(vals[0, 1]),
