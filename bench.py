@@ -6,11 +6,16 @@ E=4096 envs per GPU (FortAttack 3v3, open-loop uniform-random actions already re
 the rollout buffers) through the HIP step kernel with its fused collector write
 (obs / rewards / masks / done rows of the RolloutStorage layout), followed by the GAE scan, the
 one-pass fp64 advantage moments and the advantage normalisation (the only cross-GPU exchange: one
-all-gather of N x 3 doubles when --gpus > 1).  Inputs are in HBM before the timed
-region starts.  The MPNN policy forward is NOT part of this workload (BASELINE config 2:
-"random policy, step-kernel only"); bench_rollout_mpnn.py times config 3.
+all-gather of N x 3 doubles when --gpus > 1).  Inputs are in HBM before the timed region starts.
+That is BASELINE config 2 ("random policy, step-kernel only") plus the collector: `value`.
+
+The same JSON line carries a second record, `closed_loop` = BASELINE config 3 (config 4 when
+--gpus > 1): the MPNN actor-critic (PyTorch-ROCm) in the loop -- per env-step one two-team forward,
+sampling and one fa_collect_step, then V(obs[T]), GAE and the advantage statistics -- and the
+PPO update after it.
 
     python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus 8                      # spawns 8 ranks itself (torch.distributed.run)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
         --master-port 29500 bench.py --gpus 8 --steps 20 --warmup 3
 
@@ -19,16 +24,15 @@ Prints ONE JSON line on rank 0.
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
-HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s measured copy
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~4.7 TB/s measured copy
 
 
 def measured_stream():
@@ -49,38 +53,86 @@ def algorithmic_bytes_per_env_step(n_agents):
     return 138 * n_agents + 9
 
 
-def cpu_baseline(E, G, A, budget_s=16.0):
-    """The CPU oracle (oracle/fa_oracle.c, a C port of the reference's env.step) timed on
-    this box's host cores on a bounded sample of the same workload (uniform-random actions,
-    auto-reset, 3v3).  OpenMP over envs; the thread count is swept (one subprocess each) and
-    the best is reported with its thread count."""
-    import subprocess
+def host_cpu():
+    """CPU model, physical cores and hardware threads of the box (for cpu_baseline)."""
+    model, cores, threads = "?", set(), 0
+    try:
+        phys = core = None
+        for line in open("/proc/cpuinfo"):
+            k, _, v = line.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "model name":
+                model = v
+            elif k == "physical id":
+                phys = v
+            elif k == "core id":
+                core = v
+            elif k == "processor":
+                threads += 1
+            elif not k and phys is not None:
+                cores.add((phys, core))
+        if phys is not None:
+            cores.add((phys, core))
+    except Exception:
+        pass
+    return model, len(cores) or threads, threads
+
+
+def cpu_baseline(E, G, A, T, budget_s=20.0):
+    """The CPU oracle (oracle/fa_oracle.c, a C port of the reference's env.step) timed on this box's
+    host cores on a bounded sample of the same workload (uniform-random actions, auto-reset).
+    Form: fao_rollout -- ONE OpenMP region around the T-step rollout, every thread stepping its own
+    static slice of envs (first-touch placed), threads pinned (OMP_PROC_BIND=close, OMP_PLACES=cores)
+    -- the CPU counterpart of the fused launch.  The thread count is swept (one subprocess each, so
+    that libgomp starts with the right settings) and the best is reported with its thread count."""
     avail = len(os.sched_getaffinity(0))
-    sweep = sorted({t for t in (1, 4, 8, 16, 32, 64, 128, avail) if t <= avail})
-    per = max(1.0, budget_s / len(sweep))
+    model, phys_cores, hw_threads = host_cpu()
+    sweep = sorted({t for t in (1, 8, 16, 32, 64, 128, phys_cores, avail) if 1 <= t <= avail})
+    per = max(1.0, budget_s / (len(sweep) + 1))
     runs = []
-    for t in sweep:
-        env = dict(os.environ, OMP_NUM_THREADS=str(t), OMP_PROC_BIND="false")
-        cmd = [sys.executable, os.path.join(ROOT, "oracle", "cpu_bench.py"), "--envs", str(E if t > 1 else 256),
-               "--guards", str(G), "--attackers", str(A), "--seconds", "%.2f" % per]
+
+    def run(t, mode, envs):
+        env = dict(os.environ, OMP_NUM_THREADS=str(t), OMP_PROC_BIND="close", OMP_PLACES="cores",
+                   OMP_WAIT_POLICY="active")
+        cmd = [sys.executable, os.path.join(ROOT, "oracle", "cpu_bench.py"), "--envs", str(envs), "--guards", str(G),
+               "--attackers", str(A), "--rollout", str(T), "--seconds", "%.2f" % per, "--mode", mode]
         try:
-            out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=per * 6 + 60)
-            runs.append(json.loads(out.stdout.strip().splitlines()[-1]))
+            out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=per * 8 + 60)
+            return json.loads(out.stdout.strip().splitlines()[-1])
         except Exception as exc:  # a reported baseline must not take the bench down
-            runs.append({"threads": t, "env_steps_per_s": 0.0, "error": repr(exc)})
+            return {"threads": t, "env_steps_per_s": 0.0, "error": repr(exc), "mode": mode}
+
+    for t in sweep:
+        # enough envs that every thread has a slice worth the region's fork/join (>= 16 envs per thread)
+        runs.append(run(t, "rollout", max(E, 16 * t)))
     best = max(runs, key=lambda r: r["env_steps_per_s"])
     single = next((r for r in runs if r["threads"] == 1), best)
+    per_step = run(best["threads"], "step", best.get("envs", E))   # one parallel region per env-step (round-1 form)
     return {"value": best["env_steps_per_s"], "unit": "env-steps/s", "cores": best["threads"], "kind": "port",
-            "sample": "oracle/fa_oracle.c (C port of the reference env.step + auto-reset, OpenMP over envs): "
-                      "%d envs x %d steps in %.1f s on %d threads (best of sweep %s over %d available cpus); "
-                      "1 thread: %.0f env-steps/s" % (
-                          best.get("envs", 0), best.get("steps", 0), best.get("seconds", 0.0), best["threads"],
+            "cpu_model": model, "physical_cores": phys_cores, "hardware_threads": hw_threads,
+            "sample": "oracle/fa_oracle.c fao_rollout (C port of the reference env.step + auto-reset; one OpenMP "
+                      "region per %d-step rollout, static env slices, pinned threads): %d envs x %d steps in %.1f s on "
+                      "%d threads; sweep (threads, env-steps/s) = %s over %d usable cpus; 1 thread: %.0f env-steps/s; "
+                      "one parallel region per env-step at the best thread count: %.0f env-steps/s" % (
+                          T, best.get("envs", 0), best.get("steps", 0), best.get("seconds", 0.0), best["threads"],
                           [(r["threads"], int(r["env_steps_per_s"])) for r in runs], avail,
-                          single["env_steps_per_s"]),
+                          single["env_steps_per_s"], per_step["env_steps_per_s"]),
             "single_thread": single["env_steps_per_s"],
             "reference_python_note": "the reference's own Python env.step, measured in the survey container on "
                                      "1 Xeon 2.1 GHz thread: 2580 env-steps/s at 3v3 (BASELINE.md section 3); "
                                      "it cannot run on the GPU box"}
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start N ranks under torch.distributed.run (one
+    process per GPU, rendezvous on 127.0.0.1) with the same arguments and pass their output through."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -88,6 +140,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--min-seconds", type=float, default=0.5,
+                    help="keep timing whole rollouts until the timed region is at least this long (the 128-step "
+                         "rollout takes ~0.2 ms: 20 of them are a 4 ms sample); 0 = exactly --steps")
     ap.add_argument("--envs", type=int, default=4096, help="envs per GPU")
     ap.add_argument("--rollout", type=int, default=128, help="env-steps per rollout (T)")
     ap.add_argument("--guards", type=int, default=3)
@@ -95,21 +150,36 @@ def main():
     ap.add_argument("--launch", choices=["fused", "per-step"], default="fused",
                     help="fused: one launch advances all T steps (open-loop actions); "
                          "per-step: T launches replayed from one hipGraph")
+    ap.add_argument("--no-counters", action="store_true",
+                    help="do not maintain Agent.numHit / numWasHit and the evaluation counters in the timed run")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-collector", action="store_true", help="time the step kernel only")
+    ap.add_argument("--no-closed-loop", action="store_true", help="skip the closed_loop record (MPNN in the loop)")
+    ap.add_argument("--closed-loop-rollouts", type=int, default=3)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL on ROCm)")
     ap.add_argument("--share-devices", action="store_true",
                     help="map ranks onto the visible GPUs round-robin (smoke-testing the multi-rank "
                          "path on a box with fewer GPUs than ranks; use with --backend gloo)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args))
+
+    import torch
+    import torch.distributed as dist
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm GPU (there is no CPU path)")
     if args.share_devices:
         local_rank = local_rank % torch.cuda.device_count()
+    elif local_rank >= torch.cuda.device_count():
+        raise SystemExit("rank %d has no GPU (%d visible); --share-devices --backend gloo runs several ranks on one"
+                         % (local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -125,7 +195,7 @@ def main():
     E, G, A, T = args.envs, args.guards, args.attackers, args.rollout
     N = G + A
     eng = fa.BatchedFortAttack(E, G, A, 100, base_seed=0, env_offset=rank * E, device=local_rank,
-                               track_counters=False)
+                               track_counters=not args.no_counters)
     st = fa.JointRolloutStorage(T, E, N, device=dev)
     eng.bind_storage(st)
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
@@ -163,14 +233,29 @@ def main():
         if world > 1:
             dist.barrier()
 
-    for _ in range(args.warmup):
+    # number of rollouts to time: --steps, raised so that the timed region lasts >= --min-seconds
+    # (decided from a calibration run and agreed across ranks BEFORE the timed region)
+    for _ in range(max(args.warmup, 1)):
         hot_path()
+    torch.cuda.synchronize()
+    steps = args.steps
+    if args.min_seconds > 0:
+        t0 = time.perf_counter()
+        for _ in range(5):
+            hot_path()
+        torch.cuda.synchronize()
+        est = (time.perf_counter() - t0) / 5
+        steps = max(steps, int(args.min_seconds / max(est, 1e-6)) + 1)
+        if world > 1:
+            ts = torch.tensor([steps], device=dev, dtype=torch.int64)
+            dist.all_reduce(ts, op=dist.ReduceOp.MAX)
+            steps = int(ts.item())
     barrier()
     torch.cuda.synchronize()
     # HIP events on the launch stream bracket every env rollout launch of the timed region
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
     t0 = time.perf_counter()
-    for k in range(args.steps):
+    for k in range(steps):
         ev[k][0].record()
         env_rollout()
         ev[k][1].record()
@@ -185,10 +270,10 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
-    env_steps = world * E * T * args.steps
+    env_steps = world * E * T * steps
     value = env_steps / elapsed
     launches_per_rollout = T if graph is not None else 1
-    roll_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
+    roll_ms = sum(a.elapsed_time(b) for a, b in ev) / steps
     launch_s = roll_ms * 1e-3 / launches_per_rollout
     bytes_per_launch = algorithmic_bytes_per_env_step(N) * E * (T // launches_per_rollout)
     achieved = bytes_per_launch / launch_s / 1e9
@@ -198,22 +283,31 @@ def main():
     # MI355X_MICROARCH.md); only attached when the run uses the profiled configuration.
     traffic, traffic_src = None, None
     kernel_name = eng.step_variant(T // launches_per_rollout)   # which step kernel these launches ran
-    prof = os.path.join(ROOT, "profiles", "r01_%s_summary.json" % ("fused" if graph is None else "perstep"))
-    if (E, G, A, T) == (4096, 3, 3, 128) and os.path.isfile(prof):
-        try:
-            ks = json.load(open(prof))["kernels"]
-            k = [v for n, v in ks.items() if n.split("<")[0].endswith(kernel_name.split("/")[0]) and "<3, 3," in n
-                 and "hbm_bytes_per_launch" in v]
-            if k:
-                traffic, traffic_src = k[0]["hbm_bytes_per_launch"], os.path.relpath(prof, ROOT)
-        except Exception:
-            pass
+    if (E, G, A, T) == (4096, 3, 3, 128):
+        for rnd in ("r02", "r01"):
+            prof = os.path.join(ROOT, "profiles", "%s_%s_summary.json" % (rnd, "fused" if graph is None else "perstep"))
+            if not os.path.isfile(prof):
+                continue
+            try:
+                ks = json.load(open(prof))["kernels"]
+                k = [v for n, v in ks.items() if n.split("<")[0].endswith(kernel_name.split("/")[0]) and "<3, 3," in n
+                     and "hbm_bytes_per_launch" in v]
+                if k:
+                    traffic, traffic_src = k[0]["hbm_bytes_per_launch"], os.path.relpath(prof, ROOT)
+                    break
+            except Exception:
+                pass
+
+    closed = None
+    if not args.no_closed_loop:
+        closed = closed_loop(fa, args, rank, local_rank, world, dev, barrier)
 
     if rank == 0:
         res = {
             "metric": "env-steps/sec FortAttack %dv%d, %d parallel envs per GPU" % (G, A, E),
-            "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True,
+            "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": steps, "steps_requested": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / steps, "timed_seconds": elapsed,
+            "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {
                 "workload": "FortAttack %dv%d, %d envs/GPU, %d-step rollout, open-loop uniform-random actions "
@@ -226,25 +320,85 @@ def main():
                                 "(all-gather of N x 3 f64 when n_gpus > 1) and normalisation"),
                 "envs_per_gpu": E, "rollout_steps": T, "num_guards": G, "num_attackers": A,
                 "max_time_steps": 100, "rng": "mt19937 (reference-parity reset stream)",
+                "agent_counters": "off" if args.no_counters else "on (numHit / numWasHit / evaluation counters)",
                 "launch": args.launch, "parallelism": "env shards, %d rank(s)" % world},
             "roofline": {
                 "bound": "hbm", "kernel": "%s<%d,%d>" % (kernel_name, G if (G, A) in ((3, 3), (5, 5)) else 0,
                                                        A if (G, A) in ((3, 3), (5, 5)) else 0),
                 "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                 "traffic": traffic, "traffic_source": traffic_src,
+                # what actually crosses HBM (PMC bytes) over the same launch time: the fused launch keeps the
+                # world state in registers, so `frac` (algorithmic bytes, the agreed accounting) is NOT HBM
+                # utilisation -- this is
+                "traffic_frac": (traffic / launch_s / 1e9 / HBM_PEAK_GBPS) if traffic else None,
+                "limiter": "per-wave issue chain (latency), not bandwidth, at this batch size: see DESIGN.md 3.1 / 7",
                 "measured_stream_GBps": measured_stream(),
                 "algorithmic_bytes_per_launch": bytes_per_launch,
                 "algorithmic_bytes_per_env_step": algorithmic_bytes_per_env_step(N),
                 "env_steps_per_launch": E * (T // launches_per_rollout),
                 "avg_launch_us": launch_s * 1e6, "timed_by": "hipEvents on the launch stream, %d launches" % (
-                    args.steps * launches_per_rollout)},
+                    steps * launches_per_rollout)},
             "env_rollout_ms": roll_ms,
         }
+        if closed is not None:
+            res["closed_loop"] = closed
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(E, G, A)
+            res["cpu_baseline"] = cpu_baseline(E, G, A, T)
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()
+
+
+def closed_loop(fa, args, rank, local_rank, world, dev, barrier):
+    """BASELINE config 3 (config 4 when world > 1): the MPNN actor-critic (h = 128, PyTorch-ROCm) in the
+    loop.  A rollout = T x (two-team forward + sampling + fa_collect_step), V(obs[T]), GAE and the
+    advantage moments (all-gathered over ranks); then one JointPPO update (4 epochs x 32 minibatches
+    per team; flat gradient all-reduce per optimizer step when world > 1)."""
+    import torch
+    import torch.distributed as dist
+    E, G, A, T = args.envs, args.guards, args.attackers, args.rollout
+    torch.manual_seed(0)                                      # identical initial policies on every rank
+    eng = fa.BatchedFortAttack(E, G, A, 100, base_seed=0, env_offset=rank * E, device=local_rank,
+                               track_counters=not args.no_counters)
+    L = fa.BatchedLearner(eng, num_steps=T, use_graph=True)
+    torch.manual_seed(1 + rank)                               # different action sampling per rank
+    L.reset()
+    L.collect()
+    L.after_update()
+    torch.cuda.synchronize()
+    barrier()
+    R = max(1, args.closed_loop_rollouts)
+    t0 = time.perf_counter()
+    for _ in range(R):
+        L.collect()
+        L.after_update()
+    torch.cuda.synchronize()
+    barrier()
+    t_roll = time.perf_counter() - t0
+    L.collect()
+    torch.cuda.synchronize()
+    barrier()
+    t0 = time.perf_counter()
+    L.update()
+    torch.cuda.synchronize()
+    barrier()
+    t_upd = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([t_roll, t_upd], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        t_roll, t_upd = float(tt[0]), float(tt[1])
+    per_rollout = t_roll / R
+    return {
+        "workload": "FortAttack %dv%d, %d envs/GPU, %d-step rollout, MPNN h=128 actor-critic in the loop "
+                    "(BASELINE config %s): two-team forward + sampling + fa_collect_step per env-step replayed from "
+                    "a hipGraph, V(obs[T]), GAE, advantage moments%s" % (
+                        G, A, E, T, "3" if world == 1 else "4", "" if world == 1 else " all-gathered over the ranks"),
+        "rollout_env_steps_per_s": world * E * T / per_rollout, "rollout_ms": per_rollout * 1e3,
+        "ms_per_env_step_launch": per_rollout * 1e3 / T, "rollouts_timed": R,
+        "update_s": t_upd, "train_env_steps_per_s": world * E * T / (per_rollout + t_upd),
+        "update": "JointPPO: 4 epochs x 32 minibatches x 2 teams, Adam, grad-clip%s" % (
+            "" if world == 1 else ", flat gradient all-reduce per optimizer step"),
+        "dtype": "f32 policy / f64 env", "unit": "env-steps/s"}
 
 
 if __name__ == "__main__":

@@ -1265,15 +1265,33 @@ __global__ __launch_bounds__((NPW + 2) * FA_WAVE, MINW) void fa_step_pipe_kernel
             Fx = wx + Fx;
             Fy = wy + Fy;
             // core.py:324-338 integrate_state (mass == 1.0: F/1.0 is exact)
-            vx = vx * k_damp;
-            vy = vy * k_damp;
-            vx += Fx * k_dt;
-            vy += Fy * k_dt;
-            const double speed2 = vx * vx + vy * vy;
-            if (__builtin_expect(speed2 > k_sp2, 0)) { // == sqrt(v.v) > max_speed, see fa_step_kernel
-                const double speed = sqrt_rn(speed2);
-                vx = div_rn(vx, speed) * k_vmax;
-                vy = div_rn(vy, speed) * k_vmax;
+            const double vdx = vx * k_damp, vdy = vy * k_damp;
+            vx = vdx + Fx * k_dt;
+            vy = vdy + Fy * k_dt;
+            double speed2 = vx * vx + vy * vy;
+            // rare block, one test for two cases: the speed limit (sqrt(v.v) > max_speed decided on the
+            // square, see fa_step_kernel) and a NaN -- written !(<=) so that the NaN takes it too
+            if (__builtin_expect(!(speed2 <= k_sp2), 0)) {
+                if (speed2 != speed2) {
+                    // Two agents of the env coincide exactly: their pair force is NaN (0/0, as in the
+                    // reference).  If the partner was shot in this very step the reference skips the
+                    // pair (core.py:233-236 only walks the living) while fma(NaN, 0, F) is NaN: redo
+                    // this lane's sum with the dead partners skipped, the rows are still in LDS.
+                    double Gx = u0, Gy = u1;
+#pragma unroll
+                    for (int j = 0; j < N; ++j)
+                        if ((ga1 >> j) & 1u) { Gx = s_fmx[j][lane] + Gx; Gy = s_fmy[j][lane] + Gy; }
+                    Gx = wx + Gx;
+                    Gy = wy + Gy;
+                    vx = vdx + Gx * k_dt;
+                    vy = vdy + Gy * k_dt;
+                    speed2 = vx * vx + vy * vy;
+                }
+                if (speed2 > k_sp2) {
+                    const double speed = sqrt_rn(speed2);
+                    vx = div_rn(vx, speed) * k_vmax;
+                    vy = div_rn(vy, speed) * k_vmax;
+                }
             }
             ang += rot;
             px += vx * k_dt;

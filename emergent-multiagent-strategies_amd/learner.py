@@ -12,28 +12,32 @@ rollout; the per-step sequence can be replayed from a hipGraph.
   BatchedLearner.collect()      train_fortattack.py:49-110 (rollout + wrap_horizon)
   BatchedLearner.update()       learner.py:175-188 -> JointPPO.update (ppo.py:116-204)
   BatchedLearner.after_update() learner.py:234-236 -> storage.py:51-56
-Multi-GPU: env shards per rank; the advantage statistics are all-reduced (dist.py) and the
-gradients of both policies are averaged with one flat all-reduce per optimizer step.
+Multi-GPU: env shards per rank; the advantage statistics are all-gathered and merged (dist.py) and
+joint_ppo_update() all-reduces one flat buffer per optimizer step (gradients of the un-normalised
+losses + the rank's alive-mask mean), which makes every rank take the reference's step on the union
+minibatch.
 """
 import torch
 import torch.distributed as dist
 import torch.nn as nn
-from torch._utils import _flatten_dense_tensors, _unflatten_dense_tensors
 
 from .dist import gae_adv_mean_std
 from .mpnn import MPNN, TwinMPNN
 from .storage import JointRolloutStorage
 
 
-def ppo_losses(pol, own, opp, actions, value_preds, returns, old_logp, adv, clip_param, clipped_value_loss=True):
+def ppo_losses(pol, own, opp, actions, value_preds, returns, old_logp, adv, clip_param, clipped_value_loss=True,
+               normalize=True):
     """The three alive-masked losses of JointPPO.update for one minibatch (ppo.py:146-187).
     own (B,n,6), opp (B,m,6); the rest (B,n,1).  Works on any device, no host sync: the
     reference's `if mask.mean() != 0: x /= mask.mean()` becomes a division by
-    where(mean != 0, mean, 1) (x is 0 whenever the mean is 0)."""
+    where(mean != 0, mean, 1) (x is 0 whenever the mean is 0).
+    normalize=False leaves that division out and returns mask.mean() as a fourth value: the
+    multi-rank update divides by the mean over ALL ranks' samples after the gradient all-reduce."""
     mask = own[:, :, 0:1]                                      # alive flag = obs[:,0] (ppo.py:224)
     values, logp, ent = pol.evaluate_actions(own, opp, actions)
     mm = mask.mean()
-    denom = torch.where(mm != 0, mm, torch.ones_like(mm))
+    denom = torch.where(mm != 0, mm, torch.ones_like(mm)) if normalize else torch.ones_like(mm)
     dist_entropy = (ent.unsqueeze(-1) * mask).mean() / denom
     ratio = mask * torch.exp(logp - old_logp)
     surr1 = ratio * adv
@@ -47,7 +51,71 @@ def ppo_losses(pol, own, opp, actions, value_preds, returns, old_logp, adv, clip
         # multiplying it by the mask, taking the mean and dividing by mask.mean() gives it back
         vl = 0.5 * (returns - values).pow(2).mean()
     value_loss = (vl * mask).mean() / denom
+    if not normalize:
+        return value_loss, action_loss, dist_entropy, mm
     return value_loss, action_loss, dist_entropy
+
+
+def _world(group=None):
+    return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+
+
+def joint_ppo_update(pol, opt, own_sl, opp_sl, rows, clip_param, ppo_epoch, num_mini_batch, value_loss_coef,
+                     entropy_coef, max_grad_norm, clipped_value_loss=True, group=None, sampler=None):
+    """JointPPO.update (ppo.py:116-204) for one team's shared policy over flattened rollout rows.
+
+    rows = (obs, actions, value_preds, returns, old_log_probs, advantages), each (B, N, .) with B = T * E
+    local samples.  A minibatch is one index set applied to every agent of the team and to its opponents
+    (magent_feed_forward_generator, ppo.py:207-246).  `sampler(epoch)` -> list of index tensors; default =
+    BatchSampler(SubsetRandomSampler(range(B)), int(B / num_mini_batch), drop_last=False) drawn on the device.
+
+    Several ranks (data parallel over env shards): every rank draws minibatches from ITS samples -- the
+    global minibatch is their union -- and one flat all-reduce per optimizer step carries the gradients
+    of the un-normalised losses plus this rank's alive-mask mean; dividing by the all-rank mask mean
+    afterwards gives exactly the gradient of the reference's loss on the union minibatch (the three
+    losses are linear in 1 / mask.mean()), so all ranks step identically.
+    Returns a (3,) tensor: (value_loss, action_loss, entropy) summed over the minibatches and divided by
+    ppo_epoch * num_mini_batch as the reference does (ppo.py:196-200)."""
+    obs_f, act_f, vp_f, ret_f, olp_f, adv_f = rows
+    batch = obs_f.shape[0]
+    assert batch >= num_mini_batch, (
+        "PPO requires the number of processes * number of steps = {} to be greater than "
+        "or equal to the number of PPO mini batches ({}).".format(batch, num_mini_batch))
+    mb = int(batch / num_mini_batch)                             # ppo.py:210
+    world = _world(group)
+    params = [p for p in pol.parameters()]
+    acc = torch.zeros(3, device=obs_f.device)
+    for epoch in range(ppo_epoch):
+        if sampler is not None:
+            batches = sampler(epoch)
+        else:
+            perm = torch.randperm(batch, device=obs_f.device)   # SubsetRandomSampler (ppo.py:213)
+            batches = [perm[k:k + mb] for k in range(0, batch, mb)]   # BatchSampler, drop_last=False
+        for idx in batches:
+            obs_b = obs_f[idx]
+            out = ppo_losses(pol, obs_b[:, own_sl], obs_b[:, opp_sl], act_f[idx][:, own_sl], vp_f[idx][:, own_sl],
+                             ret_f[idx][:, own_sl], olp_f[idx][:, own_sl], adv_f[idx][:, own_sl], clip_param,
+                             clipped_value_loss, normalize=(world == 1))
+            value_loss, action_loss, dist_entropy = out[:3]
+            opt.zero_grad(set_to_none=True)
+            (value_loss * value_loss_coef + action_loss - dist_entropy * entropy_coef).backward()
+            losses = torch.stack([value_loss.detach(), action_loss.detach(), dist_entropy.detach()])
+            if world > 1:
+                grads = [p.grad for p in params if p.grad is not None]
+                flat = torch.cat([g.reshape(-1) for g in grads] + [losses, out[3].detach().reshape(1)])
+                dist.all_reduce(flat, group=group)
+                flat.div_(world)                                 # equal shard sizes: mean over ranks == union mean
+                mm = flat[-1]
+                flat.div_(torch.where(mm != 0, mm, torch.ones_like(mm)))
+                losses = flat[-4:-1]
+                off = 0
+                for g in grads:
+                    g.copy_(flat[off:off + g.numel()].view_as(g))
+                    off += g.numel()
+            nn.utils.clip_grad_norm_(params, max_grad_norm)
+            opt.step()
+            acc += losses
+    return acc / (ppo_epoch * num_mini_batch)                    # ppo.py:196-200 (not the batches actually drawn)
 
 
 class BatchedLearner(object):
@@ -246,53 +314,21 @@ class BatchedLearner(object):
         self.episode_rewards = (st.rewards * st.masks[1:]).sum(0)[..., 0]
 
     # ---- PPO update (ppo.py:116-204) ------------------------------------------------------------
-    def _allreduce_grads(self, params):
-        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1):
-            return
-        grads = [p.grad for p in params if p.grad is not None]
-        flat = _flatten_dense_tensors(grads)
-        dist.all_reduce(flat, group=self.group)
-        flat.div_(dist.get_world_size(self.group))
-        for g, f in zip(grads, _unflatten_dense_tensors(flat, grads)):
-            g.copy_(f)
-
-    def update(self, train_guards_only=False):
+    def update(self, train_guards_only=False, sampler=None):
         """-> float tensor (n_trained_teams, 3) = mean (value_loss, action_loss, entropy)."""
         st, T, E = self.storage, self.T, self.E
         mean, std = self._adv_mean_std                           # ppo.py:121-123, from collect()
         self.eng.adv_normalize(mean, std, out=self.adv)          # ppo.py:123
         flat = lambda t: t.view(T * E, *t.shape[2:])
-        obs_f, act_f = flat(st.obs[:-1]), flat(st.actions)
-        vp_f, ret_f = flat(st.value_preds[:-1]), flat(st.returns[:-1])
-        olp_f, adv_f = flat(st.action_log_probs), flat(self.adv)
-        batch = T * E
-        assert batch >= self.num_mini_batch, (
-            "PPO requires the number of processes ({}) * number of steps ({}) = {} to be greater than "
-            "or equal to the number of PPO mini batches ({}).".format(E, T, batch, self.num_mini_batch))
-        mb = int(batch / self.num_mini_batch)                    # ppo.py:210
+        rows = (flat(st.obs[:-1]), flat(st.actions), flat(st.value_preds[:-1]), flat(st.returns[:-1]),
+                flat(st.action_log_probs), flat(self.adv))
         out = []
         teams = [0] if train_guards_only else [0, 1]             # learner.py:177
         for ti in teams:
-            pol, opt = self.policies[ti], self.optimizers[ti]
-            own_sl, opp_sl = self.team_slices[ti], self.team_slices[1 - ti]
-            params = [p for p in pol.parameters()]
-            acc = torch.zeros(3, device=self.device)
-            for _ in range(self.ppo_epoch):
-                perm = torch.randperm(batch, device=self.device)  # SubsetRandomSampler (ppo.py:213)
-                for k in range(0, batch, mb):                     # BatchSampler, drop_last=False
-                    idx = perm[k:k + mb]
-                    obs_b = obs_f[idx]
-                    own, opp = obs_b[:, own_sl], obs_b[:, opp_sl]
-                    value_loss, action_loss, dist_entropy = ppo_losses(
-                        pol, own, opp, act_f[idx][:, own_sl], vp_f[idx][:, own_sl], ret_f[idx][:, own_sl],
-                        olp_f[idx][:, own_sl], adv_f[idx][:, own_sl], self.clip_param, self.clipped_value_loss)
-                    opt.zero_grad(set_to_none=True)
-                    (value_loss * self.value_loss_coef + action_loss - dist_entropy * self.entropy_coef).backward()
-                    self._allreduce_grads(params)
-                    nn.utils.clip_grad_norm_(params, self.max_grad_norm)
-                    opt.step()
-                    acc += torch.stack([value_loss.detach(), action_loss.detach(), dist_entropy.detach()])
-            out.append(acc / (self.ppo_epoch * self.num_mini_batch))   # ppo.py:196-200 (not the batches actually drawn)
+            out.append(joint_ppo_update(
+                self.policies[ti], self.optimizers[ti], self.team_slices[ti], self.team_slices[1 - ti], rows,
+                self.clip_param, self.ppo_epoch, self.num_mini_batch, self.value_loss_coef, self.entropy_coef,
+                self.max_grad_norm, self.clipped_value_loss, self.group, sampler))
         return torch.stack(out)
 
     def after_update(self):

@@ -39,6 +39,7 @@ def _load():
         _lib.fao_rng_doubles.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         _lib.fao_reset.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         _lib.fao_step.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int] + [C.c_void_p] * 6
+        _lib.fao_rollout.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib.fao_get_state.argtypes = [C.c_void_p] + [C.c_void_p] * 11
         _lib.fao_set_state.argtypes = [C.c_void_p] + [C.c_void_p] * 8
     return _lib
@@ -106,6 +107,21 @@ class OracleEnv(object):
         """Timing helper: step without materialising outputs (a must be int64 (E,N) contiguous)."""
         _lib.fao_step(self._h, _p(actions), self.N, 1, int(bool(auto_reset)), None, None, None, None,
                       None, None)
+
+    def rollout_noout(self, actions, auto_reset=True):
+        """Timing helper: T steps of every env in one OpenMP region (fao_rollout).  actions: int64
+        (T, E, N) contiguous."""
+        assert actions.dtype == np.int64 and actions.flags.c_contiguous and actions.shape[1:] == (self.E, self.N)
+        _lib.fao_rollout(self._h, _p(actions), int(actions.shape[0]), int(bool(auto_reset)), None, None, None)
+
+    def rollout(self, actions, auto_reset=True):
+        """fao_rollout returning the last step's (obs, reward, done)."""
+        a = np.ascontiguousarray(actions, np.int64)
+        obs = np.empty((self.E, self.N, 6), np.float64)
+        rew = np.empty((self.E, self.N), np.float64)
+        done = np.empty(self.E, np.uint8)
+        _lib.fao_rollout(self._h, _p(a), int(a.shape[0]), int(bool(auto_reset)), _p(obs), _p(rew), _p(done))
+        return obs, rew, done
 
     def get_state(self):
         E, N = self.E, self.N

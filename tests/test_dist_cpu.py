@@ -106,3 +106,78 @@ def test_single_process_is_a_no_op_reduce():
     s0 = torch.stack([torch.full((3,), 100.0, dtype=torch.float64), x.sum(0), torch.zeros(3, dtype=torch.float64)], 1)
     mean, std, n = two_pass_mean_std(lambda: s0, lambda m: ((x - m) ** 2).sum(0))
     assert torch.allclose(mean, x.mean(0)) and torch.allclose(std, x.std(0))
+
+
+# ---- f2: the data-parallel JointPPO update (rlcore/algo/ppo.py:116-204, :207-246) ----------------
+def _ppo_rows(seed, B, N):
+    g = torch.Generator().manual_seed(seed)
+    obs = torch.randn(B, N, 6, generator=g)
+    obs[:, :, 0] = (torch.rand(B, N, generator=g) > 0.35).float()            # alive flags: uneven across shards
+    return (obs, torch.randint(0, 8, (B, N, 1), generator=g), torch.randn(B, N, 1, generator=g),
+            torch.randn(B, N, 1, generator=g), -torch.rand(B, N, 1, generator=g) * 2, torch.randn(B, N, 1, generator=g))
+
+
+def _ppo_policy(G, A):
+    from emergent_multiagent_strategies_amd.mpnn import MPNN
+    torch.manual_seed(11)
+    return MPNN(num_agents=G, num_opp_agents=A, hidden_dim=32, num_actions=8)
+
+
+_PPO = dict(clip_param=0.2, ppo_epoch=2, num_mini_batch=3, value_loss_coef=0.5, entropy_coef=0.01, max_grad_norm=0.5)
+
+
+def _ppo_index_sets(seed, B, epochs, nmb):
+    g = torch.Generator().manual_seed(seed)
+    mb = B // nmb
+    return [[p[k:k + mb] for k in range(0, B, mb)] for p in (torch.randperm(B, generator=g) for _ in range(epochs))]
+
+
+def _ppo_worker(rank, world, port, B, G, A, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from emergent_multiagent_strategies_amd.learner import joint_ppo_update
+    pol = _ppo_policy(G, A)
+    opt = torch.optim.SGD(pol.parameters(), lr=0.05)
+    rows = _ppo_rows(100 + rank, B, G + A)                                   # this rank's env shard
+    sets = _ppo_index_sets(200 + rank, B, _PPO["ppo_epoch"], _PPO["num_mini_batch"])
+    losses = joint_ppo_update(pol, opt, slice(0, G), slice(G, G + A), rows, sampler=lambda ep: sets[ep], **_PPO)
+    q.put((rank, {k: v.detach().numpy() for k, v in pol.state_dict().items()}, losses.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_ppo_update_equals_one_rank_on_the_union_minibatches():
+    """Two ranks, each with its own shard of samples and its own index sets: after joint_ppo_update both
+    hold IDENTICAL parameters, equal (to float32 summation order) to one process stepping on the union
+    of the two minibatches -- including the alive-mask normalisation, whose mask.mean() must be the
+    union's, not each rank's."""
+    from emergent_multiagent_strategies_amd.learner import joint_ppo_update
+    world, B, G, A = 2, 90, 3, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ppo_worker, args=(r, world, port, B, G, A, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict((r, (sd, ls)) for r, sd, ls in (q.get(timeout=180) for _ in range(world)))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for k in got[0][0]:
+        assert np.array_equal(got[0][0][k], got[1][0][k]), k                 # every rank took the same step
+    assert np.array_equal(got[0][1], got[1][1])
+    # one process on the union: rows concatenated, minibatch k = rank 0's index set k + rank 1's (offset B)
+    pol = _ppo_policy(G, A)
+    init = {k: v.clone() for k, v in pol.state_dict().items()}
+    opt = torch.optim.SGD(pol.parameters(), lr=0.05)
+    parts = [_ppo_rows(100 + r, B, G + A) for r in range(world)]
+    rows = tuple(torch.cat([parts[0][k], parts[1][k]]) for k in range(6))
+    s0, s1 = [_ppo_index_sets(200 + r, B, _PPO["ppo_epoch"], _PPO["num_mini_batch"]) for r in range(world)]
+    union = [[torch.cat([a, b + B]) for a, b in zip(e0, e1)] for e0, e1 in zip(s0, s1)]
+    losses = joint_ppo_update(pol, opt, slice(0, G), slice(G, G + A), rows, sampler=lambda ep: union[ep], **_PPO)
+    moved = 0.0
+    for k, v in pol.state_dict().items():
+        assert np.abs(v.numpy() - got[0][0][k]).max() < 2e-6, k
+        moved = max(moved, float((v - init[k]).abs().max()))
+    assert moved > 1e-3                                                      # the update did something
+    assert np.abs(losses.numpy() - got[0][1]).max() < 1e-5

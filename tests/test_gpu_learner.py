@@ -130,3 +130,52 @@ def test_ensemble_attackers_per_env_strategy(fa, use_graph):
     out = L.update(train_guards_only=True)
     assert out.shape == (1, 3)
     assert all(torch.equal(a, b) for a, b in zip(att_before, L.attacker_pool[0].parameters()))
+
+
+def test_ensemble_rollout_config5_shape_vs_oracle(fa):
+    """BASELINE config 5's per-GPU shape: 5v5, 4096 envs, K = 5 frozen attacker strategies (h = 128),
+    closed loop.  The env rows must equal the oracle driven by the sampled actions, every env's
+    attacker log-probs must come from the strategy assigned to that env at that step, and a strategy
+    id may only change where an episode ended."""
+    from fa_oracle import OracleEnv
+    torch.manual_seed(5)
+    E, G, A, T, max_t, K = 4096, 5, 5, 48, 20, 5
+    N = G + A
+    eng = fa.BatchedFortAttack(E, G, A, max_t, base_seed=55)
+    orc = OracleEnv(E, G, A, max_t, base_seed=55)
+    L = fa.BatchedLearner(eng, num_steps=T, num_mini_batch=8, ppo_epoch=1, use_graph=False)
+    pool_sd = [fa.MPNN(num_agents=A, num_opp_agents=G, num_actions=8).state_dict() for _ in range(K)]
+    L.load_attacker_ensemble([{"models": [None] * G + [sd] * A, "ob_rms": (None, None)} for sd in pool_sd])
+    L.reset()
+    st = L.storage
+    ids_at = []
+    for s in range(T):
+        ids_at.append(L.attacker_id.clone())
+        L.step(s)
+    assert len(torch.unique(torch.stack(ids_at))) == K
+    _check_rollout_env_rows(L, orc)
+    att = slice(G, N)
+    with torch.no_grad():
+        for s in (0, T // 2, T - 1):
+            obs = st.obs[s]
+            lp_all = torch.stack([p.evaluate_actions(obs[:, att], obs[:, :G], st.actions[s, :, att])[1]
+                                  for p in L.attacker_pool])
+            want = lp_all[ids_at[s], torch.arange(E, device="cuda")]
+            assert (want - st.action_log_probs[s, :, att]).abs().max() < 1e-4, s
+    for s in range(T - 1):
+        moved = ids_at[s + 1] != ids_at[s]
+        assert bool((moved <= (st.done[s] != 0)).all()), s
+    assert int(st.done.sum()) > E
+
+
+def _check_rollout_env_rows(learner, orc):
+    st, T = learner.storage, learner.T
+    obs, rew, msk, done, acts = [getattr(st, k).cpu().numpy() for k in ("obs", "rewards", "masks", "done", "actions")]
+    assert np.array_equal(obs[0], orc.reset().astype(np.float32))
+    for s in range(T):
+        ref = orc.step(acts[s, :, :, 0], auto_reset=True)
+        assert np.array_equal(done[s], ref["done"]), s
+        assert np.array_equal(obs[s + 1], ref["obs"].astype(np.float32)), s
+        assert np.array_equal(rew[s, :, :, 0], ref["reward"].astype(np.float32)), s
+        want_mask = np.where(ref["done"][:, None] != 0, 1, ref["alive_before"]).astype(np.float32)
+        assert np.array_equal(msk[s + 1, :, :, 0], want_mask), s

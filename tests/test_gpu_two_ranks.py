@@ -1,0 +1,165 @@
+"""GPU, two processes sharing cuda:0 (gloo rendezvous on 127.0.0.1): the multi-rank path with the REAL
+kernels under each rank -- env shards by env_offset, fused rollout + GAE + advantage moments on each
+shard, one all-gather of N x 3 doubles, exact merge -- against one process running all the envs; then
+the data-parallel BatchedLearner (closed-loop rollout, JointPPO update with the flat all-reduce) and
+bench.py's self-launching --gpus 2 path.
+"""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _inputs(E, N, T):
+    g = torch.Generator().manual_seed(77)
+    acts = torch.randint(0, 8, (T, E, N, 1), generator=g)
+    acts = torch.where(torch.rand(T, E, N, 1, generator=g) < 0.25, torch.full_like(acts, 7), acts)
+    vals = torch.randn(T + 1, E, N, 1, generator=g)
+    return acts, vals
+
+
+def _run_shard(fa, E_total, lo, per, G, A, T, max_t, group_world):
+    """Rollout + GAE + (all-rank) advantage statistics + normalisation for envs [lo, lo + per)."""
+    from emergent_multiagent_strategies_amd.dist import gae_adv_mean_std
+    N = G + A
+    acts, vals = _inputs(E_total, N, T)
+    eng = fa.BatchedFortAttack(per, G, A, max_t, base_seed=31, env_offset=lo)
+    st = fa.JointRolloutStorage(T, per, N, device="cuda")
+    eng.bind_storage(st)
+    eng.collect_reset()
+    st.actions.copy_(acts[:, lo:lo + per].cuda())
+    st.value_preds.copy_(vals[:, lo:lo + per].cuda())
+    eng.collect_rollout(0, T)
+    mean, std = gae_adv_mean_std(eng, 0.99, 0.95)
+    adv = eng.adv_normalize(mean, std)
+    torch.cuda.synchronize()
+    out = {k: getattr(st, k).cpu().numpy() for k in ("obs", "rewards", "masks", "done", "returns")}
+    out.update(mean=mean.cpu().numpy(), std=std.cpu().numpy(), adv=adv.cpu().numpy())
+    return out
+
+
+def _collector_worker(rank, world, port, cfg, ref_path, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    sys.path.insert(0, ROOT)
+    torch.cuda.set_device(0)                                    # both ranks on the one GPU
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import emergent_multiagent_strategies_amd as fa
+    E, G, A, T, max_t = cfg
+    per = E // world
+    got = _run_shard(fa, E, rank * per, per, G, A, T, max_t, world)
+    ref = np.load(ref_path)
+    sl = slice(rank * per, (rank + 1) * per)
+    err = []
+    for k in ("obs", "rewards", "masks", "done", "returns"):    # rows and GAE: bit for bit
+        if not np.array_equal(got[k], ref[k][:, sl]):
+            err.append(k)
+    if np.abs(got["mean"] - ref["mean"]).max() > 1e-12 or np.abs(got["std"] / ref["std"] - 1).max() > 1e-12:
+        err.append("mean/std")
+    if np.abs(got["adv"] - ref["adv"][:, sl]).max() > 1e-6:
+        err.append("adv")
+    q.put((rank, err, got["mean"], got["std"]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_real_kernels_equal_one_process(tmp_path):
+    import emergent_multiagent_strategies_amd as fa
+    cfg = (512, 3, 3, 48, 15)
+    E, G, A, T, max_t = cfg
+    ref = _run_shard(fa, E, 0, E, G, A, T, max_t, 1)            # one process, all envs, no collective
+    assert int(ref["done"].sum()) > 0
+    ref_path = str(tmp_path / "ref.npz")
+    np.savez(ref_path, **ref)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_collector_worker, args=(r, 2, port, cfg, ref_path, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank, err, _, _ in got:
+        assert err == [], (rank, err)
+    assert np.array_equal(got[0][2], got[1][2]) and np.array_equal(got[0][3], got[1][3])   # same bits on every rank
+
+
+def _learner_worker(rank, world, port, use_graph, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    sys.path.insert(0, ROOT)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import emergent_multiagent_strategies_amd as fa
+    E, G, A, T = 64, 3, 3, 16
+    torch.manual_seed(0)                                        # same initial policies on every rank
+    eng = fa.BatchedFortAttack(E, G, A, 10, base_seed=3, env_offset=rank * E)
+    L = fa.BatchedLearner(eng, num_steps=T, hidden_dim=32, num_mini_batch=4, ppo_epoch=2, use_graph=use_graph)
+    init = [p.detach().clone() for pol in L.policies for p in pol.parameters()]
+    torch.manual_seed(100 + rank)                               # different sampling / minibatches per rank
+    L.reset()
+    for _ in range(2):
+        L.collect()
+        losses = L.update()
+        L.after_update()
+    torch.cuda.synchronize()
+    params = [p.detach().cpu().numpy() for pol in L.policies for p in pol.parameters()]
+    moved = max(float((a - b).abs().max()) for a, b in zip(init, (p for pol in L.policies for p in pol.parameters())))
+    q.put((rank, params, losses.cpu().numpy(), moved, L.storage.actions.cpu().numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_two_rank_learner_update_keeps_ranks_identical(use_graph):
+    """BatchedLearner on two ranks (different env shards, different sampled actions, different minibatch
+    permutations): after two collect + update rounds both ranks hold bit-identical parameters."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_learner_worker, args=(r, 2, port, use_graph, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted((q.get(timeout=600) for _ in range(2)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    (_, p0, l0, moved0, a0), (_, p1, l1, moved1, a1) = got
+    for a, b in zip(p0, p1):
+        assert np.array_equal(a, b)
+    assert np.array_equal(l0, l1) and np.isfinite(l0).all()
+    assert moved0 > 1e-5 and not np.array_equal(a0, a1)         # they trained, on different data
+
+
+def test_bench_self_launches_two_ranks():
+    """`python bench.py --gpus 2` with no launcher around it starts the ranks itself and prints ONE line."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-devices", "--backend",
+                          "gloo", "--envs", "512", "--rollout", "32", "--steps", "3", "--warmup", "1", "--min-seconds",
+                          "0", "--no-cpu-baseline", "--closed-loop-rollouts", "1"],
+                         cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["steps"] == 3 and r["scaling"] == "weak" and r["value"] > 0
+    assert r["roofline"]["frac"] > 0 and r["closed_loop"]["rollout_env_steps_per_s"] > 0
+    assert r["closed_loop"]["train_env_steps_per_s"] > 0

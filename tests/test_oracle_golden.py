@@ -174,3 +174,22 @@ def test_collector_gae_advnorm(golden_dir):
             st[i].after_update()
             assert np.array_equal(st[i].obs, g["after_obs"][j, i])
             assert np.array_equal(st[i].masks, g["after_masks"][j, i])
+
+
+def test_oracle_rollout_equals_per_step_calls():
+    """fao_rollout (T steps per env inside one OpenMP region: the cpu_baseline's form) == T fao_step
+    calls: last-step outputs, world state and reset-stream position, bit for bit."""
+    from fa_oracle import OracleEnv
+    E, G, A, T, max_t = 96, 3, 3, 70, 11
+    rng = np.random.RandomState(4)
+    acts = np.where(rng.rand(T, E, G + A) < 0.3, 7, rng.randint(0, 8, size=(T, E, G + A))).astype(np.int64)
+    a, b = OracleEnv(E, G, A, max_t, base_seed=9), OracleEnv(E, G, A, max_t, base_seed=9)
+    a.reset(), b.reset()
+    for t in range(T):
+        ref = a.step(acts[t], auto_reset=True)
+    obs, rew, done = b.rollout(acts, auto_reset=True)
+    assert np.array_equal(obs, ref["obs"]) and np.array_equal(rew, ref["reward"]) and np.array_equal(done, ref["done"])
+    sa, sb = a.get_state(), b.get_state()
+    for k in sa:
+        assert np.array_equal(sa[k], sb[k], equal_nan=True), k
+    assert np.array_equal(a.rng_doubles(E - 1, 8), b.rng_doubles(E - 1, 8))
