@@ -41,6 +41,12 @@ class Storage(C.Structure):
                 ("actions", c_p), ("masks", c_p), ("done", c_p)]
 
 
+class PolicyIO(C.Structure):
+    _fields_ = [("obs", c_p), ("weights", c_p * 2), ("value", c_p), ("action", c_p), ("log_prob", c_p),
+                ("counter", c_p), ("seed", C.c_uint64), ("step", C.c_int32), ("deterministic", C.c_int32),
+                ("value_only", C.c_int32)]
+
+
 class StateHost(C.Structure):
     _fields_ = [(n, c_p) for n in (
         "pos_x", "pos_y", "vel_x", "vel_y", "ang", "prev_dist", "alive", "time_step", "num_hit",
@@ -73,6 +79,9 @@ EXPORTS = {
     "fa_adv_merge": (C.c_int, [c_p, c_p, C.c_int32, c_p, c_p, c_p]),
     "fa_adv_normalize": (C.c_int, [c_p, c_p, c_p, c_p, c_p]),
     "fa_after_update": (C.c_int, [c_p, c_p]),
+    "fa_policy_act": (C.c_int, [c_p, C.POINTER(PolicyIO), c_p]),
+    "fa_collect_act": (C.c_int, [c_p, C.c_int32, c_p, c_p, C.c_uint64, c_p, C.c_int32, C.c_int32, c_p]),
+    "fa_policy_weight_floats": (C.c_int64, []),
     "fa_get_state": (C.c_int, [c_p, C.POINTER(StateHost)]),
     "fa_set_state": (C.c_int, [c_p, C.POINTER(StateHost)]),
     "fa_selftest_math": (C.c_int, [c_p, C.c_uint64, C.c_uint64, c_p]),

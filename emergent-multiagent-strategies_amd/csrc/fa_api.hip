@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "fa_device.h"
+#include "fa_policy.h"
 #include "fortattack.h"
 
 hipError_t fa_launch_step(const FaStepArgs &a, hipStream_t st);
@@ -496,6 +497,59 @@ int fa_after_update(fa_env *env, void *stream) {
     FA_HIP(hipMemcpyAsync(st.masks, st.masks + T * EN, EN * sizeof(float), hipMemcpyDeviceToDevice, s));
     return FA_OK;
 }
+
+static int policy_launch(fa_env *env, const float *obs, const float *wg, const float *wa, float *value, int64_t *action,
+                         float *logp, const int64_t *counter, uint64_t seed, int step, int deterministic, int value_only,
+                         void *stream, const char *who) {
+    if (!obs || !wg || !wa) return fail(FA_ERR_INVALID, std::string(who) + ": obs and both weight buffers are required");
+    if (!value_only && (!action || !logp)) return fail(FA_ERR_INVALID, std::string(who) + ": action and log_prob are required");
+    if (value_only && !value) return fail(FA_ERR_INVALID, std::string(who) + ": value_only needs value");
+    if (env->cfg.num_guards > FA_POLICY_MAX_TEAM || env->cfg.num_attackers > FA_POLICY_MAX_TEAM)
+        return fail(FA_ERR_INVALID, std::string(who) + ": teams of more than 8 agents are not supported by the fused policy");
+    DeviceGuard guard(env->cfg.device_id);
+    FaPolicyArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.obs = obs;
+    a.w[0] = wg;
+    a.w[1] = wa;
+    a.value = value;
+    a.action = action;
+    a.logp = logp;
+    a.counter = counter;
+    a.seed = seed;
+    a.env_offset = env->cfg.env_offset;
+    a.E = env->cfg.num_envs;
+    a.G = env->cfg.num_guards;
+    a.A = env->cfg.num_attackers;
+    a.step = step;
+    a.deterministic = deterministic;
+    a.value_only = value_only;
+    FA_HIP(fa_launch_policy(a, static_cast<hipStream_t>(stream)));
+    return FA_OK;
+}
+
+int fa_policy_act(fa_env *env, const fa_policy_io *io, void *stream) {
+    if (!env || !io) return fail(FA_ERR_INVALID, "fa_policy_act: null argument");
+    return policy_launch(env, io->obs, io->weights[0], io->weights[1], io->value, io->action, io->log_prob, io->counter,
+                         io->seed, io->step, io->deterministic, io->value_only, stream, "fa_policy_act");
+}
+
+int fa_collect_act(fa_env *env, int32_t step, const float *wg, const float *wa, uint64_t seed, const int64_t *counter,
+                   int32_t deterministic, int32_t value_only, void *stream) {
+    if (!env) return fail(FA_ERR_INVALID, "fa_collect_act: null env");
+    if (!env->bound) return fail(FA_ERR_STATE, "fa_collect_act: no storage bound");
+    const fa_storage &st = env->st;
+    if (step < 0 || step > st.num_steps || (!value_only && step == st.num_steps))
+        return fail(FA_ERR_INVALID, "fa_collect_act: step outside the bound storage");
+    if (!value_only && !st.action_log_probs) return fail(FA_ERR_STATE, "fa_collect_act: storage has no action_log_probs");
+    const size_t EN = (size_t)env->cfg.num_envs * env->N;
+    return policy_launch(env, st.obs + (size_t)step * EN * FA_OBS_DIM, wg, wa, st.value_preds + (size_t)step * EN,
+                         value_only ? nullptr : st.actions + (size_t)step * EN,
+                         value_only ? nullptr : st.action_log_probs + (size_t)step * EN, counter, seed, step,
+                         deterministic, value_only, stream, "fa_collect_act");
+}
+
+int64_t fa_policy_weight_floats(void) { return FA_POLICY_WEIGHT_FLOATS; }
 
 int fa_get_state(fa_env *env, const fa_state_host *o) {
     if (!env || !o) return fail(FA_ERR_INVALID, "fa_get_state: null argument");

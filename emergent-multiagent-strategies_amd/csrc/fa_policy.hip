@@ -1,0 +1,380 @@
+// fa_policy.hip -- the MPNN actor-critic forward (reference mpnn.py:117-192: _fwd, act, get_value) of a
+// whole batch of envs as ONE fused kernel for CDNA4: encoders, opponent attention, the K = 3 message
+// passing rounds, policy / value heads, log-softmax and categorical sampling, written straight into
+// the rollout rows value_preds[s] / actions[s] / action_log_probs[s].
+//
+// Why a kernel of its own: as PyTorch ops one forward of both teams at 4096 envs is ~80 launches and
+// 0.9 ms (18 small fp32 GEMMs at ~50 TFLOP/s plus 60 elementwise / reduction kernels on (24576 x 128)
+// activations); the step kernel next to it takes 7 us.  Here the activations of a tile of envs never
+// leave the CU: 96 rows (= 32 envs x 3 agents at 3v3) live in two LDS buffers, every dense layer is a
+// chain of v_mfma_f32_32x32x2_f32 (exact fp32, 157 TFLOP/s peak) whose B operand -- the weights,
+// pre-packed in lane order by the host -- streams from L2 straight into registers, and the attention
+// between the agents of an env is done on the LDS-resident rows.
+//
+// Algebra.  The network is the reference's (same parameters); three products of consecutive linear maps
+// are folded on the host (mpnn_pack.py), which is exact in real arithmetic and changes fp32 rounding
+// only (~1e-6 relative, the size of a GEMM's own summation-order noise):
+//   scores_ij = norm * (h_i Wq)(h_j Wk)^T           = (h_i A) . h_j          A  = norm * Wq Wk^T
+//   msg_i     = (sum_j a_ij (h_j Wv)) Wout           = (sum_j a_ij h_j) Wv Wout
+//   update    = relu([h | msg] Wu^T + b)             = relu([h | hmix] [Wu1 ; Wv Wout Wu2] + b)
+// so a round is: g = h A (128x128), attention mix on LDS rows, h' = relu([h | hmix] W7 + b) (256x128)
+// -- 48k MACs per row instead of 98k -- and needs two LDS buffers instead of four.  The opponent
+// attention (mpnn.py:372-443) folds the same way: A_o = norm * Wkey Wquery^T, B_o = Wval Wout.
+//
+// Tiling.  Workgroup = 4 waves = one tile of ET = 96 / max(n, m) envs of ONE team (blockIdx.y).  Rows =
+// (env, own agent).  A 32x32x2 MFMA takes A[i = lane & 31][k = lane >> 5]: the K axis is permuted so that
+// lane half hh covers k in [hh*K/2, (hh+1)*K/2) -- then a lane's A values of four consecutive MFMAs are
+// one contiguous 16-byte LDS read, and for the K = 256 update layer half 0 reads h and half 1 reads hmix
+// from their own buffers with no concatenation.  The packed B operand uses the same permutation:
+// float4 index (cb * K/8 + t4) * 64 + lane holds W[k = hh*K/2 + 4*t4 + q][col = 32*cb + (lane & 31)],
+// q = 0..3.  Each wave owns one 32-column block of the layer's output for all three 32-row blocks (its
+// B registers are reused three times); LDS rows are padded to 132 floats (bank-conflict-free 16-byte
+// column reads).
+//
+// Sampling: Gumbel-max over the 8 logits with Philox4x32-10 uniforms keyed by (seed; rollout counter,
+// rollout step, global env index, agent) -- a draw from softmax(logits), i.e. the distribution of
+// FixedCategorical.sample (rlcore/distributions.py:12-13); the stream is the engine's own (torch's
+// generator cannot be reproduced from inside a kernel).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "fa_policy.h"
+
+namespace {
+constexpr int PR = FA_POLICY_ROWS; // rows (env, agent) per tile
+constexpr int LDA = 132;           // padded LDS row stride in floats (128 + 4)
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint32_t hi0 = __umulhi(0xD2511F53u, c[0]), lo0 = 0xD2511F53u * c[0];
+        uint32_t hi1 = __umulhi(0xCD9E8D57u, c[2]), lo1 = 0xCD9E8D57u * c[2];
+        uint32_t n0 = hi1 ^ c[1] ^ k0, n2 = hi0 ^ c[3] ^ k1;
+        c[0] = n0; c[1] = lo1; c[2] = n2; c[3] = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+
+// acc[r] += Act[rows of block r][K] * W[K][32 columns of one block]   (fp32 MFMA, exact fmaf chain)
+// arow: this lane's first A element -- &Act[(rb0*32 + (lane & 31)) * LDA + <start of the lane half's k range>]
+// wp:   packed weights of the column block: [K/8][64] float4
+template <int K, int NRB>
+__device__ __forceinline__ void gemm_cb(const float *arow, const float4 *__restrict__ wp, f32x16 (&acc)[NRB], int lane) {
+    constexpr int NT = K / 8;          // 16-byte steps per lane half
+    constexpr int CH = NT < 8 ? NT : 8; // weights prefetched a chunk of CH steps ahead
+    float4 bq[CH], bn[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) bq[c] = wp[c * 64 + lane];
+#pragma unroll
+    for (int t0 = 0; t0 < NT; t0 += CH) {
+        if (t0 + CH < NT) {
+#pragma unroll
+            for (int c = 0; c < CH; ++c) bn[c] = wp[(t0 + CH + c) * 64 + lane];
+        }
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+#pragma unroll
+            for (int r = 0; r < NRB; ++r) {
+                const float4 a = *reinterpret_cast<const float4 *>(arow + r * 32 * LDA + (t0 + c) * 4);
+                acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bq[c].x, acc[r], 0, 0, 0);
+                acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bq[c].y, acc[r], 0, 0, 0);
+                acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bq[c].z, acc[r], 0, 0, 0);
+                acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bq[c].w, acc[r], 0, 0, 0);
+            }
+        }
+        if (t0 + CH < NT) {
+#pragma unroll
+            for (int c = 0; c < CH; ++c) bq[c] = bn[c];
+        }
+    }
+}
+
+// C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+template <bool RELU>
+__device__ __forceinline__ void store_acc(float *dst, int rb, const f32x16 &acc, float bias, int lane) {
+    const int col = lane & 31, hh = lane >> 5;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const int row = rb * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
+        float v = acc[reg] + bias;
+        if (RELU) v = fmaxf(v, 0.0f);
+        dst[row * LDA + col] = v;
+    }
+}
+
+__device__ __forceinline__ float group16_sum(float v) { // sum over the 16 lanes of a row's sub-group
+    v += __shfl_xor(v, 1);
+    v += __shfl_xor(v, 2);
+    v += __shfl_xor(v, 4);
+    v += __shfl_xor(v, 8);
+    return v;
+}
+
+// Attention mix of one row r = (env el, own agent i) by a 16-lane sub-group: scores s_j = g[r] . key[j]
+// over the env's `nk` key rows (skipping j == skip), softmax, out[r] = sum_j a_j key[j]  (W floats per row,
+// W / 16 per lane).  `g` and `out` may be the same row (g[r] is only read by this sub-group).
+template <int W>
+__device__ __forceinline__ void attend_row(const float *grow, const float *key0, int nk, int skip, float *orow, int q) {
+    constexpr int C = W / 16; // columns per lane: 4 or 8
+    float gv[C];
+#pragma unroll
+    for (int c = 0; c < C; c += 4) *reinterpret_cast<float4 *>(gv + c) = *reinterpret_cast<const float4 *>(grow + q * C + c);
+    float s[FA_POLICY_MAX_TEAM];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < FA_POLICY_MAX_TEAM; ++j) {
+        s[j] = -INFINITY;
+        if (j < nk && j != skip) {
+            float kv[C];
+#pragma unroll
+            for (int c = 0; c < C; c += 4)
+                *reinterpret_cast<float4 *>(kv + c) = *reinterpret_cast<const float4 *>(key0 + j * LDA + q * C + c);
+            float d = 0.0f;
+#pragma unroll
+            for (int c = 0; c < C; ++c) d = fmaf(gv[c], kv[c], d);
+            s[j] = group16_sum(d);
+            mx = fmaxf(mx, s[j]);
+        }
+    }
+    float den = 0.0f;
+#pragma unroll
+    for (int j = 0; j < FA_POLICY_MAX_TEAM; ++j) {
+        s[j] = (j < nk && j != skip) ? __expf(s[j] - mx) : 0.0f;
+        den += s[j];
+    }
+    const float inv = den > 0.0f ? 1.0f / den : 0.0f; // a team of one has nobody to listen to: msg = 0 (mpnn.py:266-274)
+    float ov[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) ov[c] = 0.0f;
+#pragma unroll
+    for (int j = 0; j < FA_POLICY_MAX_TEAM; ++j) {
+        if (j < nk && j != skip) {
+            const float a = s[j] * inv;
+#pragma unroll
+            for (int c = 0; c < C; c += 4) {
+                const float4 kv = *reinterpret_cast<const float4 *>(key0 + j * LDA + q * C + c);
+                ov[c] = fmaf(a, kv.x, ov[c]);
+                ov[c + 1] = fmaf(a, kv.y, ov[c + 1]);
+                ov[c + 2] = fmaf(a, kv.z, ov[c + 2]);
+                ov[c + 3] = fmaf(a, kv.w, ov[c + 3]);
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < C; c += 4) *reinterpret_cast<float4 *>(orow + q * C + c) = *reinterpret_cast<const float4 *>(ov + c);
+}
+
+__global__ __launch_bounds__(256, 1) void fa_policy_kernel(FaPolicyArgs a) {
+    __shared__ __attribute__((aligned(16))) float sH[PR * LDA]; // own hidden state h (128 wide)
+    __shared__ __attribute__((aligned(16))) float sG[PR * LDA]; // g / hmix; opponent stage scratch
+    __shared__ float sX[PR * 2 * FA_OBS_DIM];                    // observations of the tile's envs (all agents)
+    __shared__ float sO[PR * 16];                                // logits (8) + value per row
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int team = blockIdx.y;
+    const int N = a.G + a.A;
+    const int n = team == 0 ? a.G : a.A, m = N - n;   // own / opponent team size
+    const int own0 = team == 0 ? 0 : a.G, opp0 = team == 0 ? a.G : 0;
+    const int ET = PR / (n > m ? n : m);               // envs per tile
+    const int e0 = blockIdx.x * ET;
+    if (e0 >= a.E) return;
+    const int ne = (a.E - e0) < ET ? (a.E - e0) : ET;  // envs of this tile
+    const float *W = a.w[team];
+
+    // ---- observations of the tile (contiguous in the (E, N, 6) row) -------------------------------------
+    for (int k = tid; k < ET * N * FA_OBS_DIM; k += 256)
+        sX[k] = k < ne * N * FA_OBS_DIM ? a.obs[(size_t)e0 * N * FA_OBS_DIM + k] : 0.0f;
+    __syncthreads();
+
+    // ---- encoders (mpnn.py:37-38): h1 = relu(x We + be) -> sH[:, 0:64] (own rows), ho -> sG[:, 0:64] (opp rows)
+    {
+        const int col = tid & 63, grp = tid >> 6;
+        float we[FA_OBS_DIM], wo[FA_OBS_DIM];
+#pragma unroll
+        for (int k = 0; k < FA_OBS_DIM; ++k) {
+            we[k] = W[FA_POFF_WE + k * 64 + col];
+            wo[k] = W[FA_POFF_WOE + k * 64 + col];
+        }
+        const float be = W[FA_POFF_BE + col], bo = W[FA_POFF_BOE + col];
+        for (int r = grp; r < PR; r += 4) {
+            float vo = 0.0f, vp = 0.0f;
+            if (r < ET * n) {
+                const int el = r / n, i = r - el * n;
+                const float *x = sX + (el * N + own0 + i) * FA_OBS_DIM;
+                vo = be;
+#pragma unroll
+                for (int k = 0; k < FA_OBS_DIM; ++k) vo = fmaf(x[k], we[k], vo);
+                vo = fmaxf(vo, 0.0f);
+            }
+            if (r < ET * m) {
+                const int el = r / m, j = r - el * m;
+                const float *x = sX + (el * N + opp0 + j) * FA_OBS_DIM;
+                vp = bo;
+#pragma unroll
+                for (int k = 0; k < FA_OBS_DIM; ++k) vp = fmaf(x[k], wo[k], vp);
+                vp = fmaxf(vp, 0.0f);
+            }
+            sH[r * LDA + col] = vo;
+            sG[r * LDA + col] = vp;
+        }
+    }
+    __syncthreads();
+
+    const int li = lane & 31, hh = lane >> 5;
+    const float4 *Wq = reinterpret_cast<const float4 *>(W);
+    // ---- opponent attention (mpnn.py:372-443): g_o = h1 A_o -> sG[:, 64:128] --------------------------------
+    // 64 output columns = 2 column blocks: waves 0,1 take row blocks 0,1; waves 2,3 row block 2
+    {
+        const int cb = wave & 1;
+        const float4 *wp = Wq + FA_POFF_AO / 4 + cb * (64 / 8) * 64;
+        if (wave < 2) {
+            f32x16 acc[2] = {};
+            gemm_cb<64, 2>(sH + li * LDA + hh * 32, wp, acc, lane);
+            store_acc<false>(sG + 64 + cb * 32, 0, acc[0], 0.0f, lane);
+            store_acc<false>(sG + 64 + cb * 32, 1, acc[1], 0.0f, lane);
+        } else {
+            f32x16 acc[1] = {};
+            gemm_cb<64, 1>(sH + (64 + li) * LDA + hh * 32, wp, acc, lane);
+            store_acc<false>(sG + 64 + cb * 32, 2, acc[0], 0.0f, lane);
+        }
+    }
+    __syncthreads();
+    // scores against the env's opponents, softmax, mix of the opponents' encodings -> sG[r][64:128]
+    {
+        const int q = lane & 15;
+        for (int r = wave * 4 + (lane >> 4); r < PR; r += 16) {
+            const int el = r / n; // (rows beyond the tile's envs mix zeros: harmless, never stored)
+            if (r < ET * n) attend_row<64>(sG + r * LDA + 64, sG + (el * m) * LDA, m, -1, sG + r * LDA + 64, q);
+        }
+    }
+    __syncthreads();
+    // e_opp = hmix_o B_o -> sH[:, 64:128]   (h = [h1 | e_opp], mpnn.py:143)
+    {
+        const int cb = wave & 1;
+        const float4 *wp = Wq + FA_POFF_BO / 4 + cb * (64 / 8) * 64;
+        if (wave < 2) {
+            f32x16 acc[2] = {};
+            gemm_cb<64, 2>(sG + li * LDA + 64 + hh * 32, wp, acc, lane);
+            store_acc<false>(sH + 64 + cb * 32, 0, acc[0], 0.0f, lane);
+            store_acc<false>(sH + 64 + cb * 32, 1, acc[1], 0.0f, lane);
+        } else {
+            f32x16 acc[1] = {};
+            gemm_cb<64, 1>(sG + (64 + li) * LDA + 64 + hh * 32, wp, acc, lane);
+            store_acc<false>(sH + 64 + cb * 32, 2, acc[0], 0.0f, lane);
+        }
+    }
+    __syncthreads();
+
+    // ---- K = 3 rounds of message passing with shared weights (mpnn.py:155-157) ------------------------------
+    for (int round = 0; round < 3; ++round) {
+        {   // g = h A -> sG (wave = column block)
+            f32x16 acc[3] = {};
+            gemm_cb<128, 3>(sH + li * LDA + hh * 64, Wq + FA_POFF_AM / 4 + wave * (128 / 8) * 64, acc, lane);
+#pragma unroll
+            for (int rb = 0; rb < 3; ++rb) store_acc<false>(sG + wave * 32, rb, acc[rb], 0.0f, lane);
+        }
+        __syncthreads();
+        {   // team attention, self excluded (mpnn.py:297-298): hmix -> sG rows
+            const int q = lane & 15;
+            for (int r = wave * 4 + (lane >> 4); r < PR; r += 16) {
+                const int el = r / n, i = r - el * n;
+                if (r < ET * n) attend_row<128>(sG + r * LDA, sH + (el * n) * LDA, n, i, sG + r * LDA, q);
+            }
+        }
+        __syncthreads();
+        {   // h' = relu([h | hmix] W7 + bu): lane half 0 walks h, half 1 walks hmix
+            f32x16 acc[3] = {};
+            gemm_cb<256, 3>((hh ? sG : sH) + li * LDA, Wq + FA_POFF_W7 / 4 + wave * (256 / 8) * 64, acc, lane);
+            const float bias = W[FA_POFF_BU + wave * 32 + li];
+            __syncthreads(); // every wave has read the old h
+#pragma unroll
+            for (int rb = 0; rb < 3; ++rb) store_acc<true>(sH + wave * 32, rb, acc[rb], bias, lane);
+        }
+        __syncthreads();
+    }
+
+    // ---- heads: [p | v] = relu(h [Wp0 | Wv0] + b) (mpnn.py:66-72), p -> sG, v -> sH ------------------------
+    {
+        f32x16 accp[3] = {}, accv[3] = {};
+        gemm_cb<128, 3>(sH + li * LDA + hh * 64, Wq + FA_POFF_W8 / 4 + wave * (128 / 8) * 64, accp, lane);
+        gemm_cb<128, 3>(sH + li * LDA + hh * 64, Wq + FA_POFF_W8 / 4 + (4 + wave) * (128 / 8) * 64, accv, lane);
+        const float bp = W[FA_POFF_B8 + wave * 32 + li], bv = W[FA_POFF_B8 + 128 + wave * 32 + li];
+        __syncthreads(); // every wave has read h
+#pragma unroll
+        for (int rb = 0; rb < 3; ++rb) {
+            store_acc<true>(sG + wave * 32, rb, accp[rb], bp, lane);
+            store_acc<true>(sH + wave * 32, rb, accv[rb], bv, lane);
+        }
+    }
+    __syncthreads();
+    // logits (8) | value (1) = [p | v] W9 + b9, W9 block diagonal in a 32-column block: wave = row block
+    if (wave < 3) {
+        f32x16 acc[1] = {};
+        gemm_cb<256, 1>((hh ? sH : sG) + (wave * 32 + li) * LDA, Wq + FA_POFF_W9 / 4, acc, lane);
+        if (li < 16) {
+            const float bias = W[FA_POFF_B9 + li];
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int row = wave * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
+                sO[row * 16 + li] = acc[0][reg] + bias;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- value, log-softmax, sample, log-prob of the sample -> rollout rows ----------------------------------
+    if (tid < ne * n) {
+        const int el = tid / n, i = tid - el * n;
+        const int e = e0 + el;
+        const size_t o = (size_t)e * N + own0 + i;
+        const float *lo = sO + tid * 16;
+        if (a.value) a.value[o] = lo[8];
+        if (!a.value_only) {
+            float lg[FA_NUM_ACTIONS], mx = -INFINITY;
+#pragma unroll
+            for (int k = 0; k < FA_NUM_ACTIONS; ++k) { lg[k] = lo[k]; mx = fmaxf(mx, lg[k]); }
+            float se = 0.0f;
+#pragma unroll
+            for (int k = 0; k < FA_NUM_ACTIONS; ++k) se += expf(lg[k] - mx);
+            const float lse = mx + logf(se);
+            int act = 0;
+            if (a.deterministic) { // FixedCategorical.mode (distributions.py:16-17)
+                float best = lg[0];
+#pragma unroll
+                for (int k = 1; k < FA_NUM_ACTIONS; ++k)
+                    if (lg[k] > best) { best = lg[k]; act = k; }
+            } else {
+                const uint64_t ge = (uint64_t)(a.env_offset + e);
+                const uint32_t ctr = a.counter ? (uint32_t)a.counter[0] : 0u;
+                float best = -INFINITY;
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    uint32_t c[4] = {(uint32_t)ge, (uint32_t)(ge >> 32) ^ ((uint32_t)(own0 + i) << 16) ^ ((uint32_t)half << 31),
+                                     (uint32_t)a.step, ctr};
+                    philox4x32_10(c, (uint32_t)a.seed, (uint32_t)(a.seed >> 32));
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float u = ((float)(c[k] >> 8) + 0.5f) * (1.0f / 16777216.0f); // (0, 1)
+                        const float z = lg[half * 4 + k] - logf(-logf(u));                   // Gumbel-max
+                        if (z > best) { best = z; act = half * 4 + k; }
+                    }
+                }
+            }
+            float la = lg[0];
+#pragma unroll
+            for (int k = 1; k < FA_NUM_ACTIONS; ++k) la = (k == act) ? lg[k] : la;
+            a.action[o] = (int64_t)act;
+            a.logp[o] = la - lse;
+        }
+    }
+}
+} // namespace
+
+hipError_t fa_launch_policy(const FaPolicyArgs &a, hipStream_t st) {
+    const int n_max = a.G > a.A ? a.G : a.A;
+    const int ET = PR / n_max;
+    const int tiles = (a.E + ET - 1) / ET;
+    hipLaunchKernelGGL(fa_policy_kernel, dim3(tiles, 2), dim3(256), 0, st, a);
+    return hipGetLastError();
+}

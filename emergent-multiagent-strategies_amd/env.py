@@ -209,6 +209,33 @@ class BatchedFortAttack(object):
     def after_update(self):
         _lib.check(self._lib.fa_after_update(self._h, _stream()), "fa_after_update")
 
+    # -- fused policy (csrc/fa_policy.hip) ----------------------------------------------------
+    def policy_act(self, obs, w_guards, w_attackers, seed=0, counter=None, step=0, deterministic=False,
+                   value_only=False, out=None):
+        """fa_policy_act: both teams' MPNN forward + sampling on an observation row obs (E, N, 6) float32.
+        w_*: packed weight buffers (mpnn_pack.pack_policy).  Returns (value, action, log_prob), each (E, N)
+        (action / log_prob are None with value_only)."""
+        assert obs.is_cuda and obs.dtype == torch.float32 and obs.is_contiguous() and tuple(obs.shape) == (self.E, self.N, 6)
+        for w in (w_guards, w_attackers):
+            assert w.is_cuda and w.dtype == torch.float32 and w.is_contiguous() and w.numel() == self._lib.fa_policy_weight_floats()
+        value, action, logp = out if out is not None else (
+            self._new((self.E, self.N), torch.float32),
+            None if value_only else self._new((self.E, self.N), torch.int64),
+            None if value_only else self._new((self.E, self.N), torch.float32))
+        io = _lib.PolicyIO()
+        io.obs, io.value, io.action, io.log_prob, io.counter = _ptr(obs), _ptr(value), _ptr(action), _ptr(logp), _ptr(counter)
+        io.weights[0], io.weights[1] = w_guards.data_ptr(), w_attackers.data_ptr()
+        io.seed, io.step, io.deterministic, io.value_only = int(seed), int(step), int(bool(deterministic)), int(bool(value_only))
+        _lib.check(self._lib.fa_policy_act(self._h, C.byref(io), _stream()), "fa_policy_act")
+        return value, action, logp
+
+    def collect_act(self, step, w_guards, w_attackers, seed=0, counter=None, deterministic=False, value_only=False):
+        """fa_collect_act: the policies act on storage.obs[step] and write value_preds / actions /
+        action_log_probs[step] (value_only: only value_preds[step], the V(obs[T]) of wrap_horizon)."""
+        _lib.check(self._lib.fa_collect_act(self._h, int(step), _ptr(w_guards), _ptr(w_attackers), int(seed),
+                                            _ptr(counter), int(bool(deterministic)), int(bool(value_only)), _stream()),
+                   "fa_collect_act")
+
     # -- state snapshot ----------------------------------------------------------------
     _F64 = ("pos_x", "pos_y", "vel_x", "vel_y", "ang", "prev_dist")
 

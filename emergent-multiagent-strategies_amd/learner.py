@@ -3,11 +3,12 @@
 What the reference does per env-step in Python -- cat the per-agent observations
 (learner.py:150-152), one MPNN forward per team (:160), chunk the outputs back per agent
 (:164-170, with a ``.cpu().numpy()`` per agent), ``env.step``, seven ``copy_`` per agent into
-its RolloutStorage (storage.py:33-43) -- is here: two MPNN forwards on one contiguous
-``obs[s]`` row each, their outputs written straight into the ``value_preds[s] / actions[s] /
-action_log_probs[s]`` rows, and one ``fa_collect_step`` launch that reads ``actions[s]`` and
-writes ``obs[s+1] / rewards[s] / masks[s+1] / done[s]``.  Nothing leaves the GPU during a
-rollout; the per-step sequence can be replayed from a hipGraph.
+its RolloutStorage (storage.py:33-43) -- is here two launches per env-step: ``fa_collect_act``
+(the fused MPNN forward of both teams + sampling, csrc/fa_policy.hip: reads the ``obs[s]`` row, writes
+``value_preds[s] / actions[s] / action_log_probs[s]``) and ``fa_collect_step`` (reads ``actions[s]``,
+writes ``obs[s+1] / rewards[s] / masks[s+1] / done[s]``).  Nothing leaves the GPU during a rollout and
+the whole T-step rollout + V(obs[T]) replays from ONE hipGraph.  ``policy_backend="torch"`` keeps the
+forwards in the PyTorch modules (any hidden size; also what an attacker ensemble uses).
 
   BatchedLearner.collect()      train_fortattack.py:49-110 (rollout + wrap_horizon)
   BatchedLearner.update()       learner.py:175-188 -> JointPPO.update (ppo.py:116-204)
@@ -22,6 +23,7 @@ import torch.distributed as dist
 import torch.nn as nn
 
 from .dist import gae_adv_mean_std
+from . import mpnn_pack
 from .mpnn import MPNN, TwinMPNN
 from .storage import JointRolloutStorage
 
@@ -121,8 +123,11 @@ def joint_ppo_update(pol, opt, own_sl, opp_sl, rows, clip_param, ppo_epoch, num_
 class BatchedLearner(object):
     def __init__(self, eng, num_steps=128, hidden_dim=128, lr=1e-4, clip_param=0.2, ppo_epoch=4,
                  num_mini_batch=32, value_loss_coef=0.5, entropy_coef=0.01, max_grad_norm=0.5,
-                 gamma=0.99, tau=0.95, clipped_value_loss=True, use_graph=False, group=None):
+                 gamma=0.99, tau=0.95, clipped_value_loss=True, use_graph=False, group=None, policy_backend="auto",
+                 sample_seed=None):
         # defaults: arguments.py:22-45
+        # policy_backend: "hip" = the fused fa_policy kernel runs the rollout's forwards (hidden_dim 128),
+        # "torch" = the PyTorch modules do, "auto" = hip whenever it supports the configuration
         self.eng, self.T, self.G, self.A, self.N, self.E = eng, num_steps, eng.G, eng.A, eng.N, eng.E
         self.device = eng.device
         self.gamma, self.tau = gamma, tau
@@ -145,6 +150,16 @@ class BatchedLearner(object):
         self.episode_rewards = torch.zeros((self.E, self.N), device=self.device)
         self.attacker_pool, self.attacker_id = [], None
         self._twin_net = None
+        hip_ok = all(mpnn_pack.supported(p) for p in self.policies)
+        if policy_backend not in ("auto", "hip", "torch"):
+            raise ValueError("policy_backend must be 'auto', 'hip' or 'torch'")
+        if policy_backend == "hip" and not hip_ok:
+            raise ValueError("the fused policy kernel needs hidden_dim = 128 and teams of <= 8 agents")
+        self.policy_backend = "hip" if (policy_backend != "torch" and hip_ok) else "torch"
+        # packed weights of the two policies (rewritten in place whenever the parameters may have moved)
+        self._packed = [mpnn_pack.pack_policy(p) for p in self.policies] if self.policy_backend == "hip" else None
+        self.sample_seed = int(torch.initial_seed() if sample_seed is None else sample_seed) & ((1 << 63) - 1)
+        self._rollout_counter = torch.zeros(1, dtype=torch.int64, device=self.device)
 
     # ---- model I/O (train_fortattack.py:123-128, learner.py:245-249) ----------------------
     def state_dicts(self):
@@ -183,6 +198,7 @@ class BatchedLearner(object):
             raise RuntimeError("load the ensemble before the first reset() when use_graph is set")
         self.attacker_pool = pool
         self.attacker_id = torch.randint(len(pool), (self.E,), device=self.device)
+        self.attacker_id_rows = torch.zeros((self.T, self.E), dtype=torch.int64, device=self.device)
 
     def _attacker_forward(self, fn_name, own, opp):
         """Run every strategy on the whole batch and keep, per env, the output of that env's."""
@@ -195,9 +211,9 @@ class BatchedLearner(object):
 
     # ---- rollout -------------------------------------------------------------------------
     def reset(self):
-        """env.reset() + initialize_obs (train_fortattack.py:29,49).  With use_graph the
-        per-step hipGraphs are captured here first: capture needs a few real warm-up steps,
-        and before the first reset the world holds nothing worth keeping."""
+        """env.reset() + initialize_obs (train_fortattack.py:29,49).  With use_graph the rollout's
+        hipGraph is captured here first: capture needs a few real warm-up steps, and before the first
+        reset the world holds nothing worth keeping."""
         if self.use_graph and self._graphs is None:
             if self.eng.max_time_steps < 8:
                 raise ValueError("use_graph needs max_time_steps >= 8 (warm-up steps must not end an episode)")
@@ -212,9 +228,16 @@ class BatchedLearner(object):
             self._twin_net = TwinMPNN(self.policies[0], self.policies[1])
         return self._twin_net
 
+    def _hip(self):
+        """The fused kernel runs the forwards unless an attacker ensemble is loaded (per-env weights)."""
+        return self.policy_backend == "hip" and not self.attacker_pool
+
     @torch.no_grad()
     def _act_into_storage(self, s):
         st = self.storage
+        if self._hip():   # one launch: both teams' forward + sampling -> value_preds / actions / action_log_probs[s]
+            self.eng.collect_act(s, self._packed[0], self._packed[1], self.sample_seed, self._rollout_counter)
+            return
         obs = st.obs[s]
         twin = self._twin()
         if twin is not None:
@@ -238,6 +261,7 @@ class BatchedLearner(object):
         self._act_into_storage(s)
         self.eng.collect_step(s, auto_reset=True)
         if self.attacker_pool:   # sample_attacker() after every episode end (train_fortattack_v2.py:110-111)
+            self.attacker_id_rows[s].copy_(self.attacker_id)   # which strategy each env faced at step s
             fresh = torch.randint(len(self.attacker_pool), (self.E,), device=self.device)
             self.attacker_id.copy_(torch.where(self.storage.done[s] != 0, fresh, self.attacker_id))  # in place: graph-safe
 
@@ -257,29 +281,57 @@ class BatchedLearner(object):
         obs = np.stack([np.ones((E, N)), tile(x), tile(y), tile(ang), np.zeros((E, N)), np.zeros((E, N))], -1)
         self.storage.obs[:2] = torch.from_numpy(obs.astype(np.float32)).to(self.device)
 
+    @torch.no_grad()
+    def _value_last(self):
+        """wrap_horizon: V(obs[T]) -> value_preds[T] (learner.py:196-202)."""
+        st = self.storage
+        if self._hip():
+            self.eng.collect_act(self.T, self._packed[0], self._packed[1], value_only=True)
+            return
+        obs = st.obs[self.T]
+        if self._twin() is not None:
+            st.value_preds[self.T].copy_(self._twin_net.get_value(obs))
+            return
+        for pol, own_sl, opp_sl in ((self.policies[0], self.team_slices[0], self.team_slices[1]),
+                                    (self.policies[1], self.team_slices[1], self.team_slices[0])):
+            if pol is self.policies[1] and self.attacker_pool:
+                st.value_preds[self.T, :, own_sl] = self._attacker_forward("get_value", obs[:, own_sl], obs[:, opp_sl])
+            else:
+                st.value_preds[self.T, :, own_sl] = pol.get_value(obs[:, own_sl], obs[:, opp_sl])
+
     def _capture(self):
-        """One hipGraph per rollout index (every launch argument is then a fixed pointer)."""
+        """ONE hipGraph for the whole rollout: T x (act + env step) and V(obs[T]) -- every launch argument
+        is a fixed pointer into the rollout buffers, so the T steps are T different node sets."""
         import numpy as np
         self._warm_state()
         side = torch.cuda.Stream(self.device)
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
-            for s in (0, 1, 0):  # warm up allocator / rocBLAS handles on a side stream
+            for s in (0, 1, 0):  # warm up allocator / rocBLAS handles / code objects on a side stream
                 self.step(s)
+            self._value_last()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        graphs = []
-        pool = None
-        for s in range(self.T):
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=pool):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for s in range(self.T):
                 self.step(s)
-            pool = g.pool()
-            graphs.append(g)
+            self._value_last()
         # the warm-up steps set prevDist; it survives resets in the reference (quirk Q1), so put
         # back "None" -- everything else is rewritten by the reset that follows
         self.eng.set_state(dict(prev_dist=np.full((self.E, self.N), np.nan)))
-        return graphs
+        return g
+
+    def refresh_policy_weights(self):
+        """Bring every derived copy of the parameters up to date IN PLACE (captured graphs read them):
+        the fused kernel's packed buffers, the torch path's fused / stacked operands."""
+        if self._packed is not None:
+            for pol, buf in zip(self.policies, self._packed):
+                mpnn_pack.pack_policy(pol, out=buf)
+        for pol in self.policies + list(self.attacker_pool):
+            pol.refresh_fused_weights()
+        if self._twin() is not None:
+            self._twin_net.refresh()
 
     def collect(self):
         """A T-step rollout from the current obs[0] + GAE (train_fortattack.py:51-110).
@@ -287,27 +339,14 @@ class BatchedLearner(object):
         st = self.storage
         if self.use_graph and self._graphs is None:
             raise RuntimeError("call reset() before collect()")
-        for pol in self.policies + list(self.attacker_pool):
-            pol.refresh_fused_weights()   # captured graphs read these buffers; weights may have moved
-        if self._twin() is not None:
-            self._twin_net.refresh()
-        for s in range(self.T):
-            if self._graphs is not None:
-                self._graphs[s].replay()
-            else:
+        self.refresh_policy_weights()
+        self._rollout_counter.add_(1)              # a fresh sampling stream for this rollout (fused kernel)
+        if self._graphs is not None:
+            self._graphs.replay()
+        else:
+            for s in range(self.T):
                 self.step(s)
-        with torch.no_grad():                      # wrap_horizon: V(obs[T]) (learner.py:196-202)
-            obs = st.obs[self.T]
-            if self._twin() is not None:
-                st.value_preds[self.T].copy_(self._twin_net.get_value(obs))
-            else:
-                for pol, own_sl, opp_sl in ((self.policies[0], self.team_slices[0], self.team_slices[1]),
-                                            (self.policies[1], self.team_slices[1], self.team_slices[0])):
-                    if pol is self.policies[1] and self.attacker_pool:
-                        st.value_preds[self.T, :, own_sl] = self._attacker_forward("get_value", obs[:, own_sl],
-                                                                                   obs[:, opp_sl])
-                    else:
-                        st.value_preds[self.T, :, own_sl] = pol.get_value(obs[:, own_sl], obs[:, opp_sl])
+            self._value_last()
         # compute_returns + the advantage mean / std of ppo.py:121-123 (over ALL ranks) in one pass
         self._adv_mean_std = gae_adv_mean_std(self.eng, self.gamma, self.tau, self.group)
         # train_fortattack.py:88: episode_rewards += reward * masks (alive before the step)

@@ -223,6 +223,39 @@ int fa_adv_normalize(fa_env *env, const double *mean, const double *std, float *
 /* RolloutStorage.after_update (storage.py:51-56). */
 int fa_after_update(fa_env *env, void *stream);
 
+/* ---- policy in the loop ------------------------------------ */
+/* The MPNN actor-critic forward of both teams (reference mpnn.py:117-192: _fwd + act / get_value;
+ * called per env-step from learner.py:143-172) as ONE fused launch: encoders, opponent attention,
+ * the K = 3 message-passing rounds, policy and value heads, log-softmax and categorical sampling
+ * (FixedCategorical.sample / .mode, rlcore/distributions.py:12-17), hidden_dim = 128, fp32 MFMA.
+ * weights[t] is team t's policy (0 = guards, 1 = attackers) in the packed layout of
+ * csrc/fa_policy.h (FA_POFF_*; FA_POLICY_WEIGHT_FLOATS floats; filled from a reference state_dict
+ * by mpnn_pack.pack_policy) -- three pairs of consecutive linear maps are pre-multiplied there, which
+ * is exact in real arithmetic.  Outputs are (E, N) rows, guards first: value, action (0..7), log-prob of the
+ * action.  Sampling stream: Philox4x32-10 keyed by (seed; *counter, step, global env index, agent).
+ * Teams of up to 8 agents. */
+typedef struct fa_policy_io {
+    const float *obs;            /* (E, N, 6) device: the observation row the policies act on */
+    const float *weights[2];     /* device, packed (see above) */
+    float *value;                /* (E, N) or NULL */
+    int64_t *action;             /* (E, N); ignored when value_only */
+    float *log_prob;             /* (E, N); ignored when value_only */
+    const int64_t *counter;      /* device scalar or NULL: bump it once per rollout so that equal (seed, step)
+                                    of different rollouts draw differently */
+    uint64_t seed;
+    int32_t step;                /* rollout index of this call (part of the sampling key) */
+    int32_t deterministic;       /* != 0: argmax instead of a sample */
+    int32_t value_only;          /* != 0: get_value (mpnn.py:202-205): only `value` is written */
+} fa_policy_io;
+int fa_policy_act(fa_env *env, const fa_policy_io *io, void *stream);
+/* The same on the bound storage: reads obs[step], writes value_preds[step], actions[step],
+ * action_log_probs[step] (Learner.act + the policy half of RolloutStorage.insert, learner.py:143-172,
+ * storage.py:33-43); with value_only only value_preds[step] (wrap_horizon's V(obs[T]), learner.py:196-202). */
+int fa_collect_act(fa_env *env, int32_t step, const float *weights_guards, const float *weights_attackers,
+                   uint64_t seed, const int64_t *counter, int32_t deterministic, int32_t value_only, void *stream);
+/* number of floats of one team's packed weight buffer */
+int64_t fa_policy_weight_floats(void);
+
 /* ---- state access (synchronous; tests / checkpoint) ------------------------------ */
 int fa_get_state(fa_env *env, const fa_state_host *out);
 int fa_set_state(fa_env *env, const fa_state_host *in); /* pos/vel/ang/prev_dist/alive/time_step */

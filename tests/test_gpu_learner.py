@@ -47,8 +47,9 @@ def _check_rollout_against_oracle(fa, learner, orc, first):
     return ep_start, rew, vals, msk, rets
 
 
-@pytest.mark.parametrize("use_graph", [False, True])
-def test_closed_loop_rollout_and_update(fa, use_graph, tmp_path):
+@pytest.mark.parametrize("use_graph,hidden,backend", [(False, 32, "torch"), (True, 32, "torch"),
+                                                      (False, 128, "hip"), (True, 128, "hip")])
+def test_closed_loop_rollout_and_update(fa, use_graph, hidden, backend, tmp_path):
     import collector_oracle as co
     from fa_oracle import OracleEnv
     torch.manual_seed(0)
@@ -56,7 +57,8 @@ def test_closed_loop_rollout_and_update(fa, use_graph, tmp_path):
     N = G + A
     eng = fa.BatchedFortAttack(E, G, A, max_t, base_seed=21)
     orc = OracleEnv(E, G, A, max_t, base_seed=21)
-    L = fa.BatchedLearner(eng, num_steps=T, hidden_dim=32, num_mini_batch=4, ppo_epoch=2, use_graph=use_graph)
+    L = fa.BatchedLearner(eng, num_steps=T, hidden_dim=hidden, num_mini_batch=4, ppo_epoch=2, use_graph=use_graph)
+    assert L.policy_backend == backend
     L.reset()
     stale = np.zeros((T + 1, E, N, 1), np.float32)
     for upd in range(2):
@@ -84,7 +86,7 @@ def test_closed_loop_rollout_and_update(fa, use_graph, tmp_path):
     L.save(path)
     ck = torch.load(path, weights_only=False)
     assert set(ck) == {"models", "ob_rms"} and len(ck["models"]) == N and ck["ob_rms"] == (None, None)
-    L2 = fa.BatchedLearner(fa.BatchedFortAttack(8, G, A, max_t), num_steps=4, hidden_dim=32)
+    L2 = fa.BatchedLearner(fa.BatchedFortAttack(8, G, A, max_t), num_steps=4, hidden_dim=hidden)
     L2.load(path)
     for a, b in zip(L.policies[1].parameters(), L2.policies[1].parameters()):
         assert torch.equal(a, b)
@@ -106,14 +108,15 @@ def test_ensemble_attackers_per_env_strategy(fa, use_graph):
     L.reset()
     ids_before = L.attacker_id.clone()
     st = L.storage
-    # step by step (eager path of collect) so the strategy ids in force at each step are known
-    ids_at = []
-    for s in range(T):
-        ids_at.append(L.attacker_id.clone())
-        if L._graphs is not None:
-            L._graphs[s].replay()
-        else:
+    if use_graph:       # the whole rollout replays from one graph; attacker_id_rows logs the ids in force per step
+        L._graphs.replay()
+        ids_at = list(L.attacker_id_rows.clone())
+    else:               # step by step (eager path of collect)
+        ids_at = []
+        for s in range(T):
+            ids_at.append(L.attacker_id.clone())
             L.step(s)
+        assert torch.equal(torch.stack(ids_at), L.attacker_id_rows)
     att = slice(G, G + A)
     with torch.no_grad():
         for s in range(T):

@@ -1,0 +1,134 @@
+"""GPU numerics of the fused policy kernel (csrc/fa_policy.hip, through fa_policy_act / fa_collect_act)
+against the plain PyTorch fp32 MPNN module (emergent-multiagent-strategies_amd/mpnn.py, itself pinned to
+the reference's mpnn.py by tests/test_mpnn_cpu.py).
+
+Tolerance: 2e-4 absolute on values and log-probs (fp32 MFMA chains of length 64..256 over five to six
+layers, three linear-map pairs pre-multiplied on the host; observed ~1e-5).  Sampling is checked as a
+distribution (it is the engine's own Philox stream, not torch's).
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-4
+
+
+@pytest.fixture(scope="module")
+def fa():
+    import emergent_multiagent_strategies_amd as m
+    assert torch.cuda.is_available()
+    m._lib.load()
+    return m
+
+
+def _policies(fa, G, A, seed):
+    from emergent_multiagent_strategies_amd import mpnn_pack
+    torch.manual_seed(seed)
+    pols = [fa.MPNN(num_agents=G, num_opp_agents=A, num_actions=8).cuda(),
+            fa.MPNN(num_agents=A, num_opp_agents=G, num_actions=8).cuda()]
+    for pol in pols:
+        for p in pol.parameters():          # non-zero biases, larger logits than the 0.01-gain init gives
+            if p.dim() == 1:
+                p.data.uniform_(-0.3, 0.3)
+        pol.dist.linear.weight.data.mul_(3.0)
+    return pols, [mpnn_pack.pack_policy(p) for p in pols]
+
+
+def _obs(E, N, seed):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    obs = torch.randn((E, N, 6), device="cuda", generator=g)
+    obs[:, :, 0] = (torch.rand((E, N), device="cuda", generator=g) > 0.3).float()
+    obs[:, :, 3] = obs[:, :, 3] * 3 + 4.7    # headings are O(1..10)
+    return obs.contiguous()
+
+
+def _torch_reference(pols, obs, G):
+    with torch.no_grad():
+        lg, vg = pols[0].logits_value(obs[:, :G], obs[:, G:])
+        la, va = pols[1].logits_value(obs[:, G:], obs[:, :G])
+    return torch.cat((lg, la), 1), torch.cat((vg, va), 1)[..., 0]
+
+
+@pytest.mark.parametrize("G,A,E", [(3, 3, 4096), (5, 5, 1000), (2, 4, 333), (1, 3, 65), (8, 8, 50), (3, 3, 1), (4, 1, 97)])
+def test_fused_forward_matches_torch_module(fa, G, A, E):
+    N = G + A
+    pols, packed = _policies(fa, G, A, 10 * G + A)
+    eng = fa.BatchedFortAttack(E, G, A, 20)
+    obs = _obs(E, N, E)
+    logits, value = _torch_reference(pols, obs, G)
+    v, act, lp = eng.policy_act(obs, packed[0], packed[1], deterministic=True)
+    assert (v - value).abs().max() < TOL
+    logp_all = F.log_softmax(logits, dim=-1)
+    assert (lp - logp_all.gather(-1, act.unsqueeze(-1))[..., 0]).abs().max() < TOL
+    top2 = logits.topk(2, dim=-1).values
+    clear = (top2[..., 0] - top2[..., 1]) > 1e-3                  # argmax is only defined away from ties
+    assert torch.equal(act[clear], logits.argmax(-1)[clear]) and float(clear.float().mean()) > 0.9
+    assert int(act.min()) >= 0 and int(act.max()) <= 7
+    v2, none_a, none_l = eng.policy_act(obs, packed[0], packed[1], value_only=True)   # get_value (mpnn.py:202-205)
+    assert torch.equal(v2, v) and none_a is None and none_l is None
+
+
+def test_sampling_is_a_draw_from_softmax_and_reproducible(fa):
+    G, A, E = 3, 3, 16384
+    N = G + A
+    pols, packed = _policies(fa, G, A, 3)
+    eng = fa.BatchedFortAttack(E, G, A, 20)
+    obs = _obs(1, N, 9).expand(E, N, 6).contiguous()             # every env sees the same observation
+    logits, _ = _torch_reference(pols, obs[:1], G)
+    probs = F.softmax(logits[0], dim=-1)                          # (N, 8)
+    counter = torch.zeros(1, dtype=torch.int64, device="cuda")
+    v, act, lp = eng.policy_act(obs, packed[0], packed[1], seed=123, counter=counter, step=5)
+    freq = torch.stack([(act == k).float().mean(0) for k in range(8)], -1)          # (N, 8)
+    sigma = torch.sqrt(probs * (1 - probs) / E) + 1e-4
+    assert float(((freq - probs).abs() / sigma).max()) < 5.5     # every cell within 5.5 sigma
+    assert (lp - F.log_softmax(logits[0], -1)[None].expand(E, N, 8).gather(-1, act.unsqueeze(-1))[..., 0]).abs().max() < TOL
+    _, act2, lp2 = eng.policy_act(obs, packed[0], packed[1], seed=123, counter=counter, step=5)
+    assert torch.equal(act, act2) and torch.equal(lp, lp2)        # same key -> same draws
+    for kw in (dict(seed=124, step=5), dict(seed=123, step=6)):
+        _, other, _ = eng.policy_act(obs, packed[0], packed[1], counter=counter, **kw)
+        assert float((other != act).float().mean()) > 0.3
+    counter.add_(1)                                               # the per-rollout counter is part of the key
+    _, other, _ = eng.policy_act(obs, packed[0], packed[1], seed=123, counter=counter, step=5)
+    assert float((other != act).float().mean()) > 0.3
+    # agents of one env and neighbouring envs draw independently
+    a0 = act[:, 0].float()
+    assert abs(float(torch.corrcoef(torch.stack((a0[:-1], a0[1:])))[0, 1])) < 0.05
+    assert abs(float(torch.corrcoef(torch.stack((act[:, 0].float(), act[:, 1].float())))[0, 1])) < 0.05
+
+
+def test_env_shards_draw_what_one_big_batch_draws(fa):
+    """The sampling key holds the GLOBAL env index: two half handles (env_offset) == one full handle."""
+    G, A, E = 3, 3, 640
+    N = G + A
+    pols, packed = _policies(fa, G, A, 4)
+    obs = _obs(E, N, 2)
+    full = fa.BatchedFortAttack(E, G, A, 20).policy_act(obs, packed[0], packed[1], seed=7, step=3)
+    lo = fa.BatchedFortAttack(E // 2, G, A, 20, env_offset=0).policy_act(obs[:E // 2].contiguous(), packed[0], packed[1], seed=7, step=3)
+    hi = fa.BatchedFortAttack(E // 2, G, A, 20, env_offset=E // 2).policy_act(obs[E // 2:].contiguous(), packed[0], packed[1], seed=7, step=3)
+    for k in range(3):
+        assert torch.equal(full[k], torch.cat((lo[k], hi[k])))
+
+
+def test_collect_act_writes_the_policy_rows(fa):
+    G, A, E, T = 3, 3, 200, 6
+    N = G + A
+    pols, packed = _policies(fa, G, A, 5)
+    eng = fa.BatchedFortAttack(E, G, A, 20, base_seed=1)
+    st = fa.JointRolloutStorage(T, E, N, device="cuda")
+    eng.bind_storage(st)
+    eng.collect_reset()
+    for s in range(T):
+        eng.collect_act(s, packed[0], packed[1], seed=11)
+        eng.collect_step(s)
+    eng.collect_act(T, packed[0], packed[1], value_only=True)
+    for s in range(T + 1):
+        logits, value = _torch_reference(pols, st.obs[s], G)
+        assert (st.value_preds[s, :, :, 0] - value).abs().max() < TOL, s
+        if s < T:
+            want = F.log_softmax(logits, -1).gather(-1, st.actions[s])[..., 0]
+            assert (st.action_log_probs[s, :, :, 0] - want).abs().max() < TOL, s
+    assert len(torch.unique(st.actions)) == 8
+    with pytest.raises(fa.FaError):
+        eng.collect_act(T, packed[0], packed[1])                 # step T has no action row

@@ -145,3 +145,33 @@ def test_twin_forward_equals_two_separate_forwards(MPNN):
             assert (lt2[1] - la2).abs().max() < 1e-5 and (lt2[1] - lt[1]).abs().max() > 1e-4
     with pytest.raises(ValueError):
         TwinMPNN(MPNN(num_agents=2, num_opp_agents=3, num_actions=8), MPNN(num_agents=3, num_opp_agents=2, num_actions=8))
+
+
+@pytest.mark.parametrize("n,m", [(3, 3), (5, 5), (2, 4), (1, 3), (4, 1)])
+def test_packed_weights_reproduce_the_module(n, m):
+    """mpnn_pack: the fused kernel's weight buffer (three linear-map pairs multiplied out, dense operands in
+    MFMA B-operand lane order) evaluated with plain torch ops == MPNN.logits_value."""
+    from emergent_multiagent_strategies_amd.mpnn import MPNN
+    from emergent_multiagent_strategies_amd import mpnn_pack as mp_
+    torch.manual_seed(n * 10 + m)
+    pol = MPNN(num_agents=n, num_opp_agents=m, num_actions=8)
+    for p in pol.parameters():                      # biases are zero-initialised: make them count
+        if p.dim() == 1:
+            p.data.uniform_(-0.3, 0.3)
+    flat = mp_.pack_policy(pol)
+    assert flat.numel() == mp_.WEIGHT_FLOATS and flat.dtype == torch.float32
+    own, opp = torch.randn(50, n, 6), torch.randn(50, m, 6)
+    own[:, :, 0], opp[:, :, 0] = (torch.rand(50, n) > 0.3).float(), (torch.rand(50, m) > 0.3).float()
+    with torch.no_grad():
+        logits, value = pol.logits_value(own, opp)
+    l2, v2 = mp_.folded_forward(flat, own, opp)
+    assert (logits - l2).abs().max() < 2e-5 and (value - v2).abs().max() < 2e-5
+    w = torch.randn(256, 128)
+    assert torch.equal(mp_.unpack_gemm(mp_.pack_gemm(w), 256, 128), w)
+    # lane order: float4 (cb * K/8 + t4) * 64 + lane = W[(lane >> 5) * K/2 + 4*t4 + q][32*cb + (lane & 31)]
+    pk, K = mp_.pack_gemm(w).view(-1, 4), 256
+    for cb, t4, lane, q in ((0, 0, 0, 0), (3, 31, 63, 3), (1, 7, 40, 2)):
+        assert pk[(cb * (K // 8) + t4) * 64 + lane, q] == w[(lane >> 5) * (K // 2) + 4 * t4 + q, 32 * cb + (lane & 31)]
+    mp_.pack_policy(pol, out=flat)                  # in-place refresh keeps the storage
+    with pytest.raises(ValueError):
+        mp_.pack_policy(MPNN(num_agents=3, num_opp_agents=3, hidden_dim=32, num_actions=8))
