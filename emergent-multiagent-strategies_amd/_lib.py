@@ -44,7 +44,7 @@ class Storage(C.Structure):
 class PolicyIO(C.Structure):
     _fields_ = [("obs", c_p), ("weights", c_p * 2), ("value", c_p), ("action", c_p), ("log_prob", c_p),
                 ("counter", c_p), ("seed", C.c_uint64), ("step", C.c_int32), ("deterministic", C.c_int32),
-                ("value_only", C.c_int32)]
+                ("value_only", C.c_int32), ("attacker_pool", c_p), ("pool_size", C.c_int32), ("env_strategy", c_p)]
 
 
 class StateHost(C.Structure):
@@ -67,6 +67,7 @@ EXPORTS = {
     "fa_num_envs": (C.c_int, [c_p]),
     "fa_reset": (C.c_int, [c_p, c_p, c_p, c_p, c_p]),
     "fa_step": (C.c_int, [c_p, C.POINTER(StepIO), c_p]),
+    "fa_set_reset_choice": (C.c_int, [c_p, C.c_int32, c_p]),
     "fa_bind_storage": (C.c_int, [c_p, C.POINTER(Storage)]),
     "fa_collect_step": (C.c_int, [c_p, C.c_int32, C.c_int32, c_p]),
     "fa_collect_rollout": (C.c_int, [c_p, C.c_int32, C.c_int32, C.c_int32, c_p]),
@@ -80,7 +81,7 @@ EXPORTS = {
     "fa_adv_normalize": (C.c_int, [c_p, c_p, c_p, c_p, c_p]),
     "fa_after_update": (C.c_int, [c_p, c_p]),
     "fa_policy_act": (C.c_int, [c_p, C.POINTER(PolicyIO), c_p]),
-    "fa_collect_act": (C.c_int, [c_p, C.c_int32, c_p, c_p, C.c_uint64, c_p, C.c_int32, C.c_int32, c_p]),
+    "fa_collect_act": (C.c_int, [c_p, C.c_int32, C.POINTER(PolicyIO), c_p]),
     "fa_policy_weight_floats": (C.c_int64, []),
     "fa_get_state": (C.c_int, [c_p, C.POINTER(StateHost)]),
     "fa_set_state": (C.c_int, [c_p, C.POINTER(StateHost)]),

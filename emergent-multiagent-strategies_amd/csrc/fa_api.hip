@@ -12,7 +12,7 @@
 
 hipError_t fa_launch_step(const FaStepArgs &a, hipStream_t st);
 hipError_t fa_launch_reset(const FaStepArgs &a, hipStream_t st);
-const char *fa_step_variant_name(int G, int A, int E, int nsteps, int step_kernel);
+const char *fa_step_variant_name(int G, int A, int E, int nsteps, int step_kernel, bool choice);
 hipError_t fa_launch_seed(const FaState &s, int E, uint64_t base_seed, int64_t env_offset, int skip_words,
                           hipStream_t st);
 hipError_t fa_launch_selftest(unsigned long long n_per_thread, unsigned long long seed, unsigned long long *mismatch,
@@ -55,6 +55,10 @@ struct fa_env {
     double *adv_partial; // [ADV_BLOCKS][N]
     double *adv_stats;   // [N][3] scratch of fa_adv_mean_std
     int adv_blocks;
+    int choice_k;        // fa_set_reset_choice
+    int32_t *choice_out;
+    int32_t *grp_env_list, *grp_tile_strategy; // fused policy with an attacker ensemble: envs grouped by strategy
+    int grp_tiles_max;
 };
 
 namespace {
@@ -145,6 +149,8 @@ FaStepArgs base_args(const fa_env *env) {
     a.rng_mode = env->cfg.rng_mode;
     a.track_counters = env->cfg.track_counters;
     a.step_kernel = env->cfg.step_kernel;
+    a.choice_k = env->choice_k;
+    a.choice_out = env->choice_out;
     a.seed = env->cfg.base_seed;
     a.env_offset = env->cfg.env_offset;
     a.c = env->c;
@@ -237,6 +243,11 @@ int fa_create(const fa_config *cfg, fa_env **out) {
     const size_t o_ale = carve(EN * sizeof(uint32_t));
     const size_t o_adv = carve((size_t)env->adv_blocks * FA_MAX_AGENTS * 2 * sizeof(double));
     const size_t o_advs = carve((size_t)FA_MAX_AGENTS * 4 * sizeof(double));
+    const bool fused_ok = cfg->num_guards <= FA_POLICY_MAX_TEAM && cfg->num_attackers <= FA_POLICY_MAX_TEAM;
+    const int tile_envs = fused_ok ? fa_policy_tile_envs(cfg->num_guards, cfg->num_attackers) : 1;
+    env->grp_tiles_max = fused_ok ? (cfg->num_envs + tile_envs - 1) / tile_envs + FA_POLICY_MAX_POOL : 0;
+    const size_t o_gel = carve((size_t)env->grp_tiles_max * tile_envs * sizeof(int32_t));
+    const size_t o_gts = carve((size_t)env->grp_tiles_max * sizeof(int32_t));
     env->slab_bytes = off;
     hipError_t he = hipMalloc(&env->slab, env->slab_bytes);
     if (he != hipSuccess) {
@@ -265,6 +276,8 @@ int fa_create(const fa_config *cfg, fa_env **out) {
     env->s.alive_end = reinterpret_cast<uint32_t *>(b + o_ale);
     env->adv_partial = reinterpret_cast<double *>(b + o_adv);
     env->adv_stats = reinterpret_cast<double *>(b + o_advs);
+    env->grp_env_list = reinterpret_cast<int32_t *>(b + o_gel);
+    env->grp_tile_strategy = reinterpret_cast<int32_t *>(b + o_gts);
 
     // construction state (core.py:102-104): alive, prevDist None (NaN); positions are
     // defined by the first reset.
@@ -328,6 +341,14 @@ int fa_step(fa_env *env, const fa_step_io *io, void *stream) {
     a.was_hit = io->was_hit;
     a.auto_reset = io->auto_reset;
     FA_HIP(fa_launch_step(a, static_cast<hipStream_t>(stream)));
+    return FA_OK;
+}
+
+int fa_set_reset_choice(fa_env *env, int32_t k, int32_t *choice_out) {
+    if (!env) return fail(FA_ERR_INVALID, "fa_set_reset_choice: null env");
+    if (k < 0 || (k > 0 && !choice_out)) return fail(FA_ERR_INVALID, "fa_set_reset_choice: k >= 0, and k > 0 needs choice_out");
+    env->choice_k = k;
+    env->choice_out = k > 0 ? choice_out : nullptr;
     return FA_OK;
 }
 
@@ -500,13 +521,17 @@ int fa_after_update(fa_env *env, void *stream) {
 
 static int policy_launch(fa_env *env, const float *obs, const float *wg, const float *wa, float *value, int64_t *action,
                          float *logp, const int64_t *counter, uint64_t seed, int step, int deterministic, int value_only,
-                         void *stream, const char *who) {
-    if (!obs || !wg || !wa) return fail(FA_ERR_INVALID, std::string(who) + ": obs and both weight buffers are required");
+                         const float *pool, int pool_size, const int32_t *env_strategy, void *stream, const char *who) {
+    if (!obs || !wg || (!wa && pool_size <= 0))
+        return fail(FA_ERR_INVALID, std::string(who) + ": obs and both teams' weight buffers are required");
     if (!value_only && (!action || !logp)) return fail(FA_ERR_INVALID, std::string(who) + ": action and log_prob are required");
     if (value_only && !value) return fail(FA_ERR_INVALID, std::string(who) + ": value_only needs value");
     if (env->cfg.num_guards > FA_POLICY_MAX_TEAM || env->cfg.num_attackers > FA_POLICY_MAX_TEAM)
         return fail(FA_ERR_INVALID, std::string(who) + ": teams of more than 8 agents are not supported by the fused policy");
+    if (pool_size > 0 && (!pool || !env_strategy || pool_size > FA_POLICY_MAX_POOL))
+        return fail(FA_ERR_INVALID, std::string(who) + ": an attacker pool needs weights, env_strategy and <= 64 strategies");
     DeviceGuard guard(env->cfg.device_id);
+    hipStream_t s = static_cast<hipStream_t>(stream);
     FaPolicyArgs a;
     std::memset(&a, 0, sizeof(a));
     a.obs = obs;
@@ -524,29 +549,39 @@ static int policy_launch(fa_env *env, const float *obs, const float *wg, const f
     a.step = step;
     a.deterministic = deterministic;
     a.value_only = value_only;
-    FA_HIP(fa_launch_policy(a, static_cast<hipStream_t>(stream)));
+    if (pool_size > 0) { // group the envs into tiles of equal strategy, then one launch over the grouped tiles
+        FA_HIP(fa_launch_group_envs(env_strategy, a.E, pool_size, a.G, a.A, env->grp_env_list, env->grp_tile_strategy,
+                                    env->grp_tiles_max, s));
+        a.pool = pool;
+        a.env_list = env->grp_env_list;
+        a.tile_strategy = env->grp_tile_strategy;
+        a.tiles = env->grp_tiles_max;
+    }
+    FA_HIP(fa_launch_policy(a, s));
     return FA_OK;
 }
 
 int fa_policy_act(fa_env *env, const fa_policy_io *io, void *stream) {
     if (!env || !io) return fail(FA_ERR_INVALID, "fa_policy_act: null argument");
     return policy_launch(env, io->obs, io->weights[0], io->weights[1], io->value, io->action, io->log_prob, io->counter,
-                         io->seed, io->step, io->deterministic, io->value_only, stream, "fa_policy_act");
+                         io->seed, io->step, io->deterministic, io->value_only, io->attacker_pool, io->pool_size,
+                         io->env_strategy, stream, "fa_policy_act");
 }
 
-int fa_collect_act(fa_env *env, int32_t step, const float *wg, const float *wa, uint64_t seed, const int64_t *counter,
-                   int32_t deterministic, int32_t value_only, void *stream) {
-    if (!env) return fail(FA_ERR_INVALID, "fa_collect_act: null env");
+int fa_collect_act(fa_env *env, int32_t step, const fa_policy_io *io, void *stream) {
+    if (!env || !io) return fail(FA_ERR_INVALID, "fa_collect_act: null argument");
     if (!env->bound) return fail(FA_ERR_STATE, "fa_collect_act: no storage bound");
     const fa_storage &st = env->st;
+    const int value_only = io->value_only;
     if (step < 0 || step > st.num_steps || (!value_only && step == st.num_steps))
         return fail(FA_ERR_INVALID, "fa_collect_act: step outside the bound storage");
     if (!value_only && !st.action_log_probs) return fail(FA_ERR_STATE, "fa_collect_act: storage has no action_log_probs");
     const size_t EN = (size_t)env->cfg.num_envs * env->N;
-    return policy_launch(env, st.obs + (size_t)step * EN * FA_OBS_DIM, wg, wa, st.value_preds + (size_t)step * EN,
-                         value_only ? nullptr : st.actions + (size_t)step * EN,
-                         value_only ? nullptr : st.action_log_probs + (size_t)step * EN, counter, seed, step,
-                         deterministic, value_only, stream, "fa_collect_act");
+    return policy_launch(env, st.obs + (size_t)step * EN * FA_OBS_DIM, io->weights[0], io->weights[1],
+                         st.value_preds + (size_t)step * EN, value_only ? nullptr : st.actions + (size_t)step * EN,
+                         value_only ? nullptr : st.action_log_probs + (size_t)step * EN, io->counter, io->seed, step,
+                         io->deterministic, value_only, io->attacker_pool, io->pool_size, io->env_strategy, stream,
+                         "fa_collect_act");
 }
 
 int64_t fa_policy_weight_floats(void) { return FA_POLICY_WEIGHT_FLOATS; }
@@ -622,7 +657,7 @@ int fa_selftest_math(fa_env *env, uint64_t samples, uint64_t seed, uint64_t *mis
 const char *fa_step_variant(fa_env *env, int32_t num_steps) {
     if (!env) return "";
     return fa_step_variant_name(env->cfg.num_guards, env->cfg.num_attackers, env->cfg.num_envs, num_steps,
-                                env->cfg.step_kernel);
+                                env->cfg.step_kernel, env->choice_k > 0);
 }
 
 int fa_rng_peek(fa_env *env, int32_t e, int32_t count, double *out_host) {

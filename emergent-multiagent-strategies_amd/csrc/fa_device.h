@@ -64,6 +64,8 @@ struct FaStepArgs {
     int32_t E, G, A, max_t;
     int32_t auto_reset, rng_mode, track_counters, nsteps; // nsteps: env-steps per launch
     int32_t step_kernel;                                  // FA_KERNEL_* of the handle (host side only)
+    int32_t choice_k;                                     // > 0: np.random.choice(choice_k) follows every reset
+    int32_t *choice_out;                                  // (E) the drawn index, see fa_set_reset_choice
     uint64_t seed;
     int64_t env_offset;
     FaDerived c;

@@ -38,6 +38,16 @@ struct FaPolicyArgs {
     uint64_t seed;
     int64_t env_offset;
     int32_t E, G, A, step, deterministic, value_only;
+    // ensemble of frozen attacker strategies (learner.py:119-140): envs grouped by strategy
+    const float *pool;             // pool_size packed weight buffers back to back, or null
+    const int32_t *env_list;       // [tiles][ET] env index of every tile slot (-1 = empty), from fa_group_envs_kernel
+    const int32_t *tile_strategy;  // [tiles] strategy of the tile's envs (-1 = unused tile)
+    int32_t tiles;                 // grid size in tiles when env_list is set
 };
+#define FA_POLICY_MAX_POOL 64 // strategies in an ensemble
 
 hipError_t fa_launch_policy(const FaPolicyArgs &a, hipStream_t st);
+// envs -> tiles of equal strategy: env_list / tile_strategy for a launch with `pool`
+hipError_t fa_launch_group_envs(const int32_t *env_strategy, int E, int pool_size, int G, int A, int32_t *env_list,
+                                int32_t *tile_strategy, int tiles_max, hipStream_t st);
+int fa_policy_tile_envs(int G, int A);

@@ -177,14 +177,27 @@ __global__ __launch_bounds__(256, 1) void fa_policy_kernel(FaPolicyArgs a) {
     const int n = team == 0 ? a.G : a.A, m = N - n;   // own / opponent team size
     const int own0 = team == 0 ? 0 : a.G, opp0 = team == 0 ? a.G : 0;
     const int ET = PR / (n > m ? n : m);               // envs per tile
-    const int e0 = blockIdx.x * ET;
-    if (e0 >= a.E) return;
-    const int ne = (a.E - e0) < ET ? (a.E - e0) : ET;  // envs of this tile
+    // which envs: a contiguous range, or -- ensemble of attacker strategies -- the tile's slots of the
+    // strategy-sorted env list (every env of a tile then shares one set of attacker weights)
+    __shared__ int sE[PR];
     const float *W = a.w[team];
+    if (a.env_list) {
+        const int strat = a.tile_strategy[blockIdx.x];
+        if (strat < 0) return;
+        if (team == 1) W = a.pool + (size_t)strat * FA_POLICY_WEIGHT_FLOATS;
+        if (tid < ET) sE[tid] = a.env_list[blockIdx.x * ET + tid];
+    } else {
+        const int e0 = blockIdx.x * ET;
+        if (e0 >= a.E) return;
+        if (tid < ET) sE[tid] = e0 + tid < a.E ? e0 + tid : -1;
+    }
+    __syncthreads();
 
-    // ---- observations of the tile (contiguous in the (E, N, 6) row) -------------------------------------
-    for (int k = tid; k < ET * N * FA_OBS_DIM; k += 256)
-        sX[k] = k < ne * N * FA_OBS_DIM ? a.obs[(size_t)e0 * N * FA_OBS_DIM + k] : 0.0f;
+    // ---- observations of the tile's envs (N * 6 contiguous floats per env) -------------------------------
+    for (int k = tid; k < ET * N * FA_OBS_DIM; k += 256) {
+        const int el = k / (N * FA_OBS_DIM), e = sE[el];
+        sX[k] = e >= 0 ? a.obs[(size_t)e * N * FA_OBS_DIM + (k - el * N * FA_OBS_DIM)] : 0.0f;
+    }
     __syncthreads();
 
     // ---- encoders (mpnn.py:37-38): h1 = relu(x We + be) -> sH[:, 0:64] (own rows), ho -> sG[:, 0:64] (opp rows)
@@ -324,9 +337,10 @@ __global__ __launch_bounds__(256, 1) void fa_policy_kernel(FaPolicyArgs a) {
     __syncthreads();
 
     // ---- value, log-softmax, sample, log-prob of the sample -> rollout rows ----------------------------------
-    if (tid < ne * n) {
-        const int el = tid / n, i = tid - el * n;
-        const int e = e0 + el;
+    const int el_out = tid / n;
+    if (tid < ET * n && sE[el_out] >= 0) {
+        const int el = el_out, i = tid - el * n;
+        const int e = sE[el];
         const size_t o = (size_t)e * N + own0 + i;
         const float *lo = sO + tid * 16;
         if (a.value) a.value[o] = lo[8];
@@ -369,12 +383,49 @@ __global__ __launch_bounds__(256, 1) void fa_policy_kernel(FaPolicyArgs a) {
         }
     }
 }
+// Ensemble: sort the envs into tiles of equal strategy.  One workgroup: histogram, tile ranges per
+// strategy, scatter (the order inside a strategy's tiles is arbitrary -- every output is per env and the
+// sampling key holds the env index, so results do not depend on it).
+__global__ __launch_bounds__(1024) void fa_group_envs_kernel(const int32_t *__restrict__ strat, int E, int K, int ET, int tiles_max,
+                                                            int32_t *__restrict__ env_list, int32_t *__restrict__ tile_strategy) {
+    __shared__ int cnt[FA_POLICY_MAX_POOL], start[FA_POLICY_MAX_POOL], cur[FA_POLICY_MAX_POOL];
+    const int tid = threadIdx.x;
+    if (tid < FA_POLICY_MAX_POOL) { cnt[tid] = 0; cur[tid] = 0; }
+    __syncthreads();
+    auto clampk = [&](int k) { return k < 0 ? 0 : (k >= K ? K - 1 : k); };
+    for (int e = tid; e < E; e += blockDim.x) atomicAdd(&cnt[clampk(strat[e])], 1);
+    for (int s = tid; s < tiles_max * ET; s += blockDim.x) env_list[s] = -1;
+    __syncthreads();
+    if (tid == 0) {
+        int t = 0;
+        for (int k = 0; k < K; ++k) {
+            start[k] = t * ET;
+            const int nt = (cnt[k] + ET - 1) / ET;
+            for (int j = 0; j < nt && t + j < tiles_max; ++j) tile_strategy[t + j] = k;
+            t += nt;
+        }
+        for (; t < tiles_max; ++t) tile_strategy[t] = -1;
+    }
+    __syncthreads();
+    for (int e = tid; e < E; e += blockDim.x) {
+        const int k = clampk(strat[e]);
+        env_list[start[k] + atomicAdd(&cur[k], 1)] = e;
+    }
+}
 } // namespace
 
+int fa_policy_tile_envs(int G, int A) { return PR / (G > A ? G : A); }
+
+hipError_t fa_launch_group_envs(const int32_t *env_strategy, int E, int pool_size, int G, int A, int32_t *env_list,
+                                int32_t *tile_strategy, int tiles_max, hipStream_t st) {
+    hipLaunchKernelGGL(fa_group_envs_kernel, dim3(1), dim3(1024), 0, st, env_strategy, E, pool_size, fa_policy_tile_envs(G, A),
+                       tiles_max, env_list, tile_strategy);
+    return hipGetLastError();
+}
+
 hipError_t fa_launch_policy(const FaPolicyArgs &a, hipStream_t st) {
-    const int n_max = a.G > a.A ? a.G : a.A;
-    const int ET = PR / n_max;
-    const int tiles = (a.E + ET - 1) / ET;
+    const int ET = fa_policy_tile_envs(a.G, a.A);
+    const int tiles = a.env_list ? a.tiles : (a.E + ET - 1) / ET;
     hipLaunchKernelGGL(fa_policy_kernel, dim3(tiles, 2), dim3(256), 0, st, a);
     return hipGetLastError();
 }

@@ -793,6 +793,45 @@ __global__ __launch_bounds__(NW * FA_WAVE) void fa_step_kernel(FaStepArgs a) {
                     if (RESET_ONLY) { uint8_t *gr = a.s.game_result + (size_t)e * 3; gr[0] = gr[1] = gr[2] = 0; }
                 }
             }
+            // ---- ensemble path: master.sample_attacker() after every env.reset() -- np.random.choice(k)
+            // on the SAME stream (learner.py:119-121, train_fortattack_v2.py:29-35,104-111; quirk Q14).
+            // Legacy RandomState.choice -> randint(0, k): genrand_int32() & mask until <= k - 1.
+            if (a.choice_k > 0) {
+                int extra = 0; // MT words the env's choice consumed
+                if (do_reset && i == 0) {
+                    const uint32_t rng = (uint32_t)(a.choice_k - 1);
+                    uint32_t mask = rng, v = 0;
+                    mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+                    if (rng != 0u) {
+                        if (a.rng_mode == 0) {
+                            uint32_t *mt = a.s.mt + (size_t)e * FA_MT_N;
+                            int c = mt_base; // lane 0: its draw base IS the env's cursor (< 624)
+                            do {
+                                const uint32_t nw = mt_twist(mt[c], mt[mt_wrap(c + 1)], mt[mt_wrap(c + FA_MT_M)]);
+                                mt[c] = nw;
+                                v = mt_temper(nw) & mask;
+                                c = mt_wrap(c + 1);
+                                ++extra;
+                            } while (v > rng);
+                            a.s.mt_pos[e] = c;
+                        } else { // Philox mode: counter-based, keyed like the reset draw with agent index 255
+                            const uint64_t genv = (uint64_t)(a.env_offset + e);
+                            uint32_t ctr = 0;
+                            do {
+                                uint32_t cc[4] = {(uint32_t)genv, (uint32_t)(genv >> 32), a.s.reset_count[e], 255u | (ctr << 8)};
+                                philox4x32_10(cc, (uint32_t)a.seed, (uint32_t)(a.seed >> 32));
+                                v = cc[0] & mask;
+                                ++ctr;
+                            } while (v > rng);
+                        }
+                    }
+                    a.choice_out[e] = (int)v;
+                }
+                if (a.rng_mode == 0) {
+                    extra = __shfl(extra, gbase); // from the env's lane 0
+                    if (do_reset) mt_base = (mt_base - 4 * i + extra) % FA_MT_N + 4 * i;
+                }
+            }
         }
 
         // ---- observation row (fortattack_env_v1.py:238) ------------------------------------
@@ -1413,24 +1452,25 @@ __global__ void fa_seed_kernel(FaState s, int E, uint64_t base_seed, int64_t env
 // which step kernel a launch of `nsteps` env-steps uses: 0 = pipelined (two workgroups per CU build),
 // -3 = pipelined (three per CU build), 1/2/3 = fa_step_kernel with that many cooperating waves.
 // `forced` = the handle's fa_config.step_kernel (FA_KERNEL_*; tests pin every instantiation with it).
-static int step_variant(int G, int A, int E, int nsteps, bool reset_only, int forced) {
+static int step_variant(int G, int A, int E, int nsteps, bool reset_only, int forced, bool choice = false) {
     const int epw = FA_WAVE / (G + A);
     const int grid = (E + epw - 1) / epw;
     const bool sized = (G == 3 && A == 3) || (G == 5 && A == 5);
     if (reset_only || !sized) return 1;
+    // (the pipelined kernel draws resets ahead of time: it does not interleave the ensemble path's choice)
     switch (forced) {
-    case 1: if (nsteps >= 2) return 0; break;   // FA_KERNEL_PIPE (its prologue assumes a second step may follow)
-    case 2: if (nsteps >= 2) return -3; break;  // FA_KERNEL_PIPE3
+    case 1: if (nsteps >= 2 && !choice) return 0; break;   // FA_KERNEL_PIPE (its prologue assumes a second step may follow)
+    case 2: if (nsteps >= 2 && !choice) return -3; break;  // FA_KERNEL_PIPE3
     case 3: return 1;
     case 4: return 2;
     case 5: return 3;
     default: break;
     }
-    if (nsteps >= FA_PIPE_MIN_STEPS && grid <= FA_PIPE_MAX_GRID) return grid <= 2 * 256 ? 0 : -3;
+    if (!choice && nsteps >= FA_PIPE_MIN_STEPS && grid <= FA_PIPE_MAX_GRID) return grid <= 2 * 256 ? 0 : -3;
     return grid <= FA_THREE_WAVE_MAX_GRID ? 3 : (grid <= FA_TWO_WAVE_MAX_GRID ? 2 : 1);
 }
-const char *fa_step_variant_name(int G, int A, int E, int nsteps, int forced) {
-    switch (step_variant(G, A, E, nsteps, false, forced)) {
+const char *fa_step_variant_name(int G, int A, int E, int nsteps, int forced, bool choice) {
+    switch (step_variant(G, A, E, nsteps, false, forced, choice)) {
     case 0: return "fa_step_pipe_kernel";
     case -3: return "fa_step_pipe_kernel/3 per CU";
     case 3: return "fa_step_kernel/3 waves";
@@ -1448,7 +1488,7 @@ static hipError_t launch_step_t(const FaStepArgs &a, hipStream_t st) {
     // compile-time team sizes that fit the GPU in one round of 3 workgroups per CU use the
     // pipelined kernel; short launches (its prologue draws two resets ahead and evaluates three
     // sin/cos) and everything else use fa_step_kernel with 3 / 2 / 1 waves by grid size.
-    const int nw = step_variant(a.G, a.A, a.E, a.nsteps, RESET_ONLY, a.step_kernel);
+    const int nw = step_variant(a.G, a.A, a.E, a.nsteps, RESET_ONLY, a.step_kernel, a.choice_k > 0);
 #define FA_LAUNCH(TG_, TA_, NW_) \
     hipLaunchKernelGGL((fa_step_kernel<TG_, TA_, RESET_ONLY, COLLECT, RESET_ONLY ? 1 : NW_>), dim3(grid), \
                        dim3((RESET_ONLY ? 1 : NW_) * FA_WAVE), 0, st, a)

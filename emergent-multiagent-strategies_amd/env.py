@@ -128,6 +128,18 @@ class BatchedFortAttack(object):
         _lib.check(self._lib.fa_step(self._h, C.byref(io), _stream()), "fa_step")
         return out
 
+    def set_reset_choice(self, k, out=None):
+        """fa_set_reset_choice: np.random.choice(k) on the env's stream after every reset (the ensemble
+        path's sample_attacker, learner.py:119-121).  Returns the (E,) int32 device tensor the chosen
+        indices are written to (k = 0 switches it off)."""
+        if k and out is None:
+            out = torch.zeros(self.E, dtype=torch.int32, device=self.device)
+        if k:
+            assert out.dtype == torch.int32 and out.is_contiguous() and out.numel() == self.E and out.device == self.device
+        _lib.check(self._lib.fa_set_reset_choice(self._h, int(k), _ptr(out) if k else None), "fa_set_reset_choice")
+        self._choice_out = out if k else None   # keep it alive: the library holds the pointer
+        return self._choice_out
+
     # -- collector -------------------------------------------------------------------
     def bind_storage(self, storage):
         """Attach a JointRolloutStorage (storage.py) -- fa_bind_storage."""
@@ -210,31 +222,42 @@ class BatchedFortAttack(object):
         _lib.check(self._lib.fa_after_update(self._h, _stream()), "fa_after_update")
 
     # -- fused policy (csrc/fa_policy.hip) ----------------------------------------------------
-    def policy_act(self, obs, w_guards, w_attackers, seed=0, counter=None, step=0, deterministic=False,
-                   value_only=False, out=None):
-        """fa_policy_act: both teams' MPNN forward + sampling on an observation row obs (E, N, 6) float32.
-        w_*: packed weight buffers (mpnn_pack.pack_policy).  Returns (value, action, log_prob), each (E, N)
-        (action / log_prob are None with value_only)."""
-        assert obs.is_cuda and obs.dtype == torch.float32 and obs.is_contiguous() and tuple(obs.shape) == (self.E, self.N, 6)
+    def _policy_io(self, w_guards, w_attackers, seed, counter, step, deterministic, value_only, pool, env_strategy):
+        nfl = self._lib.fa_policy_weight_floats()
+        io = _lib.PolicyIO()
         for w in (w_guards, w_attackers):
-            assert w.is_cuda and w.dtype == torch.float32 and w.is_contiguous() and w.numel() == self._lib.fa_policy_weight_floats()
+            assert w is None or (w.is_cuda and w.dtype == torch.float32 and w.is_contiguous() and w.numel() == nfl)
+        io.weights[0], io.weights[1] = w_guards.data_ptr(), (w_attackers.data_ptr() if w_attackers is not None else None)
+        io.counter = _ptr(counter)
+        io.seed, io.step, io.deterministic, io.value_only = int(seed), int(step), int(bool(deterministic)), int(bool(value_only))
+        if pool is not None:   # (K, weight_floats) packed attacker strategies + per-env strategy index
+            assert pool.is_cuda and pool.dtype == torch.float32 and pool.is_contiguous() and pool.shape[1] == nfl
+            assert env_strategy.dtype == torch.int32 and env_strategy.is_contiguous() and env_strategy.numel() == self.E
+            io.attacker_pool, io.pool_size, io.env_strategy = _ptr(pool), int(pool.shape[0]), _ptr(env_strategy)
+        return io
+
+    def policy_act(self, obs, w_guards, w_attackers, seed=0, counter=None, step=0, deterministic=False,
+                   value_only=False, out=None, pool=None, env_strategy=None):
+        """fa_policy_act: both teams' MPNN forward + sampling on an observation row obs (E, N, 6) float32.
+        w_*: packed weight buffers (mpnn_pack.pack_policy); with `pool` (K, floats) + `env_strategy` (E) int32
+        env e's attackers run strategy env_strategy[e] of the pool.  Returns (value, action, log_prob), each
+        (E, N) (action / log_prob are None with value_only)."""
+        assert obs.is_cuda and obs.dtype == torch.float32 and obs.is_contiguous() and tuple(obs.shape) == (self.E, self.N, 6)
         value, action, logp = out if out is not None else (
             self._new((self.E, self.N), torch.float32),
             None if value_only else self._new((self.E, self.N), torch.int64),
             None if value_only else self._new((self.E, self.N), torch.float32))
-        io = _lib.PolicyIO()
-        io.obs, io.value, io.action, io.log_prob, io.counter = _ptr(obs), _ptr(value), _ptr(action), _ptr(logp), _ptr(counter)
-        io.weights[0], io.weights[1] = w_guards.data_ptr(), w_attackers.data_ptr()
-        io.seed, io.step, io.deterministic, io.value_only = int(seed), int(step), int(bool(deterministic)), int(bool(value_only))
+        io = self._policy_io(w_guards, w_attackers, seed, counter, step, deterministic, value_only, pool, env_strategy)
+        io.obs, io.value, io.action, io.log_prob = _ptr(obs), _ptr(value), _ptr(action), _ptr(logp)
         _lib.check(self._lib.fa_policy_act(self._h, C.byref(io), _stream()), "fa_policy_act")
         return value, action, logp
 
-    def collect_act(self, step, w_guards, w_attackers, seed=0, counter=None, deterministic=False, value_only=False):
+    def collect_act(self, step, w_guards, w_attackers, seed=0, counter=None, deterministic=False, value_only=False,
+                    pool=None, env_strategy=None):
         """fa_collect_act: the policies act on storage.obs[step] and write value_preds / actions /
         action_log_probs[step] (value_only: only value_preds[step], the V(obs[T]) of wrap_horizon)."""
-        _lib.check(self._lib.fa_collect_act(self._h, int(step), _ptr(w_guards), _ptr(w_attackers), int(seed),
-                                            _ptr(counter), int(bool(deterministic)), int(bool(value_only)), _stream()),
-                   "fa_collect_act")
+        io = self._policy_io(w_guards, w_attackers, seed, counter, step, deterministic, value_only, pool, env_strategy)
+        _lib.check(self._lib.fa_collect_act(self._h, int(step), C.byref(io), _stream()), "fa_collect_act")
 
     # -- state snapshot ----------------------------------------------------------------
     _F64 = ("pos_x", "pos_y", "vel_x", "vel_y", "ang", "prev_dist")

@@ -179,10 +179,15 @@ class BatchedLearner(object):
     # ---- ensemble of frozen attacker strategies (train_fortattack_v2.py, learner.py:119-140) ----
     def load_attacker_ensemble(self, checkpoints, hidden_dim=128):
         """checkpoints: list of paths (reference `ep*.pt` files), checkpoint dicts, or attacker
-        state_dicts.  Every env plays against one of the K strategies; the strategy of an env is
-        re-drawn uniformly each time that env's episode ends (the reference re-draws after every
-        episode of its single env, train_fortattack_v2.py:104-111).  Train with
-        update(train_guards_only=True)."""
+        state_dicts.  Every env plays against one of the K strategies; the strategy of an env is re-drawn
+        each time that env is reset -- the reference calls sample_attacker() after its first env.reset()
+        and after every episode-end reset (train_fortattack_v2.py:29-35,104-111), and its
+        np.random.choice(attacker_ckpts) (learner.py:120) consumes the same numpy stream the reset positions
+        come from (quirk Q14).  The engine reproduces exactly that per env (fa_set_reset_choice): `attacker_id`
+        is written by the reset itself.  Train with update(train_guards_only=True).
+        With the fused policy kernel the envs are grouped by strategy and each strategy's network runs once
+        over its own envs; the PyTorch fallback (policy_backend="torch") evaluates every strategy on every
+        env and selects."""
         pool = []
         for ck in checkpoints:
             if isinstance(ck, str):
@@ -197,13 +202,18 @@ class BatchedLearner(object):
         if self._graphs is not None:
             raise RuntimeError("load the ensemble before the first reset() when use_graph is set")
         self.attacker_pool = pool
-        self.attacker_id = torch.randint(len(pool), (self.E,), device=self.device)
-        self.attacker_id_rows = torch.zeros((self.T, self.E), dtype=torch.int64, device=self.device)
+        self.attacker_id = self.eng.set_reset_choice(len(pool))            # (E,) int32, written by every reset
+        self.attacker_id_rows = torch.zeros((self.T, self.E), dtype=torch.int32, device=self.device)
+        self._packed_pool = None
+        if self.policy_backend == "hip" and all(mpnn_pack.supported(p) for p in pool):
+            self._packed_pool = torch.stack([mpnn_pack.pack_policy(p) for p in pool]).contiguous()
+        elif self.policy_backend == "hip":
+            self.policy_backend = "torch"
 
     def _attacker_forward(self, fn_name, own, opp):
-        """Run every strategy on the whole batch and keep, per env, the output of that env's."""
+        """PyTorch fallback: run every strategy on the whole batch and keep, per env, the output of that env's."""
         outs = [getattr(pol, fn_name)(own, opp) for pol in self.attacker_pool]
-        sel = self.attacker_id
+        sel = self.attacker_id.long()
         pick = lambda ts: torch.stack(ts, 0)[sel, torch.arange(self.E, device=self.device)]
         if isinstance(outs[0], tuple):
             return tuple(pick([o[k] for o in outs]) for k in range(len(outs[0])))
@@ -229,14 +239,21 @@ class BatchedLearner(object):
         return self._twin_net
 
     def _hip(self):
-        """The fused kernel runs the forwards unless an attacker ensemble is loaded (per-env weights)."""
-        return self.policy_backend == "hip" and not self.attacker_pool
+        return self.policy_backend == "hip"
+
+    def _hip_act(self, s, value_only=False):
+        """One launch: both teams' forward + sampling -> value_preds / actions / action_log_probs[s] (with an
+        attacker ensemble: one more small launch that sorts the envs into tiles of equal strategy)."""
+        pool = self._packed_pool if self.attacker_pool else None
+        self.eng.collect_act(s, self._packed[0], None if pool is not None else self._packed[1], self.sample_seed,
+                             self._rollout_counter, value_only=value_only, pool=pool,
+                             env_strategy=self.attacker_id if pool is not None else None)
 
     @torch.no_grad()
     def _act_into_storage(self, s):
         st = self.storage
-        if self._hip():   # one launch: both teams' forward + sampling -> value_preds / actions / action_log_probs[s]
-            self.eng.collect_act(s, self._packed[0], self._packed[1], self.sample_seed, self._rollout_counter)
+        if self._hip():
+            self._hip_act(s)
             return
         obs = st.obs[s]
         twin = self._twin()
@@ -259,11 +276,11 @@ class BatchedLearner(object):
     def step(self, s):
         """One env-step of the rollout: act (learner.py:143-172) + env.step + insert."""
         self._act_into_storage(s)
-        self.eng.collect_step(s, auto_reset=True)
-        if self.attacker_pool:   # sample_attacker() after every episode end (train_fortattack_v2.py:110-111)
+        if self.attacker_pool:
             self.attacker_id_rows[s].copy_(self.attacker_id)   # which strategy each env faced at step s
-            fresh = torch.randint(len(self.attacker_pool), (self.E,), device=self.device)
-            self.attacker_id.copy_(torch.where(self.storage.done[s] != 0, fresh, self.attacker_id))  # in place: graph-safe
+        # (an env that ends here is reset by this launch, which also draws its next strategy:
+        #  sample_attacker() after every episode-end reset, train_fortattack_v2.py:104-111)
+        self.eng.collect_step(s, auto_reset=True)
 
     def _warm_state(self):
         """A harmless world for the capture warm-up steps: teams on opposite walls facing
@@ -286,7 +303,7 @@ class BatchedLearner(object):
         """wrap_horizon: V(obs[T]) -> value_preds[T] (learner.py:196-202)."""
         st = self.storage
         if self._hip():
-            self.eng.collect_act(self.T, self._packed[0], self._packed[1], value_only=True)
+            self._hip_act(self.T, value_only=True)
             return
         obs = st.obs[self.T]
         if self._twin() is not None:

@@ -172,6 +172,15 @@ int fa_reset(fa_env *env, const uint8_t *env_mask, float *obs_f32, double *obs_f
  * (fortattack_env_v1.py:87-238), _get_done (fortattack.py:202-225). */
 int fa_step(fa_env *env, const fa_step_io *io, void *stream);
 
+/* Ensemble-attacker path (train_fortattack_v2.py): every env.reset() -- the first one (:29-35) and each
+ * episode-end one (:104-111) -- is followed by Learner.sample_attacker (learner.py:119-121), whose
+ * np.random.choice(attacker_ckpts) draws from the SAME global numpy stream as the reset positions.  With
+ * k > 0 every reset of an env (fa_reset, fa_collect_reset, auto-reset inside fa_step / fa_collect_*) is
+ * followed by that draw on the env's stream and the chosen index (0..k-1) is stored in choice_out[e]
+ * (device, E int32, caller owned, must stay valid).  k = 0 switches it off.  Launches then use
+ * fa_step_kernel (the pipelined kernel draws its resets ahead and is not used with a choice). */
+int fa_set_reset_choice(fa_env *env, int32_t k, int32_t *choice_out);
+
 /* ---- collector ------------------------------------------------------------------ */
 /* Attach caller-owned rollout buffers (RolloutStorage.__init__/to, storage.py:10-31). */
 int fa_bind_storage(fa_env *env, const fa_storage *st);
@@ -246,13 +255,20 @@ typedef struct fa_policy_io {
     int32_t step;                /* rollout index of this call (part of the sampling key) */
     int32_t deterministic;       /* != 0: argmax instead of a sample */
     int32_t value_only;          /* != 0: get_value (mpnn.py:202-205): only `value` is written */
+    /* Ensemble of frozen attacker strategies (train_fortattack_v2.py; Learner.select_attacker loads one
+     * checkpoint into the attacker agents, learner.py:132-140): with pool_size > 0 env e's attackers run
+     * strategy env_strategy[e] of the pool instead of weights[1].  The envs are sorted into tiles of equal
+     * strategy first (one extra small launch), so each strategy's network runs once over ITS envs. */
+    const float *attacker_pool;  /* device: pool_size packed buffers back to back, or NULL */
+    int32_t pool_size;           /* 0 = no ensemble; at most 64 */
+    const int32_t *env_strategy; /* device (E): 0..pool_size-1, e.g. the choice_out of fa_set_reset_choice */
 } fa_policy_io;
 int fa_policy_act(fa_env *env, const fa_policy_io *io, void *stream);
-/* The same on the bound storage: reads obs[step], writes value_preds[step], actions[step],
- * action_log_probs[step] (Learner.act + the policy half of RolloutStorage.insert, learner.py:143-172,
- * storage.py:33-43); with value_only only value_preds[step] (wrap_horizon's V(obs[T]), learner.py:196-202). */
-int fa_collect_act(fa_env *env, int32_t step, const float *weights_guards, const float *weights_attackers,
-                   uint64_t seed, const int64_t *counter, int32_t deterministic, int32_t value_only, void *stream);
+/* The same on the bound storage (io->obs / value / action / log_prob are ignored): reads obs[step], writes
+ * value_preds[step], actions[step], action_log_probs[step] (Learner.act + the policy half of
+ * RolloutStorage.insert, learner.py:143-172, storage.py:33-43); with value_only only value_preds[step]
+ * (wrap_horizon's V(obs[T]), learner.py:196-202). */
+int fa_collect_act(fa_env *env, int32_t step, const fa_policy_io *io, void *stream);
 /* number of floats of one team's packed weight buffer */
 int64_t fa_policy_weight_floats(void);
 

@@ -40,6 +40,8 @@ def _load():
         _lib.fao_reset.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         _lib.fao_step.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int] + [C.c_void_p] * 6
         _lib.fao_rollout.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib.fao_set_choice.argtypes = [C.c_void_p, C.c_int]
+        _lib.fao_get_choice.argtypes = [C.c_void_p, C.c_void_p]
         _lib.fao_get_state.argtypes = [C.c_void_p] + [C.c_void_p] * 11
         _lib.fao_set_state.argtypes = [C.c_void_p] + [C.c_void_p] * 8
     return _lib
@@ -74,6 +76,15 @@ class OracleEnv(object):
         if getattr(self, "_h", None) is not None and _lib is not None:
             _lib.fao_destroy(self._h)
             self._h = None
+
+    def set_choice(self, k):
+        """Every reset is followed by np.random.choice(k) on the env's stream (learner.py:119-121)."""
+        _lib.fao_set_choice(self._h, int(k))
+
+    def get_choice(self):
+        out = np.empty(self.E, np.int32)
+        _lib.fao_get_choice(self._h, _p(out))
+        return out
 
     def rng_doubles(self, e, count):
         out = np.empty(count, np.float64)

@@ -271,9 +271,47 @@ def gen_mpnn_fixture():
     print("mpnn_h32       params(full)=%d" % int(rec["full_param_count"]))
 
 
+def gen_choice_fixture():
+    """The ensemble path's RNG interleaving: train_fortattack_v2.py follows EVERY
+    env.reset() -- the first one (:29-35) and each episode-end one (:104-111) -- with
+    master.sample_attacker(), whose only RNG use is `np.random.choice(self.attacker_ckpts)`
+    (learner.py:120) on the same global stream the resets draw from.  Driven here exactly so: reference env,
+    reset, np.random.choice(ckpts), scripted steps, on done reset + choice.  Records the checkpoint index
+    chosen after every reset and the observation after every step (post-reset where done)."""
+    G, A, max_t, T, E, base_seed, K = 5, 5, 25, 120, 4, 700, 5
+    ckpts = [220, 650, 1240, 1600, 2520]                 # arguments.py default --attacker-ckpts
+    N = G + A
+    actions = scripted_actions(np.random.RandomState(21), T, E, G, A)
+    rec = dict(actions=actions, obs0=np.zeros((E, N, 6)), obs=np.zeros((T, E, N, 6)), done=np.zeros((T, E), np.uint8),
+               choice0=np.zeros(E, np.int32), choice=np.full((T, E), -1, np.int32), reward=np.zeros((T, E, N)))
+    skip = None
+    for e in range(E):
+        np.random.seed(base_seed + e)
+        env, skip = rh.make_reference_env(G, A, max_t)
+        with rh.quiet():
+            obs = env.reset()
+        rec["obs0"][e] = obs
+        rec["choice0"][e] = ckpts.index(np.random.choice(ckpts))
+        for t in range(T):
+            with rh.quiet():
+                obs, rew, done, _ = env.step(actions[t, e].astype(np.int64))
+            rec["reward"][t, e] = np.array(rew, dtype=np.float64)
+            rec["done"][t, e] = done
+            if done:
+                with rh.quiet():
+                    obs = env.reset()
+                rec["choice"][t, e] = ckpts.index(np.random.choice(ckpts))
+            rec["obs"][t, e] = obs
+    rec["meta"] = np.array([G, A, max_t, T, E, base_seed, skip, K], np.int64)
+    print("env_choice_5v5 episodes=%d choices=%s" % (int(rec["done"].sum()), np.bincount(rec["choice"][rec["choice"] >= 0], minlength=K).tolist()))
+    np.savez_compressed(os.path.join(OUT, "env_choice_5v5.npz"), **rec)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["mt", "env", "collector", "mpnn"]
+    which = sys.argv[1:] or ["mt", "env", "collector", "mpnn", "choice"]
+    if "choice" in which:
+        gen_choice_fixture()
     if "mt" in which:
         gen_mt_kat()
     if "env" in which:

@@ -394,3 +394,32 @@ def test_large_batch_matches_oracle(fa):
         assert np.array_equal(out["done"].cpu().numpy(), ref["done"]), t
         assert np.array_equal(out["obs_f64"].cpu().numpy(), ref["obs"]), t
         assert np.array_equal(out["reward_f64"].cpu().numpy(), ref["reward"]), t
+
+
+@pytest.mark.parametrize("kernel", ["auto", "waves1", "waves2", "waves3"])
+def test_reset_choice_interleaving_golden(fa, golden_dir, kernel):
+    """Ensemble path (quirk Q14): np.random.choice(attacker_ckpts) after every env.reset() on the env's own
+    stream (learner.py:119-121, train_fortattack_v2.py:29-35,104-111) -- the engine with
+    fa_set_reset_choice against the capture of the reference env driven that way: chosen indices and
+    every observation (hence every later reset position) bit for bit."""
+    g = _load(golden_dir, "env_choice_5v5")
+    G, A, max_t, T, E, base_seed, skip, K = [int(v) for v in g["meta"]]
+    eng = fa.BatchedFortAttack(E, G, A, max_t, base_seed=base_seed, skip_doubles=skip, step_kernel=kernel)
+    choice = eng.set_reset_choice(K)
+    obs64 = torch.empty((E, G + A, 6), dtype=torch.float64, device="cuda")
+    eng.reset(obs_f64=obs64)
+    assert np.array_equal(obs64.cpu().numpy(), g["obs0"]) and np.array_equal(choice.cpu().numpy(), g["choice0"])
+    n = 0
+    for t in range(T):
+        out = eng.step(_dev(g["actions"][t], torch.int64), auto_reset=True, want=("obs_f64", "reward_f64", "done"))
+        assert np.array_equal(out["done"].cpu().numpy(), g["done"][t]), t
+        assert np.abs(out["obs_f64"].cpu().numpy() - g["obs"][t]).max() <= FLOAT_TOL, t
+        assert np.abs(out["reward_f64"].cpu().numpy() - g["reward"][t]).max() <= FLOAT_TOL, t
+        d = g["done"][t] != 0
+        assert np.array_equal(choice.cpu().numpy()[d], g["choice"][t][d]), t
+        n += int(d.sum())
+    assert n >= 10
+    # a rollout launch with a choice pending uses fa_step_kernel, never the draw-ahead pipelined kernel
+    assert "pipe" not in eng.step_variant(64)
+    eng.set_reset_choice(0)
+    assert eng.step_variant(64) == ("fa_step_pipe_kernel" if kernel == "auto" else eng.step_variant(64))

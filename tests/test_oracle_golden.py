@@ -193,3 +193,24 @@ def test_oracle_rollout_equals_per_step_calls():
     for k in sa:
         assert np.array_equal(sa[k], sb[k], equal_nan=True), k
     assert np.array_equal(a.rng_doubles(E - 1, 8), b.rng_doubles(E - 1, 8))
+
+
+def test_oracle_reset_choice_interleaving_golden(golden_dir):
+    """Ensemble path (quirk Q14): np.random.choice(attacker_ckpts) after every env.reset() on the same stream
+    (learner.py:119-121, train_fortattack_v2.py:29-35,104-111) -- the oracle against the capture of the
+    reference env driven that way: chosen checkpoint indices and every observation, bit for bit."""
+    from fa_oracle import OracleEnv
+    g = np.load(os.path.join(golden_dir, "env_choice_5v5.npz"))
+    G, A, max_t, T, E, base_seed, skip, K = [int(v) for v in g["meta"]]
+    orc = OracleEnv(E, G, A, max_t, base_seed=base_seed, skip_doubles=skip)
+    orc.set_choice(K)
+    assert np.array_equal(orc.reset(), g["obs0"]) and np.array_equal(orc.get_choice(), g["choice0"])
+    n = 0
+    for t in range(T):
+        ref = orc.step(g["actions"][t].astype(np.int64), auto_reset=True)
+        assert np.array_equal(ref["done"], g["done"][t]) and np.array_equal(ref["obs"], g["obs"][t]), t
+        assert np.array_equal(ref["reward"], g["reward"][t]), t
+        d = g["done"][t] != 0
+        assert np.array_equal(orc.get_choice()[d], g["choice"][t][d]), t
+        n += int(d.sum())
+    assert n >= 10
