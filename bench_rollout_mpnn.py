@@ -24,10 +24,16 @@ def main():
     ap.add_argument("--iters", type=int, default=3)
     ap.add_argument("--graph", type=int, default=1)
     ap.add_argument("--update", type=int, default=1)
+    ap.add_argument("--backend", default="auto", choices=["auto", "hip", "torch"], help="who runs the rollout forwards")
+    ap.add_argument("--ensemble", type=int, default=0, help="K frozen attacker strategies, one per env, re-drawn at "
+                                                              "every reset (BASELINE config 5); guards only are trained")
     a = ap.parse_args()
     torch.manual_seed(0)
     eng = fa.BatchedFortAttack(a.envs, a.guards, a.attackers, 100, base_seed=0, track_counters=False)
-    L = fa.BatchedLearner(eng, num_steps=a.rollout, use_graph=bool(a.graph))
+    L = fa.BatchedLearner(eng, num_steps=a.rollout, use_graph=bool(a.graph), policy_backend=a.backend)
+    if a.ensemble:
+        L.load_attacker_ensemble([fa.MPNN(num_agents=a.attackers, num_opp_agents=a.guards, num_actions=8).state_dict()
+                                  for _ in range(a.ensemble)])
     L.reset()
     L.collect()
     L.after_update()
@@ -39,7 +45,7 @@ def main():
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         if a.update:
-            L.update()
+            L.update(train_guards_only=bool(a.ensemble))
             torch.cuda.synchronize()
         t2 = time.perf_counter()
         L.after_update()
@@ -48,7 +54,8 @@ def main():
     steps = a.envs * a.rollout * a.iters
     print(json.dumps({
         "config": "FortAttack %dv%d, %d envs, %d-step rollout, MPNN h=128 policy in the loop (%s)" % (
-            a.guards, a.attackers, a.envs, a.rollout, "hipGraph per step" if a.graph else "eager"),
+            a.guards, a.attackers, a.envs, a.rollout, ("one hipGraph per rollout" if a.graph else "eager") + ", forwards: " + L.policy_backend +
+            (", ensemble of %d attacker strategies" % a.ensemble if a.ensemble else "")),
         "rollout_env_steps_per_s": steps / t_roll, "rollout_ms_per_env_step_launch": t_roll / (a.iters * a.rollout) * 1e3,
         "train_env_steps_per_s": steps / (t_roll + t_upd) if a.update else None,
         "update_s": t_upd / a.iters if a.update else None,

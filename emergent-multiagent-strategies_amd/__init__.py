@@ -10,6 +10,7 @@ from .storage import JointRolloutStorage, RolloutStorage  # noqa: F401
 from .env import BatchedFortAttack, FortAttackGlobalEnv, make_fortattack_env  # noqa: F401
 from .mpnn import MPNN  # noqa: F401
 from .learner import BatchedLearner  # noqa: F401
+from .rlagent import JointPPO, Neo  # noqa: F401
 
 __all__ = ["BatchedFortAttack", "FortAttackGlobalEnv", "make_fortattack_env", "JointRolloutStorage",
-           "RolloutStorage", "FaError", "Box", "Discrete", "MASpace", "MPNN", "BatchedLearner"]
+           "RolloutStorage", "FaError", "Box", "Discrete", "MASpace", "MPNN", "BatchedLearner", "Neo", "JointPPO"]

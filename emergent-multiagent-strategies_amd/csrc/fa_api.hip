@@ -638,6 +638,9 @@ int fa_set_state(fa_env *env, const fa_state_host *in) {
     FA_H2D(s.prev, in->prev_dist, EN * 8);
     FA_H2D(s.alive, in->alive, EN);
     FA_H2D(s.tstep, in->time_step, E * 4);
+    FA_H2D(s.num_hit, in->num_hit, EN * 4);
+    FA_H2D(s.num_was_hit, in->num_was_hit, EN * 4);
+    FA_H2D(s.game_result, in->game_result, E * 3);
 #undef FA_H2D
     return FA_OK;
 }

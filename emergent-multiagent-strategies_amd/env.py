@@ -296,11 +296,11 @@ class BatchedFortAttack(object):
     def set_state(self, s):
         keep = []
         sh = _lib.StateHost()
-        for k in self._F64 + ("alive", "time_step"):
+        for k in self._F64 + ("alive", "time_step", "num_hit", "num_was_hit", "game_result"):
             if k in s:
-                dt = np.float64 if k in self._F64 else (np.uint8 if k == "alive" else np.int32)
+                dt = np.float64 if k in self._F64 else (np.uint8 if k in ("alive", "game_result") else np.int32)
                 a = np.ascontiguousarray(s[k], dt)
-                assert a.shape == ((self.E,) if k == "time_step" else (self.E, self.N)), k
+                assert a.shape == ((self.E,) if k == "time_step" else (self.E, 3) if k == "game_result" else (self.E, self.N)), k
                 keep.append(a)
                 setattr(sh, k, a.ctypes.data_as(C.c_void_p))
         _lib.check(self._lib.fa_set_state(self._h, C.byref(sh)), "fa_set_state")
@@ -397,15 +397,24 @@ class FortAttackGlobalEnv(object):
     """gym_fortattack/fortattack.py:31 FortAttackGlobalEnv, one env on the GPU engine.
 
     ``reset() -> (N,6) float64``; ``step(action_n) -> (obs (N,6) f64, reward_n list,
-    done bool, {'n': [{}]*N})``.  The reference draws reset positions from numpy's
-    *global* RNG; here the stream is owned by the env: ``seed`` plays the role of the
-    ``np.random.seed(seed)`` call made before construction (train_fortattack.py:200).
+    done bool, {'n': [{}]*N})``.
+
+    RNG.  The reference draws its reset positions from numpy's GLOBAL stream
+    (fortattack_env_v1.py:66,70), seeded by the training script (train_fortattack.py:200).
+    ``seed=None`` (default) does exactly that: every reset -- and the one the scenario's constructor
+    runs (fortattack_env_v1.py:45) -- calls ``np.random.uniform`` in the reference's order and hands the
+    positions to the engine, so the global stream advances as under the reference and anything else
+    that uses it (``Learner.sample_attacker``'s ``np.random.choice``, learner.py:120) stays in step:
+    ``train_fortattack.py`` runs with the one-line import swap and no extra arguments.
+    ``seed=<int>`` makes the env own a private stream instead (the engine's device-side MT19937,
+    == the reference under ``np.random.seed(seed)`` whose construction consumed ``skip_doubles`` draws).
     Nothing is printed at episode end (the reference prints, fortattack.py:208,214,220).
     """
     metadata = {"render.modes": ["human", "rgb_array"]}
 
-    def __init__(self, num_steps, num_guards=5, num_attackers=5, seed=0, skip_doubles=None, device=0):
-        self._eng = BatchedFortAttack(1, num_guards, num_attackers, num_steps, base_seed=seed,
+    def __init__(self, num_steps, num_guards=5, num_attackers=5, seed=None, skip_doubles=None, device=0):
+        self._np_global = seed is None
+        self._eng = BatchedFortAttack(1, num_guards, num_attackers, num_steps, base_seed=0 if seed is None else seed,
                                       skip_doubles=skip_doubles, device=device)
         e = self._eng
         self.n = e.N                                              # fortattack.py:47
@@ -424,8 +433,11 @@ class FortAttackGlobalEnv(object):
         self._obs64 = torch.empty((1, e.N, 6), dtype=torch.float64, device=e.device)
         self._rew64 = torch.empty((1, e.N), dtype=torch.float64, device=e.device)
         self._done = torch.empty((1,), dtype=torch.uint8, device=e.device)
+        self._alive_before = np.ones(e.N, bool)
         self.world = _WorldView(self)
         self.agents = self.world.policy_agents
+        if self._np_global:
+            self._draw_reset_positions()   # FortAttackEnvV1.__init__ -> reset_world (fortattack_env_v1.py:45)
 
     def _state(self):
         if self._cache is None:
@@ -435,10 +447,38 @@ class FortAttackGlobalEnv(object):
     def seed(self, seed=None):  # gym.Env default: a no-op in the reference too (eval.py:26)
         return []
 
+    def _draw_reset_positions(self):
+        """The RNG calls of reset_world in the reference's order (fortattack_env_v1.py:56-70): per agent,
+        guards first, two np.random.uniform(lo, hi, 1) draws from the global stream."""
+        w = self._eng.cfg.world
+        xMin, xMax, yMin, yMax = w.wall_xmin, w.wall_xmax, w.wall_ymin, w.wall_ymax
+        pos = np.empty((self.n, 2))
+        for i in range(self.n):
+            if i >= self._eng.G:   # attackers start from far away (:66)
+                pos[i] = np.concatenate((np.random.uniform(xMin, xMax, 1), np.random.uniform(yMin, 0.8 * yMin, 1)))
+            else:                  # guards start near the door (:70)
+                pos[i] = np.concatenate((np.random.uniform(-0.8 * w.fort_dim / 2, 0.8 * w.fort_dim / 2, 1),
+                                         np.random.uniform(0.8 * yMax, yMax, 1)))
+        return pos
+
     def reset(self):
         self._cache = None
-        self._eng.reset(obs_f64=self._obs64)
-        return self._obs64[0].cpu().numpy()
+        e = self._eng
+        if self._np_global:
+            pos = self._draw_reset_positions()
+            ang = np.where(np.arange(self.n) >= e.G, np.pi / 2, 3 * np.pi / 2)            # :59
+            z = np.zeros((1, self.n))
+            # everything reset_world sets; prevDist is NOT reset (quirk Q1): left alone
+            e.set_state(dict(pos_x=pos[None, :, 0], pos_y=pos[None, :, 1], vel_x=z, vel_y=z, ang=ang[None],
+                             alive=np.ones((1, self.n), np.uint8), time_step=np.zeros(1, np.int32),
+                             num_hit=z.astype(np.int32), num_was_hit=z.astype(np.int32),
+                             game_result=np.zeros((1, 3), np.uint8)))
+            obs = np.stack([np.ones(self.n), pos[:, 0], pos[:, 1], ang, np.zeros(self.n), np.zeros(self.n)], 1)
+        else:
+            e.reset(obs_f64=self._obs64)
+            obs = self._obs64[0].cpu().numpy()
+        self._alive_before = obs[:, 0] != 0
+        return obs
 
     def step(self, action_n):
         a = np.asarray(action_n).reshape(-1)
@@ -449,7 +489,11 @@ class FortAttackGlobalEnv(object):
         self._eng.step(self._act, auto_reset=False, want=(),
                        out=dict(obs_f64=self._obs64, reward_f64=self._rew64, done=self._done))
         obs = self._obs64[0].cpu().numpy()
-        reward_n = list(self._rew64[0].cpu().numpy())
+        rew = self._rew64[0].cpu().numpy()
+        # fortattack_env_v1.py:87-92: an agent that is neither alive nor justDied gets the int literal 0;
+        # (alive or justDied) after the step == alive before it
+        reward_n = [rew[i] if self._alive_before[i] else 0 for i in range(self.n)]
+        self._alive_before = obs[:, 0] != 0
         done = bool(self._done.item())
         return obs, reward_n, done, {"n": [{} for _ in range(self.n)]}
 
@@ -463,8 +507,9 @@ class FortAttackGlobalEnv(object):
         self._eng.close()
 
 
-def make_fortattack_env(num_steps, benchmark=False, num_guards=5, num_attackers=5, seed=0,
+def make_fortattack_env(num_steps, benchmark=False, num_guards=5, num_attackers=5, seed=None,
                         skip_doubles=None, device=0):
-    """gym_fortattack/fortattack.py:17-27.  Defaults = the reference's 5v5 scenario."""
+    """gym_fortattack/fortattack.py:17-27.  Defaults = the reference's 5v5 scenario drawing its reset
+    positions from numpy's global stream (seed=None); see FortAttackGlobalEnv for `seed`."""
     return FortAttackGlobalEnv(num_steps, num_guards, num_attackers, seed=seed,
                                skip_doubles=skip_doubles, device=device)

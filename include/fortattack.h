@@ -274,7 +274,8 @@ int64_t fa_policy_weight_floats(void);
 
 /* ---- state access (synchronous; tests / checkpoint) ------------------------------ */
 int fa_get_state(fa_env *env, const fa_state_host *out);
-int fa_set_state(fa_env *env, const fa_state_host *in); /* pos/vel/ang/prev_dist/alive/time_step */
+int fa_set_state(fa_env *env, const fa_state_host *in); /* pos/vel/ang/prev_dist/alive/time_step/num_hit/
+                                                           num_was_hit/game_result; NULL fields are left alone */
 /* Device self-test: the step kernel's hand-sequenced fp64 divide / sqrt (no range-scaling
  * wrappers) against the compiler's `/` and sqrt() on >= `samples` random operands of the
  * magnitudes the step uses; mismatch_host[0] = differing quotients, [1] = differing roots,

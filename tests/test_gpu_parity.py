@@ -423,3 +423,45 @@ def test_reset_choice_interleaving_golden(fa, golden_dir, kernel):
     assert "pipe" not in eng.step_variant(64)
     eng.set_reset_choice(0)
     assert eng.step_variant(64) == ("fa_step_pipe_kernel" if kernel == "auto" else eng.step_variant(64))
+
+
+def test_facade_default_draws_from_the_global_numpy_stream(fa, golden_dir):
+    """make_fortattack_env(num_steps) with NO extra arguments, after the script's np.random.seed(seed)
+    (train_fortattack.py:200): construction and every reset consume numpy's global stream exactly as the
+    reference does -- the golden capture of the reference 5v5 env (seed 123) is reproduced, reward types
+    included (int 0 for agents that are neither alive nor justDied, fortattack_env_v1.py:87-92)."""
+    g = _load(golden_dir, "env_5v5")
+    G, A, max_t, T, E, base_seed, skip = [int(v) for v in g["meta"]]
+    assert (G, A) == (5, 5)
+    np.random.seed(base_seed)                                   # env 0 of the fixture <-> seed base_seed
+    env = fa.make_fortattack_env(max_t)
+    obs = env.reset()
+    assert obs.dtype == np.float64 and np.array_equal(obs, g["obs0"][0])
+    alive_before = obs[:, 0] != 0
+    ints = 0
+    for t in range(T):
+        obs, rew, done, info = env.step(g["actions"][t, 0].astype(np.int64))
+        assert done == bool(g["done"][t, 0])
+        assert np.abs(np.array(rew, dtype=np.float64) - g["reward"][t, 0]).max() <= FLOAT_TOL
+        for i in range(G + A):
+            assert (type(rew[i]) is int and rew[i] == 0) == (not alive_before[i]), (t, i)
+            ints += type(rew[i]) is int
+        if done:
+            assert env.world.gameResult.tolist() == g["game_result"][t, 0].tolist()
+            obs = env.reset()
+            assert env.world.gameResult.tolist() == [0, 0, 0]  # reset_world clears it (fortattack_env_v1.py:54)
+        assert np.abs(obs - g["obs"][t, 0]).max() <= FLOAT_TOL, t
+        alive_before = obs[:, 0] != 0
+    assert ints > 0 and int(g["done"][:, 0].sum()) >= 1
+    # the global stream is where the reference's would be: the next draw equals a reference-side draw
+    np.random.seed(base_seed)
+    np.random.random_sample(2 * (G + A) * (2 + int(g["done"][:, 0].sum())))   # construction + first reset + one per episode
+    expect = np.random.random_sample()
+    np.random.seed(base_seed)
+    env2 = fa.make_fortattack_env(max_t)
+    env2.reset()
+    for t in range(T):
+        _, _, d, _ = env2.step(g["actions"][t, 0].astype(np.int64))
+        if d:
+            env2.reset()
+    assert np.random.random_sample() == expect
