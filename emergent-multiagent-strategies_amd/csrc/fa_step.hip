@@ -878,6 +878,12 @@ __global__ __launch_bounds__(NW * FA_WAVE) void fa_step_kernel(FaStepArgs a) {
 //     does not wait for this step's forces (a dead agent's value is never used; a reset agent
 //     takes the constant pair).
 // Two workgroup barriers per step: B2 (pair + wall forces of step s are in LDS) and P.
+// which pair wave (1..NPW) computes partner offset d: alternating; at N = 6 the half offset (2d == N, half
+// the lanes) goes to the LAST pair wave instead -- wave 1 also owns the reset stream and the reward rows and
+// with two offsets it was the wave everybody waited for at B2 (156 vs 161 us; at N = 10 the alternating
+// split {1,3,5} / {2,4} is the faster one).  Handing the half offset to the walls wave was slower still.
+template <int N, int NPW>
+__device__ constexpr int fa_pair_wave(int d) { return (N == 6 && 2 * d == N) ? NPW : 1 + (d - 1) % NPW; }
 template <int TG, int TA, bool COLLECT, int NPW, int MINW>
 __global__ __launch_bounds__((NPW + 2) * FA_WAVE, MINW) void fa_step_pipe_kernel(FaStepArgs a) {
     constexpr int G = TG, A = TA, N = TG + TA;
@@ -910,7 +916,37 @@ __global__ __launch_bounds__((NPW + 2) * FA_WAVE, MINW) void fa_step_pipe_kernel
     __shared__ double s_rp[2][FA_WAVE]; // positions of the lane's next reset (drawn ahead by wave 1)
 
     if (wave_id == NPW + 1) {
-        // ---- last wave: walls of step s, sin/cos of the heading of step s+1 ----------------------
+        // ---- last wave: walls of step s, sin/cos of the heading of step s+1, and the done / mask rows +
+        // end-of-episode bookkeeping of the previous step ----------------------------------------------
+        uint8_t *p_done = a.done ? a.done + e : nullptr;
+        float *p_mask = a.mask32 ? a.mask32 + idx : nullptr;
+        asm volatile("" : "+v"(p_done), "+v"(p_mask));
+        bool alive0_prev = false;
+        // a step finished: buffer bo holds its by-products (called once per step, in order)
+        auto emit_flags = [&](int bo) {
+            const unsigned long long m1 = s_mask[bo][1];
+            const bool alive1 = (m1 >> lane) & 1ull;
+            const bool done = (s_mask[bo][4] >> lane) & 1ull;
+            const int n_alive_att = __popcll(((m1 >> gbase) & grp_mask) >> G);
+            // dist_door < fort_dim decided on the square, as wave 0 does (FaDerived::fort2_max)
+            const unsigned long long in_fort_b = fa_ballot(is_att && alive1 && s_dd[bo][lane] <= c.fort2_max);
+            const bool any_in_fort = ((in_fort_b >> gbase) & grp_mask) != 0ull;
+            // ---- fortattack.py:202-225 _get_done bookkeeping --------------------------------------
+            if (i == 0) {
+                if (done) {
+                    const int which = any_in_fort ? 2 : (n_alive_att == 0 ? 0 : 1);
+                    uint8_t *gr = a.s.game_result + (size_t)e * 3;
+                    gr[0] = which == 0; gr[1] = which == 1; gr[2] = which == 2;
+                    atomicAdd(a.s.result_count + (size_t)e * 3 + which, 1u);
+                }
+                if (COLLECT || a.done) *p_done = done ? 1 : 0;
+            }
+            // trainer mask (train_fortattack.py:53,87): alive BEFORE the step; an env that is
+            // reset here gets the post-reset mask 1 (initialize_new_episode, rlagent.py:31)
+            const float mk = (alive0_prev || (done && a.auto_reset != 0)) ? 1.0f : 0.0f;
+            if (COLLECT || a.mask32) *p_mask = mk;
+            p_mask += EN; p_done += a.E;
+        };
         FA_TICK_INIT
         FA_WG_BARRIER(); // P(-1)
         for (int s = 0; s < ns; ++s) {
@@ -947,10 +983,13 @@ __global__ __launch_bounds__((NPW + 2) * FA_WAVE, MINW) void fa_step_pipe_kernel
                 s_trig[(s + 1) & 1][0][lane] = cs;
                 s_trig[(s + 1) & 1][1][lane] = sn;
             }
+            if (s > 0) emit_flags(b);
+            alive0_prev = alive0;
             FA_TICK(19)
             FA_WG_BARRIER(); // P(s)
         }
         FA_WG_BARRIER(); // (wave 0 publishes the last step's by-products)
+        emit_flags(ns & 1);
         FA_TICK_FLUSH(16, 20, 30)
         return;
     }
@@ -972,11 +1011,10 @@ __global__ __launch_bounds__((NPW + 2) * FA_WAVE, MINW) void fa_step_pipe_kernel
         bool alive0_prev = false;
         // the output rows are walked with per-lane pointers and the reward constants sit in VGPRs:
         // base pointers, strides and fp64 literals as SGPRs overflow the scalar file (see wave 0)
-        float *p_rew = a.rew32 ? a.rew32 + idx : nullptr, *p_mask = a.mask32 ? a.mask32 + idx : nullptr;
-        uint8_t *p_done = a.done ? a.done + e : nullptr;
+        float *p_rew = a.rew32 ? a.rew32 + idx : nullptr;
         long long row = (long long)idx; // row of the step being emitted in the optional (E, N) outputs
         double k_fort = c.fort_dim, k_03 = 0.3, k_10 = 10.0, k_3 = 3.0, k_01 = 0.1;
-        asm volatile("" : "+v"(p_rew), "+v"(p_mask), "+v"(p_done), "+v"(row));
+        asm volatile("" : "+v"(p_rew), "+v"(row));
         asm volatile("" : "+v"(k_fort), "+v"(k_03), "+v"(k_10), "+v"(k_3), "+v"(k_01));
         // a step finished: buffer bo holds the state after it and its by-products
         // (called once per step, in order)
@@ -992,23 +1030,13 @@ __global__ __launch_bounds__((NPW + 2) * FA_WAVE, MINW) void fa_step_pipe_kernel
             const int n_alive_att = __popcll(((m1 >> gbase) & grp_mask) >> G);
             const unsigned long long in_fort_b = fa_ballot(is_att && alive1 && dist_door < k_fort);
             const bool any_in_fort = ((in_fort_b >> gbase) & grp_mask) != 0ull;
-            const bool do_reset = done && a.auto_reset != 0;
             // ---- rewards (fortattack_env_v1.py:87-188), after World.step ----------------------
+            // (the done / mask rows and the end-of-episode bookkeeping of the step: the last wave's emit_flags)
             const bool just_died = alive0 && was_hit;
             const bool rewarded = (alive1 || just_died);
             const double rew = fa_reward(is_att, rewarded, prev, dist_door, shoot, hit, was_hit, n_alive_att, any_in_fort,
                                          k_fort, k_03, k_10, k_3, k_01);
             prev = rewarded ? dist_door : prev;
-            // ---- fortattack.py:202-225 _get_done bookkeeping --------------------------------------
-            if (i == 0) {
-                if (done) {
-                    const int which = any_in_fort ? 2 : (n_alive_att == 0 ? 0 : 1);
-                    uint8_t *gr = a.s.game_result + (size_t)e * 3;
-                    gr[0] = which == 0; gr[1] = which == 1; gr[2] = which == 2;
-                    atomicAdd(a.s.result_count + (size_t)e * 3 + which, 1u);
-                }
-                if (COLLECT || a.done) *p_done = done ? 1 : 0;
-            }
             // evaluation statistics (test_fortattack_v2.py:88-101)
             if (a.track_counters) {
                 ep_rew += alive0 ? rew : 0.0;
@@ -1018,20 +1046,15 @@ __global__ __launch_bounds__((NPW + 2) * FA_WAVE, MINW) void fa_step_pipe_kernel
                     ep_rew = 0.0;
                 }
             }
-            // trainer mask (train_fortattack.py:53,87): alive BEFORE the step; an env that is
-            // reset here gets the post-reset mask 1 (initialize_new_episode, rlagent.py:31)
-            const float mk = (alive0 || do_reset) ? 1.0f : 0.0f;
             if (COLLECT) {
                 *p_rew = (float)rew;
-                *p_mask = mk;
             } else {
                 if (a.rew32) *p_rew = (float)rew;
                 if (a.rew64) a.rew64[row] = rew;
-                if (a.mask32) *p_mask = mk;
                 if (a.hit) a.hit[row] = hit ? 1 : 0;
                 if (a.was_hit) a.was_hit[row] = was_hit ? 1 : 0;
             }
-            p_rew += EN; p_mask += EN; p_done += a.E; row += (long long)EN;
+            p_rew += EN; row += (long long)EN;
         };
         float *p_obs = a.obs32 ? a.obs32 + idx * 6 : nullptr;
         long long row6 = (long long)idx * 6;
@@ -1092,7 +1115,7 @@ __global__ __launch_bounds__((NPW + 2) * FA_WAVE, MINW) void fa_step_pipe_kernel
             if constexpr (HOISTQ) {
 #pragma unroll
                 for (int d = 1; d <= NOFF; ++d) {
-                    if ((d - 1) % NPW != wave_id - 1) continue; // uniform per wave
+                    if (fa_pair_wave<N, NPW>(d) != wave_id) continue; // uniform per wave
                     int j = i + d;
                     j = j >= N ? j - N : j;
                     qx[d - 1] = s_px[b][gbase + j];
@@ -1101,7 +1124,7 @@ __global__ __launch_bounds__((NPW + 2) * FA_WAVE, MINW) void fa_step_pipe_kernel
             }
 #pragma unroll
             for (int d = 1; d <= NOFF; ++d) {
-                if ((d - 1) % NPW != wave_id - 1) continue; // uniform per wave
+                if (fa_pair_wave<N, NPW>(d) != wave_id) continue; // uniform per wave
                 int j = i + d;
                 j = j >= N ? j - N : j;
                 const bool mine = (2 * d != N) || (i < N / 2); // the half offset: one side only

@@ -5,7 +5,7 @@ import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import emergent_multiagent_strategies_amd as fa
-TIMING_LIB = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_build", "libfa_timing.so")
+TIMING_LIB = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_build", os.environ.get("FA_TIMING_LIB", "libfa_timing.so"))
 fa._lib._build.LIB = TIMING_LIB   # same C ABI + fa_dbg_read / fa_dbg_hw
 E = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 G = int(sys.argv[2]) if len(sys.argv) > 2 else 3
