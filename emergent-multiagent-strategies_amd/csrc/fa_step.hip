@@ -1179,6 +1179,9 @@ __global__ __launch_bounds__((NPW + 2) * FA_WAVE, MINW) void fa_step_pipe_kernel
     }
 
     // ---- wave 0 ----------------------------------------------------------------------------------
+    // the chain of the launch: where two workgroups share a CU it out-prioritises the helper wave of the
+    // other workgroup that sits on its SIMD
+    __builtin_amdgcn_s_setprio(3);
     FA_PROBE_WAVE0_BEGIN
     double px = a.s.px[idx], py = a.s.py[idx], vx = a.s.vx[idx], vy = a.s.vy[idx];
     double ang = a.s.ang[idx];

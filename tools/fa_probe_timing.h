@@ -6,12 +6,12 @@
 #define FA_TICK_WAVE1 0 // 1: report pair wave 1 instead of the last pair wave
 #endif
 __device__ unsigned long long g_dbg[32];
-__device__ unsigned g_hw[512];
+__device__ unsigned g_hw[4096];
 #define FA_TICK_INIT unsigned long long tacc[24] = {0}; unsigned long long tlast = clock64();
 #define FA_TICK(k) { const unsigned long long _n = clock64(); tacc[k] += _n - tlast; tlast = _n; }
 #define FA_TICK_FLUSH(lo, hi, cnt) if (lane == 0) { for (int k = lo; k < hi; ++k) atomicAdd(&g_dbg[k], tacc[k]); atomicAdd(&g_dbg[cnt], 1ull); }
 // where the hardware put this wave (HW_ID: simd [5:4], cu [11:8], se [15:13])
-#define FA_PROBE_HWID(lane, wave_id) if (lane == 0 && blockIdx.x < 64) { unsigned hw; \
+#define FA_PROBE_HWID(lane, wave_id) if (lane == 0 && blockIdx.x < 512) { unsigned hw; \
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); g_hw[blockIdx.x * 8 + wave_id] = hw | 0x80000000u; }
 #define FA_PROBE_WAVE0_BEGIN const unsigned long long tp0 = clock64();
 #define FA_PROBE_WAVE0_LOOP_BEGIN(lane) const unsigned long long tk0 = clock64(), tw0 = wall_clock64(); \
@@ -23,4 +23,4 @@ extern "C" int fa_dbg_read(unsigned long long *out, int reset) {
     if (reset) { unsigned long long z[32] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_dbg), z, sizeof(z)); }
     return 0;
 }
-extern "C" int fa_dbg_hw(unsigned *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_hw), sizeof(unsigned) * 512); }
+extern "C" int fa_dbg_hw(unsigned *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_hw), sizeof(unsigned) * 4096); }

@@ -41,13 +41,23 @@ for lo, hi, cnt in ((0, 8, 28), (10, 14, 29), (16, 20, 30)):
 print("wave 0 loop: %.1f shader-clock ticks per step, %.1f ns per step (100 MHz wall clock) -> %.3f ticks/ns" % (
     buf[20] / max(buf[28], 1) / T, buf[21] / max(buf[28], 1) / T * 10.0, buf[20] / max(buf[21], 1) / 10.0))
 print("wave 0: prologue (wave start -> P(-1)) %.0f cycles, P(-1) -> end %.0f cycles" % (buf[22] / max(buf[28], 1), buf[23] / max(buf[28], 1)))
-hw = (C.c_uint * 512)()
+hw = (C.c_uint * 4096)()
 lib.fa_dbg_hw(hw)
-print("wave placement (workgroup: wave->simd@cu.se):")
-for b in list(range(6)) + list(range(58, 64)):
+# HW_ID: wave slot [3:0], simd [5:4], cu [11:8], sh [12], se [15:13] (+ xcc from XCC_ID, not read: CUs are
+# distinguished per (se, sh, cu) only, so 8 XCDs alias -- co-residency is judged by launch order instead)
+import collections
+place = {}
+for b in range(min(512, (E + 9) // 10)):
     row = []
-    for w in range(8):
+    for w in range(4):
         v = hw[b * 8 + w]
         if v & 0x80000000:
-            row.append("w%d->simd%d@cu%d.se%d" % (w, (v >> 4) & 3, (v >> 8) & 15, (v >> 13) & 7))
-    print("  wg %3d: %s" % (b, "  ".join(row)))
+            row.append(((v >> 4) & 3, v & 15, (v >> 8) & 15, (v >> 12) & 1, (v >> 13) & 7))
+    place[b] = row
+pat = collections.Counter(tuple(r[0] for r in row) for row in place.values())
+print("wave->simd patterns (w0,w1,w2,w3):", dict(pat))
+slots = collections.Counter(tuple(r[1] for r in row) for row in place.values())
+print("wave slot ids per workgroup:", dict(slots))
+for b in list(range(4)) + list(range(256, 260)):
+    if b in place:
+        print("  wg %3d: %s" % (b, "  ".join("w%d->simd%d slot%d cu%d.sh%d.se%d" % ((w,) + r) for w, r in enumerate(place[b]))))
