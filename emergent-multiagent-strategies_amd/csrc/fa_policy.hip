@@ -56,16 +56,30 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32
     }
 }
 
+// The first weights of a layer are requested well before the layer starts (behind the previous layer's
+// stores, barrier and attention phase): an L2 round trip per layer start was a fifth of the kernel.
+template <int K>
+struct BHead {
+    static constexpr int NT = K / 8;           // 16-byte steps per lane half
+    static constexpr int CH = NT < 8 ? NT : 8;  // steps per chunk
+    float4 v[CH];
+};
+template <int K>
+__device__ __forceinline__ void prefetch_b(const float4 *__restrict__ wp, int lane, BHead<K> &h) {
+#pragma unroll
+    for (int c = 0; c < BHead<K>::CH; ++c) h.v[c] = wp[c * 64 + lane];
+}
+
 // acc[r] += Act[rows of block r][K] * W[K][32 columns of one block]   (fp32 MFMA, exact fmaf chain)
 // arow: this lane's first A element -- &Act[(rb0*32 + (lane & 31)) * LDA + <start of the lane half's k range>]
-// wp:   packed weights of the column block: [K/8][64] float4
+// wp:   packed weights of the column block: [K/8][64] float4;  head: its first chunk, already requested
 template <int K, int NRB>
-__device__ __forceinline__ void gemm_cb(const float *arow, const float4 *__restrict__ wp, f32x16 (&acc)[NRB], int lane) {
-    constexpr int NT = K / 8;          // 16-byte steps per lane half
-    constexpr int CH = NT < 8 ? NT : 8; // weights prefetched a chunk of CH steps ahead
+__device__ __forceinline__ void gemm_cb(const float *arow, const float4 *__restrict__ wp, f32x16 (&acc)[NRB], int lane,
+                                        const BHead<K> &head) {
+    constexpr int NT = BHead<K>::NT, CH = BHead<K>::CH; // weights are fetched a chunk of CH steps ahead
     float4 bq[CH], bn[CH];
 #pragma unroll
-    for (int c = 0; c < CH; ++c) bq[c] = wp[c * 64 + lane];
+    for (int c = 0; c < CH; ++c) bq[c] = head.v[c];
 #pragma unroll
     for (int t0 = 0; t0 < NT; t0 += CH) {
         if (t0 + CH < NT) {
@@ -103,11 +117,16 @@ __device__ __forceinline__ void store_acc(float *dst, int rb, const f32x16 &acc,
     }
 }
 
-__device__ __forceinline__ float group16_sum(float v) { // sum over the 16 lanes of a row's sub-group
-    v += __shfl_xor(v, 1);
-    v += __shfl_xor(v, 2);
-    v += __shfl_xor(v, 4);
-    v += __shfl_xor(v, 8);
+// sum over the 16 lanes of a row's sub-group == one DPP row: four rotate-and-add steps on the VALU
+// (row_ror:8,4,2,1), every lane ends with the total.  (__shfl_xor goes through ds_bpermute: an LDS round
+// trip per step, 4 dependent ones per score.)
+__device__ __forceinline__ float group16_sum(float v) {
+#define FA_ROR_ADD(n) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x120 | (n), 0xf, 0xf, false))
+    FA_ROR_ADD(8);
+    FA_ROR_ADD(4);
+    FA_ROR_ADD(2);
+    FA_ROR_ADD(1);
+#undef FA_ROR_ADD
     return v;
 }
 
@@ -200,6 +219,16 @@ __global__ __launch_bounds__(256, 1) void fa_policy_kernel(FaPolicyArgs a) {
     }
     __syncthreads();
 
+    const int li = lane & 31, hh = lane >> 5;
+    const float4 *Wq = reinterpret_cast<const float4 *>(W);
+    const float4 *wp_ao = Wq + FA_POFF_AO / 4 + (wave & 1) * (64 / 8) * 64;
+    const float4 *wp_bo = Wq + FA_POFF_BO / 4 + (wave & 1) * (64 / 8) * 64;
+    const float4 *wp_am = Wq + FA_POFF_AM / 4 + wave * (128 / 8) * 64;
+    const float4 *wp_w7 = Wq + FA_POFF_W7 / 4 + wave * (256 / 8) * 64;
+    const float4 *wp_w8p = Wq + FA_POFF_W8 / 4 + wave * (128 / 8) * 64;
+    const float4 *wp_w8v = Wq + FA_POFF_W8 / 4 + (4 + wave) * (128 / 8) * 64;
+    BHead<64> hd_o;
+    prefetch_b<64>(wp_ao, lane, hd_o);
     // ---- encoders (mpnn.py:37-38): h1 = relu(x We + be) -> sH[:, 0:64] (own rows), ho -> sG[:, 0:64] (opp rows)
     {
         const int col = tid & 63, grp = tid >> 6;
@@ -234,21 +263,20 @@ __global__ __launch_bounds__(256, 1) void fa_policy_kernel(FaPolicyArgs a) {
     }
     __syncthreads();
 
-    const int li = lane & 31, hh = lane >> 5;
-    const float4 *Wq = reinterpret_cast<const float4 *>(W);
     // ---- opponent attention (mpnn.py:372-443): g_o = h1 A_o -> sG[:, 64:128] --------------------------------
     // 64 output columns = 2 column blocks: waves 0,1 take row blocks 0,1; waves 2,3 row block 2
     {
         const int cb = wave & 1;
-        const float4 *wp = Wq + FA_POFF_AO / 4 + cb * (64 / 8) * 64;
         if (wave < 2) {
             f32x16 acc[2] = {};
-            gemm_cb<64, 2>(sH + li * LDA + hh * 32, wp, acc, lane);
+            gemm_cb<64, 2>(sH + li * LDA + hh * 32, wp_ao, acc, lane, hd_o);
+            prefetch_b<64>(wp_bo, lane, hd_o);
             store_acc<false>(sG + 64 + cb * 32, 0, acc[0], 0.0f, lane);
             store_acc<false>(sG + 64 + cb * 32, 1, acc[1], 0.0f, lane);
         } else {
             f32x16 acc[1] = {};
-            gemm_cb<64, 1>(sH + (64 + li) * LDA + hh * 32, wp, acc, lane);
+            gemm_cb<64, 1>(sH + (64 + li) * LDA + hh * 32, wp_ao, acc, lane, hd_o);
+            prefetch_b<64>(wp_bo, lane, hd_o);
             store_acc<false>(sG + 64 + cb * 32, 2, acc[0], 0.0f, lane);
         }
     }
@@ -263,27 +291,31 @@ __global__ __launch_bounds__(256, 1) void fa_policy_kernel(FaPolicyArgs a) {
     }
     __syncthreads();
     // e_opp = hmix_o B_o -> sH[:, 64:128]   (h = [h1 | e_opp], mpnn.py:143)
+    BHead<128> hd_m;
     {
         const int cb = wave & 1;
-        const float4 *wp = Wq + FA_POFF_BO / 4 + cb * (64 / 8) * 64;
         if (wave < 2) {
             f32x16 acc[2] = {};
-            gemm_cb<64, 2>(sG + li * LDA + 64 + hh * 32, wp, acc, lane);
+            gemm_cb<64, 2>(sG + li * LDA + 64 + hh * 32, wp_bo, acc, lane, hd_o);
+            prefetch_b<128>(wp_am, lane, hd_m);
             store_acc<false>(sH + 64 + cb * 32, 0, acc[0], 0.0f, lane);
             store_acc<false>(sH + 64 + cb * 32, 1, acc[1], 0.0f, lane);
         } else {
             f32x16 acc[1] = {};
-            gemm_cb<64, 1>(sG + (64 + li) * LDA + 64 + hh * 32, wp, acc, lane);
+            gemm_cb<64, 1>(sG + (64 + li) * LDA + 64 + hh * 32, wp_bo, acc, lane, hd_o);
+            prefetch_b<128>(wp_am, lane, hd_m);
             store_acc<false>(sH + 64 + cb * 32, 2, acc[0], 0.0f, lane);
         }
     }
     __syncthreads();
 
     // ---- K = 3 rounds of message passing with shared weights (mpnn.py:155-157) ------------------------------
+    BHead<256> hd_u;
     for (int round = 0; round < 3; ++round) {
         {   // g = h A -> sG (wave = column block)
             f32x16 acc[3] = {};
-            gemm_cb<128, 3>(sH + li * LDA + hh * 64, Wq + FA_POFF_AM / 4 + wave * (128 / 8) * 64, acc, lane);
+            gemm_cb<128, 3>(sH + li * LDA + hh * 64, wp_am, acc, lane, hd_m);
+            prefetch_b<256>(wp_w7, lane, hd_u);
 #pragma unroll
             for (int rb = 0; rb < 3; ++rb) store_acc<false>(sG + wave * 32, rb, acc[rb], 0.0f, lane);
         }
@@ -298,7 +330,8 @@ __global__ __launch_bounds__(256, 1) void fa_policy_kernel(FaPolicyArgs a) {
         __syncthreads();
         {   // h' = relu([h | hmix] W7 + bu): lane half 0 walks h, half 1 walks hmix
             f32x16 acc[3] = {};
-            gemm_cb<256, 3>((hh ? sG : sH) + li * LDA, Wq + FA_POFF_W7 / 4 + wave * (256 / 8) * 64, acc, lane);
+            gemm_cb<256, 3>((hh ? sG : sH) + li * LDA, wp_w7, acc, lane, hd_u);
+            prefetch_b<128>(round < 2 ? wp_am : wp_w8p, lane, hd_m); // next: the following round's g, or the policy head
             const float bias = W[FA_POFF_BU + wave * 32 + li];
             __syncthreads(); // every wave has read the old h
 #pragma unroll
@@ -310,8 +343,11 @@ __global__ __launch_bounds__(256, 1) void fa_policy_kernel(FaPolicyArgs a) {
     // ---- heads: [p | v] = relu(h [Wp0 | Wv0] + b) (mpnn.py:66-72), p -> sG, v -> sH ------------------------
     {
         f32x16 accp[3] = {}, accv[3] = {};
-        gemm_cb<128, 3>(sH + li * LDA + hh * 64, Wq + FA_POFF_W8 / 4 + wave * (128 / 8) * 64, accp, lane);
-        gemm_cb<128, 3>(sH + li * LDA + hh * 64, Wq + FA_POFF_W8 / 4 + (4 + wave) * (128 / 8) * 64, accv, lane);
+        BHead<128> hd_v;
+        prefetch_b<128>(wp_w8v, lane, hd_v);
+        gemm_cb<128, 3>(sH + li * LDA + hh * 64, wp_w8p, accp, lane, hd_m);
+        gemm_cb<128, 3>(sH + li * LDA + hh * 64, wp_w8v, accv, lane, hd_v);
+        if (wave < 3) prefetch_b<256>(Wq + FA_POFF_W9 / 4, lane, hd_u);
         const float bp = W[FA_POFF_B8 + wave * 32 + li], bv = W[FA_POFF_B8 + 128 + wave * 32 + li];
         __syncthreads(); // every wave has read h
 #pragma unroll
@@ -324,7 +360,7 @@ __global__ __launch_bounds__(256, 1) void fa_policy_kernel(FaPolicyArgs a) {
     // logits (8) | value (1) = [p | v] W9 + b9, W9 block diagonal in a 32-column block: wave = row block
     if (wave < 3) {
         f32x16 acc[1] = {};
-        gemm_cb<256, 1>((hh ? sH : sG) + (wave * 32 + li) * LDA, Wq + FA_POFF_W9 / 4, acc, lane);
+        gemm_cb<256, 1>((hh ? sH : sG) + (wave * 32 + li) * LDA, Wq + FA_POFF_W9 / 4, acc, lane, hd_u);
         if (li < 16) {
             const float bias = W[FA_POFF_B9 + li];
 #pragma unroll
