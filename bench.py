@@ -78,6 +78,22 @@ def host_cpu():
     return model, len(cores) or threads, threads
 
 
+def cpu_quota():
+    """CPUs' worth of time the container may use per period (cgroup v2 cpu.max / v1 cfs quota), or None when
+    unlimited / unknown: a box can expose 256 hardware threads and still be throttled to a fraction."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else float(q) / float(per)
+    except Exception:
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / per
+    except Exception:
+        return None
+
+
 def cpu_baseline(E, G, A, T, budget_s=20.0):
     """The CPU oracle (oracle/fa_oracle.c, a C port of the reference's env.step) timed on this box's
     host cores on a bounded sample of the same workload (uniform-random actions, auto-reset).
@@ -87,7 +103,9 @@ def cpu_baseline(E, G, A, T, budget_s=20.0):
     that libgomp starts with the right settings) and the best is reported with its thread count."""
     avail = len(os.sched_getaffinity(0))
     model, phys_cores, hw_threads = host_cpu()
-    sweep = sorted({t for t in (1, 8, 16, 32, 64, 128, phys_cores, avail) if 1 <= t <= avail})
+    quota = cpu_quota()
+    cap = avail if quota is None else min(avail, max(1, int(quota * 4)))   # far beyond the quota only throttles
+    sweep = sorted({t for t in (1, 8, 16, 32, 64, 128, phys_cores, avail, int(quota or 0)) if 1 <= t <= cap})
     per = max(1.0, budget_s / (len(sweep) + 1))
     runs = []
 
@@ -110,6 +128,8 @@ def cpu_baseline(E, G, A, T, budget_s=20.0):
     per_step = run(best["threads"], "step", best.get("envs", E))   # one parallel region per env-step (round-1 form)
     return {"value": best["env_steps_per_s"], "unit": "env-steps/s", "cores": best["threads"], "kind": "port",
             "cpu_model": model, "physical_cores": phys_cores, "hardware_threads": hw_threads,
+            "cgroup_cpu_quota": quota,   # CPUs' worth of time this container may use (None = unlimited)
+            "loadavg": os.getloadavg()[0],
             "sample": "oracle/fa_oracle.c fao_rollout (C port of the reference env.step + auto-reset; one OpenMP "
                       "region per %d-step rollout, static env slices, pinned threads): %d envs x %d steps in %.1f s on "
                       "%d threads; sweep (threads, env-steps/s) = %s over %d usable cpus; 1 thread: %.0f env-steps/s; "

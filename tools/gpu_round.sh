@@ -10,7 +10,7 @@ export TMPDIR=/tmp
 cd $R
 for w in $WHAT; do
 case $w in
-tests) timeout 2400 python -m pytest tests -m gpu -q > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log; tail -15 $O/pytest.log;;
+tests) timeout 2400 python -m pytest tests -m gpu -q -x > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log; tail -15 $O/pytest.log;;
 bench) timeout 900 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"; cut -c1-600 $O/bench.json; tail -3 $O/bench.err;;
 probe) timeout 300 python tools/timing_probe.py > $O/timing_probe.txt 2>&1; cat $O/timing_probe.txt | head -40;;
 closed) cd /tmp; timeout 900 rocprofv3 --kernel-trace --stats -f csv -d $O/closed_trace -o trace -- python $R/bench_rollout_mpnn.py --iters 2 --update 0 > $O/closed.json 2> $O/closed.err; cd $R;

@@ -8,7 +8,7 @@ cd /tmp
 i=0
 for grp in "SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE" "SQ_IFETCH SQ_IFETCH_LEVEL SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_BRANCH" "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS" "SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_SALU"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $grp -f csv -d $OUT/g$i -o g -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-collector ${PROBE_ARGS:-} > /dev/null 2> $OUT/g$i.err
+  rocprofv3 --kernel-trace --pmc $grp -f csv -d $OUT/g$i -o g -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-closed-loop --no-collector --min-seconds 0 ${PROBE_ARGS:-} > /dev/null 2> $OUT/g$i.err
 done
 cd $R
 python - <<'PY'

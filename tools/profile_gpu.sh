@@ -6,7 +6,7 @@
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 TAG=${1:-r01}
-ARGS=${2:---steps 20 --warmup 3 --no-cpu-baseline}
+ARGS=${2:---steps 20 --warmup 3 --no-cpu-baseline --no-closed-loop}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
