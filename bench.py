@@ -384,6 +384,7 @@ def closed_loop(fa, args, rank, local_rank, world, dev, barrier):
     torch.manual_seed(1 + rank)                               # different action sampling per rank
     L.reset()
     L.collect()
+    L.update()                                                # untimed: captures the update's hipGraphs
     L.after_update()
     torch.cuda.synchronize()
     barrier()
@@ -416,7 +417,8 @@ def closed_loop(fa, args, rank, local_rank, world, dev, barrier):
         "rollout_env_steps_per_s": world * E * T / per_rollout, "rollout_ms": per_rollout * 1e3,
         "ms_per_env_step_launch": per_rollout * 1e3 / T, "rollouts_timed": R,
         "update_s": t_upd, "train_env_steps_per_s": world * E * T / (per_rollout + t_upd),
-        "update": "JointPPO: 4 epochs x 32 minibatches x 2 teams, Adam, grad-clip%s" % (
+        "update": "JointPPO: 4 epochs x 32 minibatches x 2 teams, Adam, grad-clip; every optimizer step replayed from a "
+                  "hipGraph%s" % (
             "" if world == 1 else ", flat gradient all-reduce per optimizer step"),
         "dtype": "f32 policy / f64 env", "unit": "env-steps/s"}
 

@@ -36,6 +36,8 @@ def main():
                                   for _ in range(a.ensemble)])
     L.reset()
     L.collect()
+    if a.update:                       # untimed: captures the update's hipGraphs
+        L.update(train_guards_only=bool(a.ensemble))
     L.after_update()
     torch.cuda.synchronize()
     t_roll = t_upd = 0.0

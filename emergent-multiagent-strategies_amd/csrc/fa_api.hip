@@ -27,6 +27,8 @@ hipError_t fa_launch_adv_stats(int pass, const float *returns, const float *valu
 hipError_t fa_launch_adv_merge(const double *gathered, int W, int N, double *mean_out, double *std_out,
                                hipStream_t st);
 hipError_t fa_launch_adv_moments_fix(double *stats, int N, hipStream_t st);
+hipError_t fa_launch_attend(int width, bool backward, const float *g, const float *keys, float *out, float *attn,
+                            const float *dout, float *dg, float *dkeys, int B, int n, int nk, int skip_self, hipStream_t st);
 hipError_t fa_launch_adv_norm(const float *returns, const float *value_preds, const double *mean,
                               const double *std_, long long total, int N, float *out, hipStream_t st);
 
@@ -585,6 +587,31 @@ int fa_collect_act(fa_env *env, int32_t step, const fa_policy_io *io, void *stre
 }
 
 int64_t fa_policy_weight_floats(void) { return FA_POLICY_WEIGHT_FLOATS; }
+
+static int attend_check(const char *who, int B, int n, int nk, int width) {
+    if (B < 1 || n < 1 || nk < 1 || n > FA_POLICY_MAX_TEAM || nk > FA_POLICY_MAX_TEAM)
+        return fail(FA_ERR_INVALID, std::string(who) + ": need B >= 1 and 1 <= n, nk <= 8");
+    if (width != 64 && width != 128) return fail(FA_ERR_INVALID, std::string(who) + ": width must be 64 or 128");
+    return FA_OK;
+}
+
+int fa_attend_forward(const float *g, const float *keys, float *out, float *attn, int32_t B, int32_t n, int32_t nk,
+                      int32_t width, int32_t skip_self, void *stream) {
+    if (!g || !keys || !out || !attn) return fail(FA_ERR_INVALID, "fa_attend_forward: null argument");
+    if (int rc = attend_check("fa_attend_forward", B, n, nk, width)) return rc;
+    FA_HIP(fa_launch_attend(width, false, g, keys, out, attn, nullptr, nullptr, nullptr, B, n, nk, skip_self,
+                            static_cast<hipStream_t>(stream)));
+    return FA_OK;
+}
+
+int fa_attend_backward(const float *g, const float *keys, const float *attn, const float *dout, float *dg, float *dkeys,
+                       int32_t B, int32_t n, int32_t nk, int32_t width, int32_t skip_self, void *stream) {
+    if (!g || !keys || !attn || !dout || !dg || !dkeys) return fail(FA_ERR_INVALID, "fa_attend_backward: null argument");
+    if (int rc = attend_check("fa_attend_backward", B, n, nk, width)) return rc;
+    FA_HIP(fa_launch_attend(width, true, g, keys, nullptr, const_cast<float *>(attn), dout, dg, dkeys, B, n, nk, skip_self,
+                            static_cast<hipStream_t>(stream)));
+    return FA_OK;
+}
 
 int fa_get_state(fa_env *env, const fa_state_host *o) {
     if (!env || !o) return fail(FA_ERR_INVALID, "fa_get_state: null argument");

@@ -62,8 +62,102 @@ def _world(group=None):
     return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
 
 
+class GraphedPPOStep(object):
+    """One optimizer step of joint_ppo_update -- minibatch forward, backward, (gradient exchange,) clip, Adam --
+    captured as hipGraph(s) and replayed: the step is ~300 small kernels and its Python / dispatcher time
+    (4 ms) exceeds its GPU time (2.7 ms at 16 384 x 3 samples); replayed, only the GPU time is left.
+
+    The minibatch is gathered into static buffers (index_select, outside the graph); parameters, gradients
+    and Adam state are the live tensors (the optimizer must be `capturable`).  One rank: one graph.  Several
+    ranks: two graphs around the eager all-reduce of the flat buffer (see joint_ppo_update).  Capture needs
+    warm-up iterations; they run on this minibatch and are undone (parameters and optimizer state restored)
+    before the first real step."""
+
+    def __init__(self, pol, opt, own_sl, opp_sl, rows, mb, clip_param, value_loss_coef, entropy_coef, max_grad_norm,
+                 clipped_value_loss, group):
+        self.pol, self.opt, self.group, self.world = pol, opt, group, _world(group)
+        self.params = [p for p in pol.parameters()]
+        self.static = [torch.empty((mb,) + tuple(r.shape[1:]), dtype=r.dtype, device=r.device) for r in rows]
+        self.mb = mb
+        world = self.world
+
+        def fwd_bwd():
+            obs_b, act_b, vp_b, ret_b, olp_b, adv_b = self.static
+            out = ppo_losses(pol, obs_b[:, own_sl], obs_b[:, opp_sl], act_b[:, own_sl], vp_b[:, own_sl], ret_b[:, own_sl],
+                             olp_b[:, own_sl], adv_b[:, own_sl], clip_param, clipped_value_loss, normalize=(world == 1))
+            opt.zero_grad(set_to_none=True)
+            (out[0] * value_loss_coef + out[1] - out[2] * entropy_coef).backward()
+            losses = torch.stack([out[0].detach(), out[1].detach(), out[2].detach()])
+            if world == 1:
+                return losses, None
+            grads = [p.grad for p in self.params if p.grad is not None]
+            return losses, torch.cat([g.reshape(-1) for g in grads] + [losses, out[3].detach().reshape(1)])
+
+        def finish(losses, flat):
+            if flat is not None:                              # after the all-reduce (sum over ranks)
+                flat = flat / world
+                mm = flat[-1]
+                flat = flat / torch.where(mm != 0, mm, torch.ones_like(mm))
+                losses = flat[-4:-1]
+                off = 0
+                for p in self.params:
+                    if p.grad is not None:
+                        p.grad.copy_(flat[off:off + p.grad.numel()].view_as(p.grad))
+                        off += p.grad.numel()
+            nn.utils.clip_grad_norm_(self.params, max_grad_norm)
+            opt.step()
+            return losses.clone()
+
+        def eager():
+            losses, flat = fwd_bwd()
+            if flat is not None:
+                dist.all_reduce(flat, group=group)
+            return finish(losses, flat)
+
+        # ---- warm-up on a side stream, then undo it -------------------------------------------------------
+        for st, src in zip(self.static, rows):
+            st.copy_(src[:mb])
+        saved_p = [p.detach().clone() for p in self.params]
+        had_state = len(opt.state) > 0
+        saved_s = {p: {k: v.clone() for k, v in opt.state[p].items() if torch.is_tensor(v)} for p in self.params if p in opt.state}
+        side = torch.cuda.Stream(rows[0].device)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                eager()
+        torch.cuda.current_stream().wait_stream(side)
+        with torch.no_grad():
+            for p, q in zip(self.params, saved_p):
+                p.copy_(q)
+            for p in self.params:
+                for k, v in opt.state.get(p, {}).items():
+                    if torch.is_tensor(v):
+                        v.copy_(saved_s[p][k]) if had_state and p in saved_s else v.zero_()
+        # ---- capture -----------------------------------------------------------------------------------
+        self.g1 = torch.cuda.CUDAGraph()
+        self.g2 = None
+        if world == 1:
+            with torch.cuda.graph(self.g1):
+                self.losses = eager()
+        else:
+            with torch.cuda.graph(self.g1):
+                l0, self.flat = fwd_bwd()
+            self.g2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.g2, pool=self.g1.pool()):
+                self.losses = finish(l0, self.flat)
+
+    def run(self, rows, idx):
+        for st, src in zip(self.static, rows):
+            torch.index_select(src, 0, idx, out=st)
+        self.g1.replay()
+        if self.g2 is not None:
+            dist.all_reduce(self.flat, group=self.group)
+            self.g2.replay()
+        return self.losses
+
+
 def joint_ppo_update(pol, opt, own_sl, opp_sl, rows, clip_param, ppo_epoch, num_mini_batch, value_loss_coef,
-                     entropy_coef, max_grad_norm, clipped_value_loss=True, group=None, sampler=None):
+                     entropy_coef, max_grad_norm, clipped_value_loss=True, group=None, sampler=None, graphs=None):
     """JointPPO.update (ppo.py:116-204) for one team's shared policy over flattened rollout rows.
 
     rows = (obs, actions, value_preds, returns, old_log_probs, advantages), each (B, N, .) with B = T * E
@@ -76,6 +170,8 @@ def joint_ppo_update(pol, opt, own_sl, opp_sl, rows, clip_param, ppo_epoch, num_
     of the un-normalised losses plus this rank's alive-mask mean; dividing by the all-rank mask mean
     afterwards gives exactly the gradient of the reference's loss on the union minibatch (the three
     losses are linear in 1 / mask.mean()), so all ranks step identically.
+    `graphs`: a dict owned by the caller -> full-size minibatch steps replay from hipGraphs (GraphedPPOStep;
+    CUDA tensors and a capturable optimizer); a ragged last minibatch runs eagerly.
     Returns a (3,) tensor: (value_loss, action_loss, entropy) summed over the minibatches and divided by
     ppo_epoch * num_mini_batch as the reference does (ppo.py:196-200)."""
     obs_f, act_f, vp_f, ret_f, olp_f, adv_f = rows
@@ -94,6 +190,13 @@ def joint_ppo_update(pol, opt, own_sl, opp_sl, rows, clip_param, ppo_epoch, num_
             perm = torch.randperm(batch, device=obs_f.device)   # SubsetRandomSampler (ppo.py:213)
             batches = [perm[k:k + mb] for k in range(0, batch, mb)]   # BatchSampler, drop_last=False
         for idx in batches:
+            if graphs is not None and idx.numel() == mb:
+                key = (id(pol), mb)
+                if key not in graphs:
+                    graphs[key] = GraphedPPOStep(pol, opt, own_sl, opp_sl, rows, mb, clip_param, value_loss_coef,
+                                                 entropy_coef, max_grad_norm, clipped_value_loss, group)
+                acc += graphs[key].run(rows, idx)
+                continue
             obs_b = obs_f[idx]
             out = ppo_losses(pol, obs_b[:, own_sl], obs_b[:, opp_sl], act_f[idx][:, own_sl], vp_f[idx][:, own_sl],
                              ret_f[idx][:, own_sl], olp_f[idx][:, own_sl], adv_f[idx][:, own_sl], clip_param,
@@ -140,7 +243,11 @@ class BatchedLearner(object):
                          MPNN(num_agents=self.A, num_opp_agents=self.G, hidden_dim=hidden_dim, num_actions=8)]
         for p in self.policies:
             p.to(self.device)
-        self.optimizers = [torch.optim.Adam(p.parameters(), lr=lr) for p in self.policies]  # ppo.py:114
+        # ppo.py:114 (capturable: the step count lives on the device, so that an optimizer step can be part of a
+        # hipGraph; same arithmetic)
+        self.optimizers = [torch.optim.Adam(p.parameters(), lr=lr, capturable=self.device.type == "cuda")
+                           for p in self.policies]
+        self._update_graphs = {} if use_graph else None
         self.storage = JointRolloutStorage(num_steps, self.E, self.N, device=self.device)
         eng.bind_storage(self.storage)
         self.team_slices = [slice(0, self.G), slice(self.G, self.N)]
@@ -384,7 +491,8 @@ class BatchedLearner(object):
             out.append(joint_ppo_update(
                 self.policies[ti], self.optimizers[ti], self.team_slices[ti], self.team_slices[1 - ti], rows,
                 self.clip_param, self.ppo_epoch, self.num_mini_batch, self.value_loss_coef, self.entropy_coef,
-                self.max_grad_norm, self.clipped_value_loss, self.group, sampler))
+                self.max_grad_norm, self.clipped_value_loss, self.group, sampler,
+                graphs=None if sampler is not None else self._update_graphs))
         return torch.stack(out)
 
     def after_update(self):

@@ -67,6 +67,60 @@ def _linear(x, lin):
     return _mm(x, lin.weight.t()) + lin.bias
 
 
+def attend_mix_reference(g, keys, n, skip_self):
+    """Plain-torch statement of csrc/fa_attend.hip: g (B*n, W) rows env-major, keys (B, nk, W) ->
+    softmax_j(g_i . k_j) mixed keys, (B*n, W); j == i excluded with skip_self (a team of one gets zeros)."""
+    B, nk, W = keys.shape
+    s = torch.matmul(g.view(B, n, W), keys.transpose(1, 2))                    # (B, n, nk)
+    if skip_self:
+        if nk == 1:
+            return g * 0.0
+        s = s + torch.zeros(n, nk, device=g.device, dtype=g.dtype).fill_diagonal_(-math.inf)
+    return torch.matmul(torch.softmax(s, dim=-1), keys).reshape(B * n, W)
+
+
+class _AttendMix(torch.autograd.Function):
+    """fa_attend_forward / fa_attend_backward (one launch each) on the current stream."""
+
+    @staticmethod
+    def forward(ctx, g, keys, n, skip_self):
+        import ctypes as C
+        from . import _lib
+        lib = _lib.load()
+        g, keys = g.contiguous(), keys.contiguous()
+        B, nk, W = keys.shape
+        out = torch.empty_like(g)
+        attn = torch.empty((B * n, nk), device=g.device, dtype=g.dtype)
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        _lib.check(lib.fa_attend_forward(g.data_ptr(), keys.data_ptr(), out.data_ptr(), attn.data_ptr(), B, n, nk, W,
+                                         int(skip_self), st), "fa_attend_forward")
+        ctx.save_for_backward(g, keys, attn)
+        ctx.n, ctx.skip_self = n, int(skip_self)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        import ctypes as C
+        from . import _lib
+        lib = _lib.load()
+        g, keys, attn = ctx.saved_tensors
+        B, nk, W = keys.shape
+        dout = dout.contiguous()
+        dg, dkeys = torch.empty_like(g), torch.empty_like(keys)
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        _lib.check(lib.fa_attend_backward(g.data_ptr(), keys.data_ptr(), attn.data_ptr(), dout.data_ptr(), dg.data_ptr(),
+                                          dkeys.data_ptr(), B, ctx.n, nk, W, ctx.skip_self, st), "fa_attend_backward")
+        return dg, dkeys, None, None
+
+
+def attend_mix(g, keys, n, skip_self):
+    """The agents-of-one-env attention: the fused HIP op on the GPU (widths 64 / 128, teams <= 8, float32),
+    the plain-torch statement elsewhere."""
+    if g.is_cuda and g.dtype == torch.float32 and keys.shape[2] in (64, 128) and n <= 8 and keys.shape[1] <= 8:
+        return _AttendMix.apply(g, keys, n, skip_self)
+    return attend_mix_reference(g, keys, n, skip_self)
+
+
 def _weights_init(m):  # mpnn.py:9-14
     name = m.__class__.__name__
     if name.find("Conv") != -1 or name.find("Linear") != -1:
@@ -136,6 +190,7 @@ class MPNN(nn.Module):
             num_actions = action_space.shape[0]  # mpnn.py:73
         self.dist = _Categorical(hidden_dim, num_actions)
         self.is_recurrent = False
+        self.fold_update = True    # evaluate_actions under autograd on the GPU uses trunk_folded()
         self.apply(_weights_init)  # mpnn.py:84
         diag = torch.zeros(num_agents, num_agents)
         diag.fill_diagonal_(-math.inf)
@@ -205,11 +260,42 @@ class MPNN(nn.Module):
             return h, attn, opp_attn
         return h
 
+    # ---- the same trunk with three pairs of consecutive linear maps multiplied out ------------------------
+    def folded_weights(self):
+        """A_o = norm W_key W_query^T, B_o = W_val W_out (opponent attention); A_m = norm W_query W_key^T and
+        the two halves of the update layer, the second with W_val W_out folded in (see mpnn_pack.py).  Built
+        from the parameters inside the autograd graph: gradients reach the original tensors."""
+        a, m, hd = self.oppAttn, self.messages, self.h_dim
+        uw = self.update[0].weight
+        return (a.norm_factor * (a.W_key[0] @ a.W_query[0].t()), a.W_val[0] @ a.W_out[0],
+                m.norm_factor * (m.W_query[0] @ m.W_key[0].t()), uw[:, :hd].t(),
+                (m.W_val[0] @ m.W_out[0]) @ uw[:, hd:].t())
+
+    def trunk_folded(self, own, opp):
+        """own (B, n, 6), opp (B, m, 6) -> h (B, n, h_dim): the training forward of the PPO update.  Per round
+        one projection GEMM, the agents-of-one-env attention as ONE op (attend_mix: csrc/fa_attend.hip on
+        the GPU) and the update layer as two accumulated GEMMs -- a third of the launches and none of the
+        (B, n, n, h) broadcast temporaries of trunk().  Same function of the same parameters; float32
+        rounding differs at the 1e-6 level."""
+        B, n, m = own.shape[0], own.shape[1], opp.shape[1]
+        A_o, B_o, A_m, W7a, W7b = self.folded_weights()
+        h1 = torch.relu(_linear(own.reshape(B * n, -1), self.encoder[0]))
+        ho = torch.relu(_linear(opp.reshape(B * m, -1), self.oppEncoder[0]))
+        mix_o = attend_mix(_mm(h1, A_o), ho.view(B, m, -1), n, False)
+        h = torch.cat((h1, _mm(mix_o, B_o)), dim=1)
+        bu = self.update[0].bias
+        for _ in range(self.K):
+            mix = attend_mix(_mm(h, A_m), h.view(B, n, -1), n, True)
+            h = torch.relu(_mm(h, W7a) + _mm(mix, W7b) + bu)
+        return h.view(B, n, -1)
+
     def _value(self, h):
         return _linear(torch.relu(_linear(h, self.value_head[0])), self.value_head[2])
 
     def logits_value(self, own, opp):
-        h = self.trunk(own, opp)
+        # under autograd on the GPU (the PPO update): the folded trunk; rollouts / CPU: the reference-shaped one
+        fold = self.fold_update and own.is_cuda and torch.is_grad_enabled()
+        h = self.trunk_folded(own, opp) if fold else self.trunk(own, opp)
         return _linear(torch.relu(_linear(h, self.policy_head[0])), self.dist.linear), self._value(h)
 
     # ---- env-major API used by the batched rollout ---------------------------------------

@@ -272,6 +272,19 @@ int fa_collect_act(fa_env *env, int32_t step, const fa_policy_io *io, void *stre
 /* number of floats of one team's packed weight buffer */
 int64_t fa_policy_weight_floats(void);
 
+/* ---- PPO update: the attention between the agents of one env, forward and backward ---------------
+ * (reference mpnn.py:250-332 MultiHeadAttention / :372-443 MultiHeadOppAttention, one head, inside
+ * evaluate_actions as JointPPO.update calls it, ppo.py:146-147).  With g = h (norm W_query W_key^T) already
+ * projected by a GEMM:  s_ij = g_i . k_j over the env's nk key rows (j == i excluded when skip_self),
+ * a_i = softmax_j s_ij, out_i = sum_j a_ij k_j  (W_val W_out are folded into the next GEMM).
+ * g, out, dout, dg: (B*n, width) rows env-major; keys, dkeys: (B, nk, width); attn: (B*n, nk), written by
+ * the forward and read by the backward; width 64 or 128; n, nk <= 8.  Device pointers on the calling
+ * thread's current device; stream ordered.  The caller adds dkeys to the key tensor's gradient. */
+int fa_attend_forward(const float *g, const float *keys, float *out, float *attn, int32_t B, int32_t n, int32_t nk,
+                      int32_t width, int32_t skip_self, void *stream);
+int fa_attend_backward(const float *g, const float *keys, const float *attn, const float *dout, float *dg,
+                       float *dkeys, int32_t B, int32_t n, int32_t nk, int32_t width, int32_t skip_self, void *stream);
+
 /* ---- state access (synchronous; tests / checkpoint) ------------------------------ */
 int fa_get_state(fa_env *env, const fa_state_host *out);
 int fa_set_state(fa_env *env, const fa_state_host *in); /* pos/vel/ang/prev_dist/alive/time_step/num_hit/

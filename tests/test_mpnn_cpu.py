@@ -175,3 +175,29 @@ def test_packed_weights_reproduce_the_module(n, m):
     mp_.pack_policy(pol, out=flat)                  # in-place refresh keeps the storage
     with pytest.raises(ValueError):
         mp_.pack_policy(MPNN(num_agents=3, num_opp_agents=3, hidden_dim=32, num_actions=8))
+
+
+@pytest.mark.parametrize("n,m", [(3, 3), (5, 5), (1, 2), (2, 1)])
+def test_folded_training_trunk_equals_reference_shaped_trunk(n, m):
+    """MPNN.trunk_folded (the PPO update's forward: folded linear maps + attend_mix) == MPNN.trunk: outputs and
+    parameter gradients (CPU: attend_mix is its plain-torch statement here)."""
+    from emergent_multiagent_strategies_amd.mpnn import MPNN
+    torch.manual_seed(5 * n + m)
+    pol = MPNN(num_agents=n, num_opp_agents=m, num_actions=8)
+    for p in pol.parameters():
+        if p.dim() == 1:
+            p.data.uniform_(-0.3, 0.3)
+    own, opp = torch.randn(40, n, 6), torch.randn(40, m, 6)
+    w = torch.randn(40, n, 128)
+    grads = []
+    for fn in (pol.trunk, pol.trunk_folded):
+        pol.zero_grad()
+        h = fn(own, opp)
+        (h * w).sum().backward()
+        grads.append((h.detach().clone(), {k: p.grad.clone() for k, p in pol.named_parameters() if p.grad is not None}))
+    assert (grads[0][0] - grads[1][0]).abs().max() < 2e-5
+    # (a team of one: the reference-shaped trunk never touches messages.W_val / W_out -> no gradient at all;
+    #  the folded one multiplies a zero message through them -> a zero gradient)
+    for k in set(grads[0][1]) | set(grads[1][1]):
+        a, b = [g[1].get(k, torch.zeros_like(dict(pol.named_parameters())[k])) for g in grads]
+        assert (a - b).abs().max() <= 1e-4 * max(1.0, float(a.abs().max())), k

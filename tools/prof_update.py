@@ -12,4 +12,4 @@ L.ppo_epoch=1; L.num_mini_batch=32
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
     L.update(train_guards_only=True)
     torch.cuda.synchronize()
-print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=18, max_name_column_width=60))
+print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=40, max_name_column_width=60))
