@@ -385,7 +385,10 @@ __device__ __forceinline__ unsigned long long fa_ballot(bool p) { return __built
 #define FA_M_LE_D(a, b) __builtin_amdgcn_fcmp((double)(a), (double)(b), 5)        /* FCMP_OLE */
 __device__ __forceinline__ bool fa_lanes(unsigned long long m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
 #define FA_WG_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
-template <int TG, int TA, bool RESET_ONLY, bool COLLECT, int NW>
+// CHOICE: the ensemble path's np.random.choice after every reset (fa_set_reset_choice) is compiled in.  A
+// template parameter, not a run-time test: the draw loop's loads and stores inside the reset block cost the
+// ordinary build 13 % at large E even when never executed.
+template <int TG, int TA, bool RESET_ONLY, bool COLLECT, int NW, bool CHOICE>
 __global__ __launch_bounds__(NW * FA_WAVE) void fa_step_kernel(FaStepArgs a) {
     constexpr bool TWO = NW >= 2;    // wave 1: contact forces (+ walls when NW == 2)
     constexpr bool THREE = NW >= 3;  // wave 2: wall forces
@@ -796,7 +799,7 @@ __global__ __launch_bounds__(NW * FA_WAVE) void fa_step_kernel(FaStepArgs a) {
             // ---- ensemble path: master.sample_attacker() after every env.reset() -- np.random.choice(k)
             // on the SAME stream (learner.py:119-121, train_fortattack_v2.py:29-35,104-111; quirk Q14).
             // Legacy RandomState.choice -> randint(0, k): genrand_int32() & mask until <= k - 1.
-            if (a.choice_k > 0) {
+            if constexpr (CHOICE) {
                 int extra = 0; // MT words the env's choice consumed
                 if (do_reset && i == 0) {
                     const uint32_t rng = (uint32_t)(a.choice_k - 1);
@@ -1515,9 +1518,15 @@ static hipError_t launch_step_t(const FaStepArgs &a, hipStream_t st) {
     // pipelined kernel; short launches (its prologue draws two resets ahead and evaluates three
     // sin/cos) and everything else use fa_step_kernel with 3 / 2 / 1 waves by grid size.
     const int nw = step_variant(a.G, a.A, a.E, a.nsteps, RESET_ONLY, a.step_kernel, a.choice_k > 0);
-#define FA_LAUNCH(TG_, TA_, NW_) \
-    hipLaunchKernelGGL((fa_step_kernel<TG_, TA_, RESET_ONLY, COLLECT, RESET_ONLY ? 1 : NW_>), dim3(grid), \
-                       dim3((RESET_ONLY ? 1 : NW_) * FA_WAVE), 0, st, a)
+#define FA_LAUNCH(TG_, TA_, NW_)                                                                                      \
+    do {                                                                                                              \
+        if (a.choice_k > 0)                                                                                           \
+            hipLaunchKernelGGL((fa_step_kernel<TG_, TA_, RESET_ONLY, COLLECT, RESET_ONLY ? 1 : NW_, true>), dim3(grid), \
+                               dim3((RESET_ONLY ? 1 : NW_) * FA_WAVE), 0, st, a);                                      \
+        else                                                                                                          \
+            hipLaunchKernelGGL((fa_step_kernel<TG_, TA_, RESET_ONLY, COLLECT, RESET_ONLY ? 1 : NW_, false>), dim3(grid), \
+                               dim3((RESET_ONLY ? 1 : NW_) * FA_WAVE), 0, st, a);                                      \
+    } while (0)
 #define FA_LAUNCH_PIPE(TG_, TA_, NPW_, MINW_) \
     hipLaunchKernelGGL((fa_step_pipe_kernel<TG_, TA_, COLLECT, NPW_, MINW_>), dim3(grid), dim3((NPW_ + 2) * FA_WAVE), 0, st, a)
     if (a.G == 3 && a.A == 3) {
