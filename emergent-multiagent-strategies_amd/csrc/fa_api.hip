@@ -246,9 +246,11 @@ int fa_create(const fa_config *cfg, fa_env **out) {
     const size_t o_adv = carve((size_t)env->adv_blocks * FA_MAX_AGENTS * 2 * sizeof(double));
     const size_t o_advs = carve((size_t)FA_MAX_AGENTS * 4 * sizeof(double));
     const bool fused_ok = cfg->num_guards <= FA_POLICY_MAX_TEAM && cfg->num_attackers <= FA_POLICY_MAX_TEAM;
-    const int tile_envs = fused_ok ? fa_policy_tile_envs(cfg->num_guards, cfg->num_attackers) : 1;
+    // sized for the smallest tile the policy kernel may choose (64 rows), slots counted at the largest (96)
+    const int n_max = cfg->num_guards > cfg->num_attackers ? cfg->num_guards : cfg->num_attackers;
+    const int tile_envs = fused_ok ? 64 / n_max : 1;
     env->grp_tiles_max = fused_ok ? (cfg->num_envs + tile_envs - 1) / tile_envs + FA_POLICY_MAX_POOL : 0;
-    const size_t o_gel = carve((size_t)env->grp_tiles_max * tile_envs * sizeof(int32_t));
+    const size_t o_gel = carve((size_t)env->grp_tiles_max * (FA_POLICY_ROWS / n_max + 1) * sizeof(int32_t));
     const size_t o_gts = carve((size_t)env->grp_tiles_max * sizeof(int32_t));
     env->slab_bytes = off;
     hipError_t he = hipMalloc(&env->slab, env->slab_bytes);

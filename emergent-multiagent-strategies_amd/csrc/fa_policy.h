@@ -50,4 +50,4 @@ hipError_t fa_launch_policy(const FaPolicyArgs &a, hipStream_t st);
 // envs -> tiles of equal strategy: env_list / tile_strategy for a launch with `pool`
 hipError_t fa_launch_group_envs(const int32_t *env_strategy, int E, int pool_size, int G, int A, int32_t *env_list,
                                 int32_t *tile_strategy, int tiles_max, hipStream_t st);
-int fa_policy_tile_envs(int G, int A);
+int fa_policy_tile_envs(int E, int G, int A);

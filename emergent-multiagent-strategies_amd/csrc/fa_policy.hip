@@ -41,7 +41,6 @@
 #include "fa_policy.h"
 
 namespace {
-constexpr int PR = FA_POLICY_ROWS; // rows (env, agent) per tile
 constexpr int LDA = 132;           // padded LDS row stride in floats (128 + 4)
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -184,7 +183,12 @@ __device__ __forceinline__ void attend_row(const float *grow, const float *key0,
     for (int c = 0; c < C; c += 4) *reinterpret_cast<float4 *>(orow + q * C + c) = *reinterpret_cast<const float4 *>(ov + c);
 }
 
-__global__ __launch_bounds__(256, 1) void fa_policy_kernel(FaPolicyArgs a) {
+// NRB = 32-row blocks per tile: 3 (96 rows, one workgroup per CU: the weights in registers are reused three
+// times) or 2 (64 rows, 75 KB of LDS: two workgroups per CU, whose phases interleave -- one's MFMA chains
+// run under the other's stores / attention / barriers)
+template <int NRB>
+__global__ __launch_bounds__(256, NRB == 2 ? 2 : 1) void fa_policy_kernel(FaPolicyArgs a) {
+    constexpr int PR = 32 * NRB; // rows (env, agent) per tile
     __shared__ __attribute__((aligned(16))) float sH[PR * LDA]; // own hidden state h (128 wide)
     __shared__ __attribute__((aligned(16))) float sG[PR * LDA]; // g / hmix; opponent stage scratch
     __shared__ float sX[PR * 2 * FA_OBS_DIM];                    // observations of the tile's envs (all agents)
@@ -267,17 +271,18 @@ __global__ __launch_bounds__(256, 1) void fa_policy_kernel(FaPolicyArgs a) {
     // 64 output columns = 2 column blocks: waves 0,1 take row blocks 0,1; waves 2,3 row block 2
     {
         const int cb = wave & 1;
-        if (wave < 2) {
+        if (NRB == 3 && wave < 2) {
             f32x16 acc[2] = {};
             gemm_cb<64, 2>(sH + li * LDA + hh * 32, wp_ao, acc, lane, hd_o);
             prefetch_b<64>(wp_bo, lane, hd_o);
             store_acc<false>(sG + 64 + cb * 32, 0, acc[0], 0.0f, lane);
             store_acc<false>(sG + 64 + cb * 32, 1, acc[1], 0.0f, lane);
-        } else {
+        } else { // the last row block (NRB == 3), or row block wave >> 1 (NRB == 2: one block per wave pair)
+            const int rb = NRB == 3 ? 2 : (wave >> 1);
             f32x16 acc[1] = {};
-            gemm_cb<64, 1>(sH + (64 + li) * LDA + hh * 32, wp_ao, acc, lane, hd_o);
+            gemm_cb<64, 1>(sH + (rb * 32 + li) * LDA + hh * 32, wp_ao, acc, lane, hd_o);
             prefetch_b<64>(wp_bo, lane, hd_o);
-            store_acc<false>(sG + 64 + cb * 32, 2, acc[0], 0.0f, lane);
+            store_acc<false>(sG + 64 + cb * 32, rb, acc[0], 0.0f, lane);
         }
     }
     __syncthreads();
@@ -294,17 +299,18 @@ __global__ __launch_bounds__(256, 1) void fa_policy_kernel(FaPolicyArgs a) {
     BHead<128> hd_m;
     {
         const int cb = wave & 1;
-        if (wave < 2) {
+        if (NRB == 3 && wave < 2) {
             f32x16 acc[2] = {};
             gemm_cb<64, 2>(sG + li * LDA + 64 + hh * 32, wp_bo, acc, lane, hd_o);
             prefetch_b<128>(wp_am, lane, hd_m);
             store_acc<false>(sH + 64 + cb * 32, 0, acc[0], 0.0f, lane);
             store_acc<false>(sH + 64 + cb * 32, 1, acc[1], 0.0f, lane);
         } else {
+            const int rb = NRB == 3 ? 2 : (wave >> 1);
             f32x16 acc[1] = {};
-            gemm_cb<64, 1>(sG + (64 + li) * LDA + 64 + hh * 32, wp_bo, acc, lane, hd_o);
+            gemm_cb<64, 1>(sG + (rb * 32 + li) * LDA + 64 + hh * 32, wp_bo, acc, lane, hd_o);
             prefetch_b<128>(wp_am, lane, hd_m);
-            store_acc<false>(sH + 64 + cb * 32, 2, acc[0], 0.0f, lane);
+            store_acc<false>(sH + 64 + cb * 32, rb, acc[0], 0.0f, lane);
         }
     }
     __syncthreads();
@@ -313,11 +319,11 @@ __global__ __launch_bounds__(256, 1) void fa_policy_kernel(FaPolicyArgs a) {
     BHead<256> hd_u;
     for (int round = 0; round < 3; ++round) {
         {   // g = h A -> sG (wave = column block)
-            f32x16 acc[3] = {};
-            gemm_cb<128, 3>(sH + li * LDA + hh * 64, wp_am, acc, lane, hd_m);
+            f32x16 acc[NRB] = {};
+            gemm_cb<128, NRB>(sH + li * LDA + hh * 64, wp_am, acc, lane, hd_m);
             prefetch_b<256>(wp_w7, lane, hd_u);
 #pragma unroll
-            for (int rb = 0; rb < 3; ++rb) store_acc<false>(sG + wave * 32, rb, acc[rb], 0.0f, lane);
+            for (int rb = 0; rb < NRB; ++rb) store_acc<false>(sG + wave * 32, rb, acc[rb], 0.0f, lane);
         }
         __syncthreads();
         {   // team attention, self excluded (mpnn.py:297-298): hmix -> sG rows
@@ -329,36 +335,36 @@ __global__ __launch_bounds__(256, 1) void fa_policy_kernel(FaPolicyArgs a) {
         }
         __syncthreads();
         {   // h' = relu([h | hmix] W7 + bu): lane half 0 walks h, half 1 walks hmix
-            f32x16 acc[3] = {};
-            gemm_cb<256, 3>((hh ? sG : sH) + li * LDA, wp_w7, acc, lane, hd_u);
+            f32x16 acc[NRB] = {};
+            gemm_cb<256, NRB>((hh ? sG : sH) + li * LDA, wp_w7, acc, lane, hd_u);
             prefetch_b<128>(round < 2 ? wp_am : wp_w8p, lane, hd_m); // next: the following round's g, or the policy head
             const float bias = W[FA_POFF_BU + wave * 32 + li];
             __syncthreads(); // every wave has read the old h
 #pragma unroll
-            for (int rb = 0; rb < 3; ++rb) store_acc<true>(sH + wave * 32, rb, acc[rb], bias, lane);
+            for (int rb = 0; rb < NRB; ++rb) store_acc<true>(sH + wave * 32, rb, acc[rb], bias, lane);
         }
         __syncthreads();
     }
 
     // ---- heads: [p | v] = relu(h [Wp0 | Wv0] + b) (mpnn.py:66-72), p -> sG, v -> sH ------------------------
     {
-        f32x16 accp[3] = {}, accv[3] = {};
+        f32x16 accp[NRB] = {}, accv[NRB] = {};
         BHead<128> hd_v;
         prefetch_b<128>(wp_w8v, lane, hd_v);
-        gemm_cb<128, 3>(sH + li * LDA + hh * 64, wp_w8p, accp, lane, hd_m);
-        gemm_cb<128, 3>(sH + li * LDA + hh * 64, wp_w8v, accv, lane, hd_v);
-        if (wave < 3) prefetch_b<256>(Wq + FA_POFF_W9 / 4, lane, hd_u);
+        gemm_cb<128, NRB>(sH + li * LDA + hh * 64, wp_w8p, accp, lane, hd_m);
+        gemm_cb<128, NRB>(sH + li * LDA + hh * 64, wp_w8v, accv, lane, hd_v);
+        if (wave < NRB) prefetch_b<256>(Wq + FA_POFF_W9 / 4, lane, hd_u);
         const float bp = W[FA_POFF_B8 + wave * 32 + li], bv = W[FA_POFF_B8 + 128 + wave * 32 + li];
         __syncthreads(); // every wave has read h
 #pragma unroll
-        for (int rb = 0; rb < 3; ++rb) {
+        for (int rb = 0; rb < NRB; ++rb) {
             store_acc<true>(sG + wave * 32, rb, accp[rb], bp, lane);
             store_acc<true>(sH + wave * 32, rb, accv[rb], bv, lane);
         }
     }
     __syncthreads();
     // logits (8) | value (1) = [p | v] W9 + b9, W9 block diagonal in a 32-column block: wave = row block
-    if (wave < 3) {
+    if (wave < NRB) {
         f32x16 acc[1] = {};
         gemm_cb<256, 1>((hh ? sH : sG) + (wave * 32 + li) * LDA, Wq + FA_POFF_W9 / 4, acc, lane, hd_u);
         if (li < 16) {
@@ -450,18 +456,28 @@ __global__ __launch_bounds__(1024) void fa_group_envs_kernel(const int32_t *__re
 }
 } // namespace
 
-int fa_policy_tile_envs(int G, int A) { return PR / (G > A ? G : A); }
+// 96-row tiles unless they would leave a quarter of the CUs without a workgroup (small batches): then 64-row
+// tiles spread the same rows over more CUs.  (At 4096 envs the 96-row tile -- exactly one workgroup per CU at
+// 3v3 -- is the faster one: 0.127 vs 0.140 ms per env-step; two 64-row workgroups per CU did not overlap
+// their phases enough to pay for reusing the weights twice instead of three times.)
+static int policy_rows(int E, int G, int A) {
+    const int n_max = G > A ? G : A, et96 = FA_POLICY_ROWS / n_max;
+    const int wgs96 = 2 * ((E + et96 - 1) / et96);
+    return wgs96 < 192 ? 64 : FA_POLICY_ROWS;
+}
+int fa_policy_tile_envs(int E, int G, int A) { return policy_rows(E, G, A) / (G > A ? G : A); }
 
 hipError_t fa_launch_group_envs(const int32_t *env_strategy, int E, int pool_size, int G, int A, int32_t *env_list,
                                 int32_t *tile_strategy, int tiles_max, hipStream_t st) {
-    hipLaunchKernelGGL(fa_group_envs_kernel, dim3(1), dim3(1024), 0, st, env_strategy, E, pool_size, fa_policy_tile_envs(G, A),
+    hipLaunchKernelGGL(fa_group_envs_kernel, dim3(1), dim3(1024), 0, st, env_strategy, E, pool_size, fa_policy_tile_envs(E, G, A),
                        tiles_max, env_list, tile_strategy);
     return hipGetLastError();
 }
 
 hipError_t fa_launch_policy(const FaPolicyArgs &a, hipStream_t st) {
-    const int ET = fa_policy_tile_envs(a.G, a.A);
+    const int ET = fa_policy_tile_envs(a.E, a.G, a.A);
     const int tiles = a.env_list ? a.tiles : (a.E + ET - 1) / ET;
-    hipLaunchKernelGGL(fa_policy_kernel, dim3(tiles, 2), dim3(256), 0, st, a);
+    if (policy_rows(a.E, a.G, a.A) == 64) hipLaunchKernelGGL(fa_policy_kernel<2>, dim3(tiles, 2), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(fa_policy_kernel<3>, dim3(tiles, 2), dim3(256), 0, st, a);
     return hipGetLastError();
 }
