@@ -47,6 +47,14 @@ class PolicyIO(C.Structure):
                 ("value_only", C.c_int32), ("attacker_pool", c_p), ("pool_size", C.c_int32), ("env_strategy", c_p)]
 
 
+class PPOGradIO(C.Structure):
+    _fields_ = [("obs", c_p), ("action", c_p), ("value_pred", c_p), ("ret", c_p), ("old_log_prob", c_p), ("adv", c_p),
+                ("weights", c_p), ("weights_t", c_p), ("scale", c_p), ("slabs", c_p), ("hsave", c_p), ("out", c_p),
+                ("B", C.c_int32), ("num_guards", C.c_int32), ("num_attackers", C.c_int32), ("team", C.c_int32),
+                ("clip_param", C.c_float), ("value_loss_coef", C.c_float), ("entropy_coef", C.c_float),
+                ("clipped_value_loss", C.c_int32)]
+
+
 class StateHost(C.Structure):
     _fields_ = [(n, c_p) for n in (
         "pos_x", "pos_y", "vel_x", "vel_y", "ang", "prev_dist", "alive", "time_step", "num_hit",
@@ -85,6 +93,10 @@ EXPORTS = {
     "fa_policy_weight_floats": (C.c_int64, []),
     "fa_attend_forward": (C.c_int, [c_p, c_p, c_p, c_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, c_p]),
     "fa_attend_backward": (C.c_int, [c_p, c_p, c_p, c_p, c_p, c_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, c_p]),
+    "fa_ppo_grad": (C.c_int, [C.POINTER(PPOGradIO), c_p]),
+    "fa_ppo_grad_floats": (C.c_int64, []),
+    "fa_ppo_grad_scratch": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "fa_policy_weight_t_floats": (C.c_int64, []),
     "fa_get_state": (C.c_int, [c_p, C.POINTER(StateHost)]),
     "fa_set_state": (C.c_int, [c_p, C.POINTER(StateHost)]),
     "fa_selftest_math": (C.c_int, [c_p, C.c_uint64, C.c_uint64, c_p]),

@@ -8,6 +8,7 @@
 
 #include "fa_device.h"
 #include "fa_policy.h"
+#include "fa_train.h"
 #include "fortattack.h"
 
 hipError_t fa_launch_step(const FaStepArgs &a, hipStream_t st);
@@ -589,6 +590,42 @@ int fa_collect_act(fa_env *env, int32_t step, const fa_policy_io *io, void *stre
 }
 
 int64_t fa_policy_weight_floats(void) { return FA_POLICY_WEIGHT_FLOATS; }
+
+int64_t fa_ppo_grad_floats(void) { return FA_SLAB_FLOATS; }
+int64_t fa_policy_weight_t_floats(void) { return FA_TRANS_FLOATS; }
+
+int fa_ppo_grad_scratch(int32_t B, int32_t G, int32_t A, int64_t *slab_floats, int64_t *hsave_floats) {
+    if (B < 1 || G < 1 || A < 1 || G > FA_POLICY_MAX_TEAM || A > FA_POLICY_MAX_TEAM)
+        return fail(FA_ERR_INVALID, "fa_ppo_grad_scratch: need B >= 1 and teams of 1..8");
+    const int et = fa_train_tile_envs(G, A);
+    const int64_t tiles = (B + et - 1) / et;
+    if (slab_floats) *slab_floats = tiles * FA_SLAB_FLOATS;
+    if (hsave_floats) *hsave_floats = tiles * FA_TR_SAVE_FLOATS;
+    return FA_OK;
+}
+
+int fa_ppo_grad(const fa_ppo_grad_io *io, void *stream) {
+    if (!io) return fail(FA_ERR_INVALID, "fa_ppo_grad: null io");
+    if (!io->obs || !io->action || !io->value_pred || !io->ret || !io->old_log_prob || !io->adv || !io->weights ||
+        !io->weights_t || !io->scale || !io->slabs || !io->hsave || !io->out)
+        return fail(FA_ERR_INVALID, "fa_ppo_grad: every pointer is required");
+    if (io->B < 1 || io->num_guards < 1 || io->num_attackers < 1 || io->num_guards > FA_POLICY_MAX_TEAM ||
+        io->num_attackers > FA_POLICY_MAX_TEAM || (io->team != 0 && io->team != 1))
+        return fail(FA_ERR_INVALID, "fa_ppo_grad: need B >= 1, teams of 1..8, team 0 or 1");
+    FaTrainArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.obs = io->obs; a.action = io->action; a.value_pred = io->value_pred; a.ret = io->ret;
+    a.old_logp = io->old_log_prob; a.adv = io->adv; a.w = io->weights; a.wt = io->weights_t;
+    a.slabs = io->slabs; a.hsave = io->hsave; a.scale = io->scale;
+    a.B = io->B; a.G = io->num_guards; a.A = io->num_attackers; a.team = io->team;
+    a.clip = io->clip_param; a.c_value = io->value_loss_coef; a.c_entropy = io->entropy_coef;
+    a.clipped_value_loss = io->clipped_value_loss;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    FA_HIP(fa_launch_train(a, s));
+    const int et = fa_train_tile_envs(a.G, a.A);
+    FA_HIP(fa_launch_train_reduce(io->slabs, (a.B + et - 1) / et, io->out, s));
+    return FA_OK;
+}
 
 static int attend_check(const char *who, int B, int n, int nk, int width) {
     if (B < 1 || n < 1 || nk < 1 || n > FA_POLICY_MAX_TEAM || nk > FA_POLICY_MAX_TEAM)

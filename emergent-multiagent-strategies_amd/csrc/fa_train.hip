@@ -1,0 +1,627 @@
+// fa_train.hip -- one team's PPO minibatch in ONE launch: the MPNN forward (as fa_policy.hip, folded algebra),
+// the alive-masked clipped PPO losses of JointPPO.update (reference rlcore/algo/ppo.py:146-187) and the COMPLETE
+// backward pass down to the gradients of every kernel-facing matrix, for a tile of 64 (env, agent) rows per
+// workgroup held in four LDS buffers.
+//
+// Why: as PyTorch autograd the optimizer step is ~160 launches and 2.65 ms at 16 384 x 3 samples, of which the
+// GEMMs (hipBLASLt, 45 TFLOP/s on (49 152 x 128) x (128 x 128); the weight gradients through a split-K bmm +
+// sum) are less than half; the rest is bias / relu / add / reduction kernels over (49 152 x 128) tensors.  Here
+// the activations of a tile never leave the CU between layers; per layer the backward is two MFMA GEMMs
+// (dX = dY W^T with the transposed weights streamed from L2 like the forward's; dW = X^T dY with BOTH operands
+// read from LDS) and the elementwise work is folded into the accumulator stores.
+//
+// Weight gradients: a tile writes its partial dW set to its own slab (plain row-major, 390 KB); a second small
+// kernel sums the slabs in tile order -- no atomics, bitwise reproducible.  dA_m, dW7 (shared by the three
+// message-passing rounds) are accumulated in registers across the rounds.  What the host does with the result
+// (chain rule from the folded matrices to the module's parameters, loss normalisation by the alive-mask mean,
+// clip, Adam) is a handful of small torch ops: see learner.FusedPPOStep.
+//
+// Saved for the backward: the hidden state after the opponent stage and after rounds 1 and 2 (global scratch,
+// 96 KB per tile), all attention weights (LDS); g = h A, the attention mixes and the opponents' encodings are
+// recomputed (cheaper than a round trip).
+//
+// Buffers (64 x 132 floats each): B0 = h (forward) / h_in of the round being differentiated; B1 = g, hmix, P;
+// B2 = ho, V, recomputed g; B3 = the running dL/dh.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "fa_train.h"
+#include "fa_mfma.h"
+
+namespace {
+constexpr int TR = FA_TR_ROWS;
+constexpr int SOW = 32; // row stride of the head-output buffer sO (9 used: 8 logits + value)
+
+// acc (32 x 32) += X[rows][32 cols at X]^T * DY[rows][32 cols at DY] over the tile's 64 rows: both operands
+// from LDS, one float each per MFMA (A[i][kk] = X[row kk][i], B[kk][j] = DY[row kk][j]; lane half hh walks
+// rows hh*32 .. hh*32+31)
+__device__ __forceinline__ void gemm_tn(const float *X, int ldx, const float *DY, int ldy, f32x16 &acc, int lane) {
+    const int li = lane & 31, hh = lane >> 5;
+    const float *xp = X + (hh * 32) * ldx + li, *yp = DY + (hh * 32) * ldy + li;
+#pragma unroll
+    for (int t = 0; t < 32; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xp[t * ldx], yp[t * ldy], acc, 0, 0, 0);
+}
+
+// accumulator tile -> plain row-major global matrix with row length C
+__device__ __forceinline__ void store_tile_global(float *dst, int C, const f32x16 &acc, int lane) {
+    const int col = lane & 31, hh = lane >> 5;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) dst[((reg & 3) + 8 * (reg >> 2) + 4 * hh) * C + col] = acc[reg];
+}
+
+// dst += acc  /  dst = (dst > 0 ? acc : 0)   on an LDS tile (the lane that stores an element also owns its old value)
+__device__ __forceinline__ void store_acc_add(float *dst, int rb, const f32x16 &acc, int lane) {
+    const int col = lane & 31, hh = lane >> 5;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        float *p = dst + (rb * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * hh) * LDA + col;
+        *p += acc[reg];
+    }
+}
+__device__ __forceinline__ void store_acc_relu_mask(float *dst, int rb, const f32x16 &acc, int lane) {
+    const int col = lane & 31, hh = lane >> 5;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        float *p = dst + (rb * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * hh) * LDA + col;
+        *p = *p > 0.0f ? acc[reg] : 0.0f;
+    }
+}
+
+// out[r] = sum_j attn[j] key[j]  (recomputing a mix from saved attention weights), 16 lanes per row
+template <int W>
+__device__ __forceinline__ void mix_row(const float *attn_row, const float *key0, int nk, float *orow, int q) {
+    constexpr int C = W / 16;
+    float ov[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) ov[c] = 0.0f;
+#pragma unroll
+    for (int j = 0; j < FA_POLICY_MAX_TEAM; ++j)
+        if (j < nk) {
+            const float a = attn_row[j];
+#pragma unroll
+            for (int c = 0; c < C; c += 4) {
+                const float4 kv = *reinterpret_cast<const float4 *>(key0 + j * LDA + q * C + c);
+                ov[c] = fmaf(a, kv.x, ov[c]); ov[c + 1] = fmaf(a, kv.y, ov[c + 1]);
+                ov[c + 2] = fmaf(a, kv.z, ov[c + 2]); ov[c + 3] = fmaf(a, kv.w, ov[c + 3]);
+            }
+        }
+#pragma unroll
+    for (int c = 0; c < C; c += 4) *reinterpret_cast<float4 *>(orow + q * C + c) = *reinterpret_cast<const float4 *>(ov + c);
+}
+
+// Backward of the attention of ONE env by a 16-lane sub-group (cf. fa_attend.hip): rows r0 .. r0+n-1 of
+// dout / g (g is overwritten by dg), the env's nk key rows at key0, their gradient ADDED into dkey0 rows
+// (ADD) or written (!ADD).  W floats per row.
+template <int W, bool ADD>
+__device__ __forceinline__ void attend_env_bwd(const float *dout0, float *g0, const float *key0, float *dkey0, const float *attn0,
+                                               int n, int nk, int q) {
+    constexpr int C = W / 16;
+    constexpr int MT = FA_POLICY_MAX_TEAM;
+    float kv[MT][C], dk[MT][C];
+#pragma unroll
+    for (int j = 0; j < MT; ++j)
+#pragma unroll
+        for (int c = 0; c < C; ++c) { kv[j][c] = 0.0f; dk[j][c] = 0.0f; }
+#pragma unroll
+    for (int j = 0; j < MT; ++j)
+        if (j < nk) {
+#pragma unroll
+            for (int c = 0; c < C; c += 4)
+                *reinterpret_cast<float4 *>(&kv[j][c]) = *reinterpret_cast<const float4 *>(key0 + j * LDA + q * C + c);
+        }
+    for (int i = 0; i < n; ++i) {
+        float gv[C], dov[C];
+#pragma unroll
+        for (int c = 0; c < C; c += 4) {
+            *reinterpret_cast<float4 *>(gv + c) = *reinterpret_cast<const float4 *>(g0 + i * LDA + q * C + c);
+            *reinterpret_cast<float4 *>(dov + c) = *reinterpret_cast<const float4 *>(dout0 + i * LDA + q * C + c);
+        }
+        float a[MT], da[MT], dot = 0.0f;
+#pragma unroll
+        for (int j = 0; j < MT; ++j) {
+            a[j] = 0.0f;
+            da[j] = 0.0f;
+            if (j < nk) {
+                a[j] = attn0[i * 8 + j];
+                float d = 0.0f;
+#pragma unroll
+                for (int c = 0; c < C; ++c) d = fmaf(dov[c], kv[j][c], d);
+                da[j] = group16_sum(d);
+                dot = fmaf(a[j], da[j], dot);
+            }
+        }
+        float dgv[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) dgv[c] = 0.0f;
+#pragma unroll
+        for (int j = 0; j < MT; ++j)
+            if (j < nk) {
+                const float ds = a[j] * (da[j] - dot);
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    dgv[c] = fmaf(ds, kv[j][c], dgv[c]);
+                    dk[j][c] = fmaf(a[j], dov[c], fmaf(ds, gv[c], dk[j][c]));
+                }
+            }
+#pragma unroll
+        for (int c = 0; c < C; c += 4) *reinterpret_cast<float4 *>(g0 + i * LDA + q * C + c) = *reinterpret_cast<const float4 *>(dgv + c);
+    }
+#pragma unroll
+    for (int j = 0; j < MT; ++j)
+        if (j < nk) {
+#pragma unroll
+            for (int c = 0; c < C; c += 4) {
+                float4 *p = reinterpret_cast<float4 *>(dkey0 + j * LDA + q * C + c);
+                float4 v = *reinterpret_cast<const float4 *>(&dk[j][c]);
+                if (ADD) { const float4 o = *p; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+                *p = v;
+            }
+        }
+}
+
+__global__ __launch_bounds__(256, 1) void fa_train_kernel(FaTrainArgs a) {
+    __shared__ __attribute__((aligned(16))) float B0[TR * LDA], B1[TR * LDA], B2[TR * LDA], B3[TR * LDA];
+    __shared__ float sX[TR * 2 * FA_OBS_DIM];
+    __shared__ __attribute__((aligned(16))) float sO[TR * SOW];
+    __shared__ float sAttn[4][TR * 8]; // [opponent stage, round 0, 1, 2][row][key]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, hh = lane >> 5, q16 = lane & 15;
+    const int N = a.G + a.A;
+    const int n = a.team == 0 ? a.G : a.A, m = N - n;
+    const int own0 = a.team == 0 ? 0 : a.G, opp0 = a.team == 0 ? a.G : 0;
+    const int ET = TR / (n > m ? n : m);
+    const int e0 = blockIdx.x * ET;
+    if (e0 >= a.B) return;
+    const int ne = (a.B - e0) < ET ? (a.B - e0) : ET;
+    const int RU = ET * n, RO = ET * m; // rows in use (own / opponent side); envs beyond `ne` are zero rows
+    const float *W = a.w;
+    const float4 *Wq = reinterpret_cast<const float4 *>(a.w), *Tq = reinterpret_cast<const float4 *>(a.wt);
+    float *slab = a.slabs + (size_t)blockIdx.x * FA_SLAB_FLOATS;
+    float *hsave = a.hsave + (size_t)blockIdx.x * FA_TR_SAVE_FLOATS;
+
+    auto save_tile = [&](const float *src, float *dst) { // 64 x 128 LDS -> global
+        for (int k = tid; k < TR * 32; k += 256) {
+            const int r = k >> 5, c4 = k & 31;
+            reinterpret_cast<float4 *>(dst)[k] = *reinterpret_cast<const float4 *>(src + r * LDA + c4 * 4);
+        }
+    };
+    auto load_tile = [&](float *dst, const float *src) {
+        for (int k = tid; k < TR * 32; k += 256) {
+            const int r = k >> 5, c4 = k & 31;
+            *reinterpret_cast<float4 *>(dst + r * LDA + c4 * 4) = reinterpret_cast<const float4 *>(src)[k];
+        }
+    };
+    // encoders (mpnn.py:37-41) from sX: h1 -> dst_own[:, 0:64] (own rows), ho -> dst_opp[:, 0:64] (opponent rows)
+    auto encoders = [&](float *dst_own, float *dst_opp) {
+        const int col = tid & 63, grp = tid >> 6;
+        float we[FA_OBS_DIM], wo[FA_OBS_DIM];
+#pragma unroll
+        for (int k = 0; k < FA_OBS_DIM; ++k) { we[k] = W[FA_POFF_WE + k * 64 + col]; wo[k] = W[FA_POFF_WOE + k * 64 + col]; }
+        const float be = W[FA_POFF_BE + col], bo = W[FA_POFF_BOE + col];
+        for (int r = grp; r < TR; r += 4) {
+            if (dst_own) {
+                float v = 0.0f;
+                if (r < RU) {
+                    const int el = r / n, i = r - el * n;
+                    const float *x = sX + (el * N + own0 + i) * FA_OBS_DIM;
+                    v = be;
+#pragma unroll
+                    for (int k = 0; k < FA_OBS_DIM; ++k) v = fmaf(x[k], we[k], v);
+                    v = fmaxf(v, 0.0f);
+                }
+                dst_own[r * LDA + col] = v;
+            }
+            float v = 0.0f;
+            if (r < RO) {
+                const int el = r / m, j = r - el * m;
+                const float *x = sX + (el * N + opp0 + j) * FA_OBS_DIM;
+                v = bo;
+#pragma unroll
+                for (int k = 0; k < FA_OBS_DIM; ++k) v = fmaf(x[k], wo[k], v);
+                v = fmaxf(v, 0.0f);
+            }
+            dst_opp[r * LDA + col] = v;
+        }
+    };
+    // g_o = h1 A_o -> B1[:, 64:128]  (64 output columns: column block wave & 1, row block wave >> 1)
+    auto project_opp = [&]() {
+        BHead<64> hd;
+        const float4 *wp = Wq + FA_POFF_AO / 4 + (wave & 1) * 8 * 64;
+        prefetch_b<64>(wp, lane, hd);
+        f32x16 acc[1] = {};
+        gemm_cb<64, 1>(B0 + ((wave >> 1) * 32 + li) * LDA + hh * 32, wp, acc, lane, hd);
+        store_acc<false>(B1 + 64 + (wave & 1) * 32, wave >> 1, acc[0], 0.0f, lane);
+    };
+    // g = h A_m: B0 -> dst (all 128 columns; wave = column block)
+    auto project_team = [&](float *dst) {
+        BHead<128> hd;
+        const float4 *wp = Wq + FA_POFF_AM / 4 + wave * 16 * 64;
+        prefetch_b<128>(wp, lane, hd);
+        f32x16 acc[2] = {};
+        gemm_cb<128, 2>(B0 + li * LDA + hh * 64, wp, acc, lane, hd);
+        store_acc<false>(dst + wave * 32, 0, acc[0], 0.0f, lane);
+        store_acc<false>(dst + wave * 32, 1, acc[1], 0.0f, lane);
+    };
+
+    // ================================ forward ==========================================================
+    for (int k = tid; k < ET * N * FA_OBS_DIM; k += 256)
+        sX[k] = k < ne * N * FA_OBS_DIM ? a.obs[(size_t)e0 * N * FA_OBS_DIM + k] : 0.0f;
+    __syncthreads();
+    encoders(B0, B2);
+    __syncthreads();
+    project_opp();
+    __syncthreads();
+    for (int r = wave * 4 + (lane >> 4); r < TR; r += 16) // opponent attention (mpnn.py:372-443)
+        if (r < RU) attend_row<64>(B1 + r * LDA + 64, B2 + ((r / n) * m) * LDA, m, -1, B1 + r * LDA + 64, q16, sAttn[0] + r * 8);
+    __syncthreads();
+    {   // e_opp = mix_o B_o -> B0[:, 64:128]
+        BHead<64> hd;
+        const float4 *wp = Wq + FA_POFF_BO / 4 + (wave & 1) * 8 * 64;
+        prefetch_b<64>(wp, lane, hd);
+        f32x16 acc[1] = {};
+        gemm_cb<64, 1>(B1 + ((wave >> 1) * 32 + li) * LDA + 64 + hh * 32, wp, acc, lane, hd);
+        store_acc<false>(B0 + 64 + (wave & 1) * 32, wave >> 1, acc[0], 0.0f, lane);
+    }
+    __syncthreads();
+    save_tile(B0, hsave);
+    for (int round = 0; round < 3; ++round) {
+        project_team(B1);
+        __syncthreads();
+        for (int r = wave * 4 + (lane >> 4); r < TR; r += 16) { // team attention, self excluded (mpnn.py:250-332)
+            const int el = r / n;
+            if (r < RU) attend_row<128>(B1 + r * LDA, B0 + (el * n) * LDA, n, r - el * n, B1 + r * LDA, q16, sAttn[1 + round] + r * 8);
+        }
+        __syncthreads();
+        {   // h' = relu([h | hmix] W7 + bu)
+            BHead<256> hd;
+            const float4 *wp = Wq + FA_POFF_W7 / 4 + wave * 32 * 64;
+            prefetch_b<256>(wp, lane, hd);
+            f32x16 acc[2] = {};
+            gemm_cb<256, 2>((hh ? B1 : B0) + li * LDA, wp, acc, lane, hd);
+            const float bias = W[FA_POFF_BU + wave * 32 + li];
+            __syncthreads();
+            store_acc<true>(B0 + wave * 32, 0, acc[0], bias, lane);
+            store_acc<true>(B0 + wave * 32, 1, acc[1], bias, lane);
+        }
+        __syncthreads();
+        if (round < 2) save_tile(B0, hsave + (round + 1) * TR * 128);
+    }
+    {   // heads: P = relu(h Wp0 + b) -> B1, V = relu(h Wv0 + b) -> B2
+        BHead<128> hp, hv;
+        const float4 *wpp = Wq + FA_POFF_W8 / 4 + wave * 16 * 64, *wpv = Wq + FA_POFF_W8 / 4 + (4 + wave) * 16 * 64;
+        prefetch_b<128>(wpp, lane, hp);
+        prefetch_b<128>(wpv, lane, hv);
+        f32x16 accp[2] = {}, accv[2] = {};
+        gemm_cb<128, 2>(B0 + li * LDA + hh * 64, wpp, accp, lane, hp);
+        gemm_cb<128, 2>(B0 + li * LDA + hh * 64, wpv, accv, lane, hv);
+        const float bp = W[FA_POFF_B8 + wave * 32 + li], bv = W[FA_POFF_B8 + 128 + wave * 32 + li];
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+            store_acc<true>(B1 + wave * 32, rb, accp[rb], bp, lane);
+            store_acc<true>(B2 + wave * 32, rb, accv[rb], bv, lane);
+        }
+    }
+    __syncthreads();
+    if (wave < 2) { // [logits | value] = [P | V] W9 + b9 -> sO (row block = wave)
+        BHead<256> hd;
+        prefetch_b<256>(Wq + FA_POFF_W9 / 4, lane, hd);
+        f32x16 acc[1] = {};
+        gemm_cb<256, 1>((hh ? B2 : B1) + (wave * 32 + li) * LDA, Wq + FA_POFF_W9 / 4, acc, lane, hd);
+        const float bias = W[FA_POFF_B9 + li];
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg)
+            sO[(wave * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * hh) * SOW + li] = acc[0][reg] + bias;
+    }
+    __syncthreads();
+
+    // ================================ losses (ppo.py:150-187) and dL/d[logits | value] -> sO ==============
+    if (wave == 0) {
+        const int r = lane;
+        const float inv_count = a.scale[0], unmask = a.scale[1];
+        float vl = 0.0f, al = 0.0f, en = 0.0f, mk = 0.0f;
+        float dlg[FA_NUM_ACTIONS], dval = 0.0f;
+#pragma unroll
+        for (int k = 0; k < FA_NUM_ACTIONS; ++k) dlg[k] = 0.0f;
+        if (r < ne * n) {
+            const int el = r / n, i = r - el * n;
+            const size_t o = (size_t)(e0 + el) * N + own0 + i;
+            const float *lo = sO + r * SOW;
+            mk = sX[(el * N + own0 + i) * FA_OBS_DIM]; // the alive flag (ppo.py:224)
+            float lg[FA_NUM_ACTIONS], mx = -INFINITY;
+#pragma unroll
+            for (int k = 0; k < FA_NUM_ACTIONS; ++k) { lg[k] = lo[k]; mx = fmaxf(mx, lg[k]); }
+            float se = 0.0f;
+#pragma unroll
+            for (int k = 0; k < FA_NUM_ACTIONS; ++k) se += expf(lg[k] - mx);
+            const float lse = mx + logf(se);
+            const int act = (int)a.action[o];
+            float p[FA_NUM_ACTIONS], lpk[FA_NUM_ACTIONS], ent = 0.0f, lp = 0.0f;
+#pragma unroll
+            for (int k = 0; k < FA_NUM_ACTIONS; ++k) {
+                lpk[k] = lg[k] - lse;
+                p[k] = expf(lpk[k]);
+                ent -= p[k] * lpk[k];
+                lp = (k == act) ? lpk[k] : lp;
+            }
+            const float value = lo[8], vp = a.value_pred[o], rt = a.ret[o], adv = a.adv[o];
+            const float ratio = mk * expf(lp - a.old_logp[o]);
+            const float s1 = ratio * adv, rc = fminf(fmaxf(ratio, 1.0f - a.clip), 1.0f + a.clip), s2 = rc * adv;
+            al = mk * -fminf(s1, s2);
+            // d(-min(s1, s2))/dlp: through s1 when it is the smaller (ties: both paths agree), else through the
+            // clamp, which passes the gradient only strictly inside the clip range
+            const bool in_range = ratio > 1.0f - a.clip && ratio < 1.0f + a.clip;
+            const float g_lp = mk * ((s1 <= s2) ? -adv * ratio : (in_range ? -adv * ratio : 0.0f));
+            float g_val;
+            if (a.clipped_value_loss) {
+                const float dv = value - vp, vc = vp + fminf(fmaxf(dv, -a.clip), a.clip);
+                const float l1 = (value - rt) * (value - rt), l2 = (vc - rt) * (vc - rt);
+                vl = 0.5f * fmaxf(l1, l2) * mk;
+                const bool inside = dv > -a.clip && dv < a.clip;
+                g_val = mk * (l1 >= l2 ? (value - rt) : (inside ? (vc - rt) : 0.0f));
+            } else { // the reference's scalar-MSE branch (ppo.py:178-182): every sample counts, mask or not
+                vl = 0.5f * (rt - value) * (rt - value);
+                g_val = -(rt - value) * unmask;
+            }
+            en = ent * mk;
+            dval = a.c_value * g_val * inv_count;
+#pragma unroll
+            for (int k = 0; k < FA_NUM_ACTIONS; ++k)
+                dlg[k] = (g_lp * ((k == act ? 1.0f : 0.0f) - p[k]) + a.c_entropy * mk * p[k] * (lpk[k] + ent)) * inv_count;
+        }
+        float *dst = sO + r * SOW;
+#pragma unroll
+        for (int k = 0; k < FA_NUM_ACTIONS; ++k) dst[k] = dlg[k];
+        dst[8] = dval;
+#pragma unroll
+        for (int k = 9; k < SOW; ++k) dst[k] = 0.0f;
+        for (int off = 32; off > 0; off >>= 1) {
+            vl += __shfl_down(vl, off); al += __shfl_down(al, off); en += __shfl_down(en, off); mk += __shfl_down(mk, off);
+        }
+        if (lane == 0) { slab[FA_SLAB_LOSS] = vl; slab[FA_SLAB_LOSS + 1] = al; slab[FA_SLAB_LOSS + 2] = en; slab[FA_SLAB_LOSS + 3] = mk; }
+    }
+    __syncthreads();
+
+    // ================================ backward =========================================================
+    // ---- heads --------------------------------------------------------------------------------------
+    {   // dW9 = [P | V]^T dOUT (256 x 32): 8 k-blocks, two per wave;  db9 = column sums of dOUT
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int kb = wave * 2 + t;
+            f32x16 acc = {};
+            gemm_tn((kb < 4 ? B1 : B2) + (kb & 3) * 32, LDA, sO, SOW, acc, lane);
+            store_tile_global(slab + FA_POFF_W9 + kb * 32 * 32, 32, acc, lane);
+        }
+        if (tid < 32) {
+            float sum = 0.0f;
+            for (int r = 0; r < TR; ++r) sum += sO[r * SOW + tid];
+            slab[FA_POFF_B9 + tid] = sum;
+        }
+    }
+    {   // d[P | V] = dOUT W9^T (K = 32 -> 256 columns: blocks wave, wave + 4), through the relus in place
+        BHead<32> h0, h1;
+        const float4 *wp0 = Tq + FA_TOFF_W9T / 4 + wave * 4 * 64, *wp1 = Tq + FA_TOFF_W9T / 4 + (4 + wave) * 4 * 64;
+        prefetch_b<32>(wp0, lane, h0);
+        prefetch_b<32>(wp1, lane, h1);
+        f32x16 ap[2] = {}, av[2] = {};
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) { // A = sO (row stride SOW): one 16-byte read per four MFMAs
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float4 x = *reinterpret_cast<const float4 *>(sO + (rb * 32 + li) * SOW + hh * 16 + c * 4);
+                ap[rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(x.x, h0.v[c].x, ap[rb], 0, 0, 0);
+                ap[rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(x.y, h0.v[c].y, ap[rb], 0, 0, 0);
+                ap[rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(x.z, h0.v[c].z, ap[rb], 0, 0, 0);
+                ap[rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(x.w, h0.v[c].w, ap[rb], 0, 0, 0);
+                av[rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(x.x, h1.v[c].x, av[rb], 0, 0, 0);
+                av[rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(x.y, h1.v[c].y, av[rb], 0, 0, 0);
+                av[rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(x.z, h1.v[c].z, av[rb], 0, 0, 0);
+                av[rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(x.w, h1.v[c].w, av[rb], 0, 0, 0);
+            }
+        }
+        __syncthreads(); // dW9 has read P and V
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+            store_acc_relu_mask(B1 + wave * 32, rb, ap[rb], lane);
+            store_acc_relu_mask(B2 + wave * 32, rb, av[rb], lane);
+        }
+    }
+    __syncthreads();
+    {   // dW8 = h3^T [dP | dV] (128 x 256): 32 tiles, eight per wave (column block cb, k-blocks 0..3);  db8
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int cb = wave * 2 + t;
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) {
+                f32x16 acc = {};
+                gemm_tn(B0 + kb * 32, LDA, (cb < 4 ? B1 : B2) + (cb & 3) * 32, LDA, acc, lane);
+                store_tile_global(slab + FA_POFF_W8 + kb * 32 * 256 + cb * 32, 256, acc, lane);
+            }
+        }
+        {
+            const float *src = (tid < 128 ? B1 : B2) + (tid & 127);
+            float sum = 0.0f;
+            for (int r = 0; r < TR; ++r) sum += src[r * LDA];
+            slab[FA_POFF_B8 + tid] = sum;
+        }
+    }
+    {   // dh3 = [dP | dV] W8^T (K = 256: half 0 walks dP, half 1 dV) -> B3
+        BHead<256> hd;
+        const float4 *wp = Tq + FA_TOFF_W8T / 4 + wave * 32 * 64;
+        prefetch_b<256>(wp, lane, hd);
+        f32x16 acc[2] = {};
+        gemm_cb<256, 2>((hh ? B2 : B1) + li * LDA, wp, acc, lane, hd);
+        store_acc<false>(B3 + wave * 32, 0, acc[0], 0.0f, lane);
+        store_acc<false>(B3 + wave * 32, 1, acc[1], 0.0f, lane);
+    }
+    __syncthreads();
+
+    // ---- the three rounds, last first: B0 = the round's output h, B3 = dL/d(output) ---------------------
+    f32x16 acc_w7[8], acc_am[4]; // dW7 (256 x 128: column block = wave, 8 k-blocks), dA_m (128 x 128: 4 k-blocks)
+#pragma unroll
+    for (int t = 0; t < 8; ++t) acc_w7[t] = f32x16{};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc_am[t] = f32x16{};
+    float dbu = 0.0f; // threads 0..127: their column of the update bias gradient
+    for (int round = 2; round >= 0; --round) {
+        // dZ = dL/dh_out through the relu (in place in B3); the bias gradient
+        for (int k = tid; k < TR * 128; k += 256) {
+            const int r = k >> 7, c = k & 127;
+            if (!(B0[r * LDA + c] > 0.0f)) B3[r * LDA + c] = 0.0f;
+        }
+        __syncthreads();
+        if (tid < 128) {
+            float sum = 0.0f;
+            for (int r = 0; r < TR; ++r) sum += B3[r * LDA + tid];
+            dbu += sum;
+        }
+        // h_in -> B0, g = h_in A_m -> B2 (recomputed), hmix -> B1 (recomputed from the saved weights)
+        load_tile(B0, hsave + round * TR * 128);
+        __syncthreads();
+        project_team(B2);
+        for (int r = wave * 4 + (lane >> 4); r < TR; r += 16) {
+            if (r < RU) mix_row<128>(sAttn[1 + round] + r * 8, B0 + ((r / n) * n) * LDA, n, B1 + r * LDA, q16);
+            else {
+                *reinterpret_cast<float4 *>(B1 + r * LDA + q16 * 8) = float4{0, 0, 0, 0};
+                *reinterpret_cast<float4 *>(B1 + r * LDA + q16 * 8 + 4) = float4{0, 0, 0, 0};
+            }
+        }
+        __syncthreads();
+        // dW7 += [h_in | hmix]^T dZ
+#pragma unroll
+        for (int kb = 0; kb < 8; ++kb) gemm_tn((kb < 4 ? B0 : B1) + (kb & 3) * 32, LDA, B3 + wave * 32, LDA, acc_w7[kb], lane);
+        {   // [dh_a | dhmix] = dZ W7^T (K = 128 -> 256 columns)
+            BHead<128> ha, hm;
+            const float4 *wpa = Tq + FA_TOFF_W7T / 4 + wave * 16 * 64, *wpm = Tq + FA_TOFF_W7T / 4 + (4 + wave) * 16 * 64;
+            prefetch_b<128>(wpa, lane, ha);
+            prefetch_b<128>(wpm, lane, hm);
+            f32x16 aa[2] = {}, am[2] = {};
+            gemm_cb<128, 2>(B3 + li * LDA + hh * 64, wpa, aa, lane, ha);
+            gemm_cb<128, 2>(B3 + li * LDA + hh * 64, wpm, am, lane, hm);
+            __syncthreads(); // every wave has read dZ (and hmix, for dW7)
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) {
+                store_acc<false>(B3 + wave * 32, rb, aa[rb], 0.0f, lane);
+                store_acc<false>(B1 + wave * 32, rb, am[rb], 0.0f, lane);
+            }
+        }
+        __syncthreads();
+        // attention backward per env: dhmix (B1), g (B2) -> dg (B2 in place), dkeys added into B3.  The rows
+        // beyond the tile's envs hold a recomputed g of padding rows: their dg is zero
+        if (tid < 32)
+            for (int r = RU; r < TR; ++r) *reinterpret_cast<float4 *>(B2 + r * LDA + tid * 4) = float4{0, 0, 0, 0};
+        for (int el = wave * 4 + (lane >> 4); el < ET; el += 16)
+            attend_env_bwd<128, true>(B1 + (el * n) * LDA, B2 + (el * n) * LDA, B0 + (el * n) * LDA, B3 + (el * n) * LDA,
+                                      sAttn[1 + round] + (el * n) * 8, n, n, q16);
+        __syncthreads();
+        // dA_m += h_in^T dg ;  dh += dg A_m^T
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) gemm_tn(B0 + kb * 32, LDA, B2 + wave * 32, LDA, acc_am[kb], lane);
+        {
+            BHead<128> hd;
+            const float4 *wp = Tq + FA_TOFF_AMT / 4 + wave * 16 * 64;
+            prefetch_b<128>(wp, lane, hd);
+            f32x16 acc[2] = {};
+            gemm_cb<128, 2>(B2 + li * LDA + hh * 64, wp, acc, lane, hd);
+            store_acc_add(B3 + wave * 32, 0, acc[0], lane);
+            store_acc_add(B3 + wave * 32, 1, acc[1], lane);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int kb = 0; kb < 8; ++kb) store_tile_global(slab + FA_POFF_W7 + kb * 32 * 128 + wave * 32, 128, acc_w7[kb], lane);
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) store_tile_global(slab + FA_POFF_AM + kb * 32 * 128 + wave * 32, 128, acc_am[kb], lane);
+    if (tid < 128) slab[FA_POFF_BU + tid] = dbu;
+
+    // ---- opponent stage: B0 = [h1 | e_opp], B3 = [dh1 (so far) | de_opp] --------------------------------
+    encoders(nullptr, B2); // ho -> B2[:, 0:64] (opponent rows), recomputed
+    __syncthreads();
+    project_opp();         // g_o -> B1[:, 64:128], recomputed
+    for (int r = wave * 4 + (lane >> 4); r < TR; r += 16) { // mix_o -> B1[:, 0:64], from the saved weights
+        if (r < RU) mix_row<64>(sAttn[0] + r * 8, B2 + ((r / n) * m) * LDA, m, B1 + r * LDA, q16);
+        else *reinterpret_cast<float4 *>(B1 + r * LDA + q16 * 4) = float4{0, 0, 0, 0};
+    }
+    __syncthreads();
+    {   // dB_o = mix_o^T de_opp (64 x 64: one tile per wave)
+        f32x16 acc = {};
+        gemm_tn(B1 + (wave >> 1) * 32, LDA, B3 + 64 + (wave & 1) * 32, LDA, acc, lane);
+        store_tile_global(slab + FA_POFF_BO + (wave >> 1) * 32 * 64 + (wave & 1) * 32, 64, acc, lane);
+    }
+    {   // dmix_o = de_opp B_o^T -> B2[:, 64:128]
+        BHead<64> hd;
+        const float4 *wp = Tq + FA_TOFF_BOT / 4 + (wave & 1) * 8 * 64;
+        prefetch_b<64>(wp, lane, hd);
+        f32x16 acc[1] = {};
+        gemm_cb<64, 1>(B3 + ((wave >> 1) * 32 + li) * LDA + 64 + hh * 32, wp, acc, lane, hd);
+        store_acc<false>(B2 + 64 + (wave & 1) * 32, wave >> 1, acc[0], 0.0f, lane);
+    }
+    __syncthreads();
+    // opponent attention backward per env: dmix_o (B2[:, 64:]), g_o (B1[:, 64:]) -> dg_o in place; dho -> B1[:, 0:64]
+    for (int el = wave * 4 + (lane >> 4); el < ET; el += 16)
+        attend_env_bwd<64, false>(B2 + (el * n) * LDA + 64, B1 + (el * n) * LDA + 64, B2 + (el * m) * LDA, B1 + (el * m) * LDA,
+                                  sAttn[0] + (el * n) * 8, n, m, q16);
+    __syncthreads();
+    {   // dA_o = h1^T dg_o ;  dh1 += dg_o A_o^T
+        f32x16 acc = {};
+        gemm_tn(B0 + (wave >> 1) * 32, LDA, B1 + 64 + (wave & 1) * 32, LDA, acc, lane);
+        store_tile_global(slab + FA_POFF_AO + (wave >> 1) * 32 * 64 + (wave & 1) * 32, 64, acc, lane);
+        BHead<64> hd;
+        const float4 *wp = Tq + FA_TOFF_AOT / 4 + (wave & 1) * 8 * 64;
+        prefetch_b<64>(wp, lane, hd);
+        f32x16 acc2[1] = {};
+        gemm_cb<64, 1>(B1 + ((wave >> 1) * 32 + li) * LDA + 64 + hh * 32, wp, acc2, lane, hd);
+        store_acc_add(B3 + (wave & 1) * 32, wave >> 1, acc2[0], lane);
+    }
+    __syncthreads();
+    // ---- encoders: through the relus, then dW = x^T dpre (6 x 64) and the bias gradients ----------------
+    for (int o = tid; o < 2 * 7 * 64; o += 256) {
+        const int side = o / (7 * 64), oo = o - side * 7 * 64, k = oo >> 6, c = oo & 63;
+        float sum = 0.0f;
+        if (side == 0) {
+            for (int r = 0; r < RU; ++r) {
+                const float d = B0[r * LDA + c] > 0.0f ? B3[r * LDA + c] : 0.0f;
+                const int el = r / n, i = r - el * n;
+                sum += d * (k < 6 ? sX[(el * N + own0 + i) * FA_OBS_DIM + k] : 1.0f);
+            }
+            slab[(k < 6 ? FA_POFF_WE + k * 64 : FA_POFF_BE) + c] = sum;
+        } else {
+            for (int r = 0; r < RO; ++r) {
+                const float d = B2[r * LDA + c] > 0.0f ? B1[r * LDA + c] : 0.0f;
+                const int el = r / m, j = r - el * m;
+                sum += d * (k < 6 ? sX[(el * N + opp0 + j) * FA_OBS_DIM + k] : 1.0f);
+            }
+            slab[(k < 6 ? FA_POFF_WOE + k * 64 : FA_POFF_BOE) + c] = sum;
+        }
+    }
+}
+
+// out[k] = sum_t slabs[t][k] in tile order
+__global__ void fa_train_reduce_kernel(const float *__restrict__ slabs, int tiles, float *__restrict__ out) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= FA_SLAB_FLOATS) return;
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+    int t = 0;
+    for (; t + 4 <= tiles; t += 4) {
+        s0 += slabs[(size_t)t * FA_SLAB_FLOATS + k];
+        s1 += slabs[(size_t)(t + 1) * FA_SLAB_FLOATS + k];
+        s2 += slabs[(size_t)(t + 2) * FA_SLAB_FLOATS + k];
+        s3 += slabs[(size_t)(t + 3) * FA_SLAB_FLOATS + k];
+    }
+    for (; t < tiles; ++t) s0 += slabs[(size_t)t * FA_SLAB_FLOATS + k];
+    out[k] = (s0 + s1) + (s2 + s3);
+}
+} // namespace
+
+int fa_train_tile_envs(int G, int A) { return TR / (G > A ? G : A); }
+
+hipError_t fa_launch_train(const FaTrainArgs &a, hipStream_t st) {
+    const int ET = fa_train_tile_envs(a.G, a.A);
+    hipLaunchKernelGGL(fa_train_kernel, dim3((a.B + ET - 1) / ET), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+hipError_t fa_launch_train_reduce(const float *slabs, int tiles, float *out, hipStream_t st) {
+    hipLaunchKernelGGL(fa_train_reduce_kernel, dim3((FA_SLAB_FLOATS + 255) / 256), dim3(256), 0, st, slabs, tiles, out);
+    return hipGetLastError();
+}

@@ -513,3 +513,30 @@ def make_fortattack_env(num_steps, benchmark=False, num_guards=5, num_attackers=
     positions from numpy's global stream (seed=None); see FortAttackGlobalEnv for `seed`."""
     return FortAttackGlobalEnv(num_steps, num_guards, num_attackers, seed=seed,
                                skip_doubles=skip_doubles, device=device)
+
+
+def ppo_grad(obs, action, value_pred, ret, old_logp, adv, w, wt, scale, team, G, A, clip, c_value, c_entropy,
+             clipped_value_loss=True, scratch=None, out=None):
+    """fa_ppo_grad: one team's PPO minibatch forward + losses + backward in one fused launch (+ reduction).
+    obs (B, N, 6) float32; action (B, N[, 1]) int64; value_pred / ret / old_logp / adv (B, N[, 1]) float32; w / wt the
+    packed weights and their transposes (mpnn_pack.pack_from_params); scale: device float32[2].  Returns
+    (out, scratch): out = FA_SLAB floats (plain-layout gradients + loss sums), scratch reusable."""
+    lib = _lib.load()
+    B, N = obs.shape[0], obs.shape[1]
+    for t in (obs, value_pred, ret, old_logp, adv, w, wt, scale):
+        assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
+    assert action.dtype == torch.int64 and action.is_contiguous() and N == G + A
+    if scratch is None:
+        sf, hf = C.c_int64(), C.c_int64()
+        _lib.check(lib.fa_ppo_grad_scratch(B, G, A, C.byref(sf), C.byref(hf)), "fa_ppo_grad_scratch")
+        scratch = (torch.empty(sf.value, device=obs.device), torch.empty(hf.value, device=obs.device))
+    if out is None:
+        out = torch.empty(lib.fa_ppo_grad_floats(), device=obs.device)
+    io = _lib.PPOGradIO()
+    io.obs, io.action, io.value_pred, io.ret, io.old_log_prob, io.adv = [_ptr(t) for t in (obs, action, value_pred, ret, old_logp, adv)]
+    io.weights, io.weights_t, io.scale, io.slabs, io.hsave, io.out = [_ptr(t) for t in (w, wt, scale, scratch[0], scratch[1], out)]
+    io.B, io.num_guards, io.num_attackers, io.team = B, G, A, team
+    io.clip_param, io.value_loss_coef, io.entropy_coef = clip, c_value, c_entropy
+    io.clipped_value_loss = int(bool(clipped_value_loss))
+    _lib.check(lib.fa_ppo_grad(C.byref(io), _stream()), "fa_ppo_grad")
+    return out, scratch

@@ -100,3 +100,87 @@ def folded_forward(flat, own, opp):
     pv = torch.relu(h @ unpack_gemm(sl("W8", 32768), 128, 256) + sl("B8", 256))
     out = pv @ unpack_gemm(sl("W9", 8192), 256, 32) + sl("B9", 32)
     return out[..., :8], out[..., 8:9]
+
+
+# ---- the PPO update's fused kernel (csrc/fa_train.hip) ---------------------------------------------------------
+TOFF = dict(AOT=0, BOT=4096, AMT=8192, W7T=24576, W8T=57344, W9T=90112)     # csrc/fa_train.h
+TRANS_FLOATS = 98304
+SLAB_FLOATS = WEIGHT_FLOATS + 16
+PLAIN_SHAPES = dict(WE=(6, 64), BE=(64,), WOE=(6, 64), BOE=(64,), AO=(64, 64), BO=(64, 64), AM=(128, 128), W7=(256, 128),
+                    BU=(128,), W8=(128, 256), B8=(256,), W9=(256, 32), B9=(32,))
+
+
+def kernel_params(pol):
+    """The matrices the fused kernels work with, as float32 tensors INSIDE the autograd graph of the module's
+    parameters (the folded products of this file's header, the stacked heads, zero-padded W9 / b9): calling
+    torch.autograd.backward on them with the kernel's gradients applies the chain rule to the parameters."""
+    a, m, hd = pol.oppAttn, pol.messages, pol.h_dim
+    uw = pol.update[0].weight
+    z = lambda *s: torch.zeros(*s, device=uw.device, dtype=uw.dtype)
+    w9 = torch.cat((torch.cat((pol.dist.linear.weight.t(), z(hd, 24)), 1),
+                    torch.cat((z(hd, 8), pol.value_head[2].weight.t(), z(hd, 23)), 1)), 0)
+    return dict(
+        WE=pol.encoder[0].weight.t(), BE=pol.encoder[0].bias, WOE=pol.oppEncoder[0].weight.t(), BOE=pol.oppEncoder[0].bias,
+        AO=a.norm_factor * (a.W_key[0] @ a.W_query[0].t()), BO=a.W_val[0] @ a.W_out[0],
+        AM=m.norm_factor * (m.W_query[0] @ m.W_key[0].t()),
+        W7=torch.cat((uw[:, :hd].t(), (m.W_val[0] @ m.W_out[0]) @ uw[:, hd:].t()), 0), BU=pol.update[0].bias,
+        W8=torch.cat((pol.policy_head[0].weight.t(), pol.value_head[0].weight.t()), 1),
+        B8=torch.cat((pol.policy_head[0].bias, pol.value_head[0].bias)),
+        W9=w9, B9=torch.cat((pol.dist.linear.bias, pol.value_head[2].bias, z(23))))
+
+
+_GEMMS = ("AO", "BO", "AM", "W7", "W8", "W9")
+
+
+@torch.no_grad()
+def pack_from_params(P, out_fwd, out_t):
+    """kernel_params() -> the forward pack (FA_POFF_*) and the transposed pack (FA_TOFF_*), in place."""
+    for k, v in P.items():
+        flat = pack_gemm(v.detach()) if k in _GEMMS else v.detach().reshape(-1)
+        out_fwd[POFF[k]:POFF[k] + flat.numel()].copy_(flat)
+    for k in _GEMMS:
+        flat = pack_gemm(P[k].detach().t())
+        out_t[TOFF[k + "T"]:TOFF[k + "T"] + flat.numel()].copy_(flat)
+
+
+def split_plain(flat):
+    """A FA_SLAB buffer (gradients in plain layout at the POFF offsets) -> dict of views shaped like kernel_params()."""
+    out = {}
+    for k, shp in PLAIN_SHAPES.items():
+        nfl = 1
+        for d in shp:
+            nfl *= d
+        out[k] = flat[POFF[k]:POFF[k] + nfl].view(*shp)
+    return out
+
+
+def folded_ppo_reference(P, obs, own_sl, opp_sl, action, value_pred, ret, old_logp, adv, clip, c_value, c_entropy,
+                         clipped_value_loss=True):
+    """Plain-torch statement of csrc/fa_train.hip (forward on the kernel-facing matrices P + the losses of
+    ppo.py:146-187 WITHOUT the division by the mask mean): returns (loss, value_loss, action_loss, entropy, mask_mean)
+    where loss = c_value * value_loss + action_loss - c_entropy * entropy; differentiable in P."""
+    own, opp = obs[:, own_sl], obs[:, opp_sl]
+    n = own.shape[1]
+    h1 = torch.relu(own @ P["WE"] + P["BE"])
+    ho = torch.relu(opp @ P["WOE"] + P["BOE"])
+    att = torch.softmax((h1 @ P["AO"]) @ ho.transpose(1, 2), dim=-1)
+    h = torch.cat((h1, (att @ ho) @ P["BO"]), dim=2)
+    diag = torch.zeros(n, n, device=obs.device).fill_diagonal_(-float("inf"))
+    for _ in range(3):
+        mix = torch.softmax((h @ P["AM"]) @ h.transpose(1, 2) + diag, dim=-1) @ h if n > 1 else torch.zeros_like(h)
+        h = torch.relu(torch.cat((h, mix), dim=2) @ P["W7"] + P["BU"])
+    out = torch.relu(h @ P["W8"] + P["B8"]) @ P["W9"] + P["B9"]
+    logp_all = torch.log_softmax(out[..., :8], dim=-1)
+    value = out[..., 8:9]
+    mask = own[:, :, 0:1]
+    logp = logp_all.gather(-1, action)
+    ent = -(logp_all.exp() * logp_all).sum(-1, keepdim=True)
+    ratio = mask * torch.exp(logp - old_logp)
+    al = (mask * -torch.min(ratio * adv, torch.clamp(ratio, 1 - clip, 1 + clip) * adv)).mean()
+    if clipped_value_loss:
+        vclip = value_pred + (value - value_pred).clamp(-clip, clip)
+        vl = (0.5 * torch.max((value - ret).pow(2), (vclip - ret).pow(2)) * mask).mean()
+    else:
+        vl = 0.5 * (ret - value).pow(2).mean()
+    en = (ent * mask).mean()
+    return vl * c_value + al - en * c_entropy, vl, al, en, mask.mean()

@@ -285,6 +285,40 @@ int fa_attend_forward(const float *g, const float *keys, float *out, float *attn
 int fa_attend_backward(const float *g, const float *keys, const float *attn, const float *dout, float *dg,
                        float *dkeys, int32_t B, int32_t n, int32_t nk, int32_t width, int32_t skip_self, void *stream);
 
+/* One team's PPO minibatch as one fused launch (+ a small reduction): the MPNN forward of evaluate_actions
+ * (mpnn.py:194-200), the alive-masked clipped losses of JointPPO.update (rlcore/algo/ppo.py:146-187) and the
+ * complete backward pass, hidden_dim = 128, teams of up to 8.  `weights` is the team's policy in the packed
+ * layout of fa_policy_act, `weights_t` the transposes the backward needs (csrc/fa_train.h FA_TOFF_*; both
+ * written by mpnn_pack).  `out` receives FA_SLAB floats: the gradient of the loss
+ *     value_loss * c_value + action_loss - entropy * c_entropy
+ * with respect to every kernel-facing matrix, in PLAIN row-major layout at the offsets of the packed buffer
+ * (csrc/fa_policy.h FA_POFF_*: encoders, A_o, B_o, A_m, W7, W8, W9 and the biases -- the host applies the
+ * chain rule to the module's own parameters, mpnn_pack.KernelParams), followed at fa_ppo_grad_floats() - 16
+ * by the sums over the minibatch of {value loss, action loss, entropy * mask, mask}.
+ * scale: device float[2] = {1 / (B n mask_mean'), mask_mean'}, mask_mean' = the minibatch's alive-mask mean
+ * (ppo.py:150-187 divides every loss by it; pass {1 / (B n), 1} to normalise later, e.g. across ranks).
+ * obs (B, N, 6); action / value_pred / ret / old_log_prob / adv (B, N), of which the team's columns are read.
+ * slabs / hsave: scratch of fa_ppo_grad_scratch() floats.  Bitwise reproducible (no atomics). */
+typedef struct fa_ppo_grad_io {
+    const float *obs;
+    const int64_t *action;
+    const float *value_pred, *ret, *old_log_prob, *adv;
+    const float *weights, *weights_t;
+    const float *scale;
+    float *slabs, *hsave;      /* scratch */
+    float *out;                /* fa_ppo_grad_floats() floats */
+    int32_t B;                 /* envs in the minibatch */
+    int32_t num_guards, num_attackers;
+    int32_t team;              /* 0: the guards' policy on the guards' rows, 1: the attackers' */
+    float clip_param, value_loss_coef, entropy_coef;
+    int32_t clipped_value_loss;
+} fa_ppo_grad_io;
+int fa_ppo_grad(const fa_ppo_grad_io *io, void *stream);
+int64_t fa_ppo_grad_floats(void);
+/* scratch sizes in floats for a minibatch of B envs */
+int fa_ppo_grad_scratch(int32_t B, int32_t num_guards, int32_t num_attackers, int64_t *slab_floats, int64_t *hsave_floats);
+int64_t fa_policy_weight_t_floats(void);
+
 /* ---- state access (synchronous; tests / checkpoint) ------------------------------ */
 int fa_get_state(fa_env *env, const fa_state_host *out);
 int fa_set_state(fa_env *env, const fa_state_host *in); /* pos/vel/ang/prev_dist/alive/time_step/num_hit/

@@ -178,3 +178,49 @@ def test_update_forward_on_gpu_matches_reference_shaped_forward(fa, G, A):
         assert (res[0][k] - res[1][k]).abs().max() < TOL
     for k, ga in res[0][3].items():
         assert (ga - res[1][3][k]).abs().max() <= 2e-4 * max(1e-3, float(ga.abs().max())), k
+
+
+@pytest.mark.parametrize("G,A,team,B,clipped", [(3, 3, 0, 500, True), (3, 3, 1, 21, True), (3, 3, 0, 43, False),
+                                                (5, 5, 1, 200, True), (2, 4, 0, 100, True), (4, 2, 1, 77, True)])
+def test_fused_ppo_grad_matches_torch_autograd(fa, G, A, team, B, clipped):
+    """fa_ppo_grad (forward + PPO losses + complete backward of one team's minibatch, one launch) against torch
+    autograd through the plain-torch statement of the same computation on the same kernel-facing matrices."""
+    from emergent_multiagent_strategies_amd import mpnn_pack as mp_
+    from emergent_multiagent_strategies_amd.env import ppo_grad
+    N = G + A
+    pols, _ = _policies(fa, G, A, 11 + team)
+    pol = pols[team]
+    own_sl, opp_sl = (slice(0, G), slice(G, N)) if team == 0 else (slice(G, N), slice(0, G))
+    n = G if team == 0 else A
+    g = torch.Generator(device="cuda").manual_seed(B)
+    obs = _obs(B, N, B + 1)
+    rnd = lambda *s: torch.randn(*s, device="cuda", generator=g)
+    action = torch.randint(0, 8, (B, N, 1), device="cuda", generator=g)
+    value_pred, ret, adv = rnd(B, N, 1), rnd(B, N, 1), rnd(B, N, 1)
+    old_logp = -torch.rand((B, N, 1), device="cuda", generator=g) * 2.5
+    clip, c_v, c_e = 0.2, 0.5, 0.01
+    P = {k: v.detach().clone().requires_grad_(True) for k, v in mp_.kernel_params(pol).items()}
+    loss, vl, al, en, mm = mp_.folded_ppo_reference(P, obs, own_sl, opp_sl, action[:, own_sl], value_pred[:, own_sl], ret[:, own_sl],
+                                                    old_logp[:, own_sl], adv[:, own_sl], clip, c_v, c_e, clipped)
+    loss.backward()
+    w = torch.zeros(mp_.WEIGHT_FLOATS, device="cuda")
+    wt = torch.zeros(mp_.TRANS_FLOATS, device="cuda")
+    mp_.pack_from_params(P, w, wt)
+    scale = torch.tensor([1.0 / (B * n), 1.0], device="cuda")
+    out, _ = ppo_grad(obs, action, value_pred, ret, old_logp, adv, w, wt, scale, team, G, A, clip, c_v, c_e, clipped)
+    torch.cuda.synchronize()
+    sums = out[mp_.WEIGHT_FLOATS:mp_.WEIGHT_FLOATS + 4] / (B * n)
+    for got, want in zip(sums, (vl, al, en, mm)):
+        assert abs(float(got) - float(want)) <= 1e-5 * max(1.0, abs(float(want)))
+    grads = mp_.split_plain(out)
+    worst = {}
+    for k, gk in grads.items():
+        ref = P[k].grad
+        if k == "W9":
+            assert float(gk[:, 9:].abs().max()) == 0.0
+        if k == "B9":
+            gk, ref = gk[:9], ref[:9]
+        scale_k = max(float(ref.abs().max()), 1e-6)
+        worst[k] = float((gk - ref).abs().max()) / scale_k
+    print({k: "%.1e" % v for k, v in worst.items()})
+    assert max(worst.values()) < 2e-3, worst
