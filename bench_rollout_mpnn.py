@@ -25,12 +25,13 @@ def main():
     ap.add_argument("--graph", type=int, default=1)
     ap.add_argument("--update", type=int, default=1)
     ap.add_argument("--backend", default="auto", choices=["auto", "hip", "torch"], help="who runs the rollout forwards")
+    ap.add_argument("--update-backend", default="auto", choices=["auto", "fused", "torch"])
     ap.add_argument("--ensemble", type=int, default=0, help="K frozen attacker strategies, one per env, re-drawn at "
                                                               "every reset (BASELINE config 5); guards only are trained")
     a = ap.parse_args()
     torch.manual_seed(0)
     eng = fa.BatchedFortAttack(a.envs, a.guards, a.attackers, 100, base_seed=0, track_counters=False)
-    L = fa.BatchedLearner(eng, num_steps=a.rollout, use_graph=bool(a.graph), policy_backend=a.backend)
+    L = fa.BatchedLearner(eng, num_steps=a.rollout, use_graph=bool(a.graph), policy_backend=a.backend, update_backend=a.update_backend)
     if a.ensemble:
         L.load_attacker_ensemble([fa.MPNN(num_agents=a.attackers, num_opp_agents=a.guards, num_actions=8).state_dict()
                                   for _ in range(a.ensemble)])

@@ -186,3 +186,33 @@ def _check_rollout_env_rows(learner, orc, ids_at=None):
         assert np.array_equal(rew[s, :, :, 0], ref["reward"].astype(np.float32)), s
         want_mask = np.where(ref["done"][:, None] != 0, 1, ref["alive_before"]).astype(np.float32)
         assert np.array_equal(msk[s + 1, :, :, 0], want_mask), s
+
+
+@pytest.mark.parametrize("G,A,clipped", [(3, 3, True), (5, 5, True), (3, 3, False)])
+def test_fused_update_follows_the_torch_update(fa, G, A, clipped):
+    """BatchedLearner.update with the fused fa_ppo_grad step (update_backend="fused") vs PyTorch autograd
+    (update_backend="torch") from the same rollout, same initial policies and the same minibatch permutations:
+    the averaged losses agree and the parameters stay together (Adam amplifies rounding differences of
+    near-zero gradients to at most one learning-rate step)."""
+    E, T = 256, 16
+    res = []
+    for backend in ("torch", "fused"):
+        torch.manual_seed(3)
+        eng = fa.BatchedFortAttack(E, G, A, 12, base_seed=9)
+        L = fa.BatchedLearner(eng, num_steps=T, num_mini_batch=4, ppo_epoch=2, use_graph=True, update_backend=backend,
+                              clipped_value_loss=clipped, lr=1e-4)
+        L.reset()
+        L.collect()
+        torch.manual_seed(77)                       # the minibatch permutations
+        losses = L.update()
+        torch.cuda.synchronize()
+        step = next(iter(v for k, v in L._update_graphs.items() if k != "fused"))
+        assert step.fused == (backend == "fused")
+        res.append((losses.cpu(), [p.detach().cpu().clone() for pol in L.policies for p in pol.parameters()],
+                    L.storage.actions.clone()))
+    (l0, p0, a0), (l1, p1, a1) = res
+    assert torch.equal(a0, a1)                      # same rollout
+    assert (l0 - l1).abs().max() < 2e-4 * max(1.0, float(l0.abs().max())), (l0, l1)
+    worst = max(float((x - y).abs().max()) for x, y in zip(p0, p1))
+    print("max parameter distance fused vs torch: %.2e" % worst)
+    assert worst < 4e-4                             # 8 Adam steps of 1e-4
