@@ -64,7 +64,8 @@ def _world(group=None):
 
 class GraphedPPOStep(object):
     """One optimizer step of joint_ppo_update -- minibatch forward, backward, (gradient exchange,) clip, Adam --
-    captured as hipGraph(s) and replayed: the step is ~300 small kernels and its Python / dispatcher time
+    captured as hipGraph(s) and replayed.  `fused`: forward, losses and backward are ONE launch of the fa_ppo_grad
+    kernel (csrc/fa_train.hip) instead of PyTorch autograd.  Why graphs: the step is ~300 small kernels and its Python / dispatcher time
     (4 ms) exceeds its GPU time (2.7 ms at 16 384 x 3 samples); replayed, only the GPU time is left.
 
     The minibatch is gathered into static buffers (index_select, outside the graph); parameters, gradients
@@ -74,14 +75,54 @@ class GraphedPPOStep(object):
     before the first real step."""
 
     def __init__(self, pol, opt, own_sl, opp_sl, rows, mb, clip_param, value_loss_coef, entropy_coef, max_grad_norm,
-                 clipped_value_loss, group):
+                 clipped_value_loss, group, fused=False):
         self.pol, self.opt, self.group, self.world = pol, opt, group, _world(group)
         self.params = [p for p in pol.parameters()]
         self.static = [torch.empty((mb,) + tuple(r.shape[1:]), dtype=r.dtype, device=r.device) for r in rows]
         self.mb = mb
         world = self.world
+        self.fused = bool(fused)
+        if self.fused:   # csrc/fa_train.hip: forward + losses + backward of the minibatch in one launch
+            from .env import ppo_grad
+            dev = rows[0].device
+            N = rows[0].shape[1]
+            n_own = own_sl.stop - own_sl.start
+            team, G = (0, n_own) if own_sl.start == 0 else (1, N - n_own)
+            self._w = torch.zeros(mpnn_pack.WEIGHT_FLOATS, device=dev)
+            self._wt = torch.zeros(mpnn_pack.TRANS_FLOATS, device=dev)
+            self._scale = torch.zeros(2, device=dev)
+            self._out = torch.zeros(mpnn_pack.SLAB_FLOATS, device=dev)
+            self._scratch = None
+            keys = list(mpnn_pack.PLAIN_SHAPES)
+            inv_count = 1.0 / (mb * n_own)
+
+        def fused_fwd_bwd():
+            """kernel-facing matrices from the parameters (inside autograd) -> packed -> fa_ppo_grad -> the chain
+            rule back to the parameters by torch.autograd.backward on those matrices"""
+            obs_b, act_b, vp_b, ret_b, olp_b, adv_b = self.static
+            P = mpnn_pack.kernel_params(pol)
+            mpnn_pack.pack_from_params(P, self._w, self._wt)
+            mm = obs_b[:, own_sl, 0].mean()
+            mmp = torch.where(mm != 0, mm, torch.ones_like(mm))
+            # one rank: every loss divided by the mask mean here; several: after the all-reduce (finish())
+            self._scale.copy_(torch.stack((inv_count / mmp if world == 1 else torch.full_like(mmp, inv_count), mmp)))
+            _, self._scratch = ppo_grad(obs_b, act_b, vp_b, ret_b, olp_b, adv_b, self._w, self._wt, self._scale, team, G,
+                                        N - G, clip_param, value_loss_coef, entropy_coef, clipped_value_loss,
+                                        scratch=self._scratch, out=self._out)
+            opt.zero_grad(set_to_none=True)
+            g = mpnn_pack.split_plain(self._out)
+            torch.autograd.backward([P[k] for k in keys], [g[k] for k in keys])
+            sums = self._out[mpnn_pack.WEIGHT_FLOATS:mpnn_pack.WEIGHT_FLOATS + 3] * inv_count
+            if not clipped_value_loss:      # the scalar-MSE value loss is not masked (ppo.py:178-182)
+                sums = sums * torch.stack((mmp, torch.ones_like(mmp), torch.ones_like(mmp)))
+            if world == 1:
+                return sums / mmp, None
+            grads = [p.grad for p in self.params if p.grad is not None]
+            return sums, torch.cat([gr.reshape(-1) for gr in grads] + [sums, mm.reshape(1)])
 
         def fwd_bwd():
+            if self.fused:
+                return fused_fwd_bwd()
             obs_b, act_b, vp_b, ret_b, olp_b, adv_b = self.static
             out = ppo_losses(pol, obs_b[:, own_sl], obs_b[:, opp_sl], act_b[:, own_sl], vp_b[:, own_sl], ret_b[:, own_sl],
                              olp_b[:, own_sl], adv_b[:, own_sl], clip_param, clipped_value_loss, normalize=(world == 1))
@@ -194,7 +235,8 @@ def joint_ppo_update(pol, opt, own_sl, opp_sl, rows, clip_param, ppo_epoch, num_
                 key = (id(pol), mb)
                 if key not in graphs:
                     graphs[key] = GraphedPPOStep(pol, opt, own_sl, opp_sl, rows, mb, clip_param, value_loss_coef,
-                                                 entropy_coef, max_grad_norm, clipped_value_loss, group)
+                                                 entropy_coef, max_grad_norm, clipped_value_loss, group,
+                                                 fused=graphs.get("fused", False) and mpnn_pack.supported(pol))
                 acc += graphs[key].run(rows, idx)
                 continue
             obs_b = obs_f[idx]
@@ -227,7 +269,7 @@ class BatchedLearner(object):
     def __init__(self, eng, num_steps=128, hidden_dim=128, lr=1e-4, clip_param=0.2, ppo_epoch=4,
                  num_mini_batch=32, value_loss_coef=0.5, entropy_coef=0.01, max_grad_norm=0.5,
                  gamma=0.99, tau=0.95, clipped_value_loss=True, use_graph=False, group=None, policy_backend="auto",
-                 sample_seed=None):
+                 sample_seed=None, update_backend="auto"):
         # defaults: arguments.py:22-45
         # policy_backend: "hip" = the fused fa_policy kernel runs the rollout's forwards (hidden_dim 128),
         # "torch" = the PyTorch modules do, "auto" = hip whenever it supports the configuration
@@ -247,7 +289,11 @@ class BatchedLearner(object):
         # hipGraph; same arithmetic)
         self.optimizers = [torch.optim.Adam(p.parameters(), lr=lr, capturable=self.device.type == "cuda")
                            for p in self.policies]
-        self._update_graphs = {} if use_graph else None
+        # update_backend "fused" (the default where it applies: use_graph, hidden_dim 128): every optimizer step's
+        # forward + losses + backward is the fa_ppo_grad kernel; "torch": PyTorch autograd with the fa_attend op
+        if update_backend not in ("auto", "fused", "torch"):
+            raise ValueError("update_backend must be 'auto', 'fused' or 'torch'")
+        self._update_graphs = {"fused": update_backend != "torch"} if use_graph else None
         self.storage = JointRolloutStorage(num_steps, self.E, self.N, device=self.device)
         eng.bind_storage(self.storage)
         self.team_slices = [slice(0, self.G), slice(self.G, self.N)]
