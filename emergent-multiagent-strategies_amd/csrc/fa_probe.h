@@ -15,4 +15,5 @@
 #define FA_PROBE_WAVE0_LOOP_BEGIN(lane)
 #define FA_PROBE_WAVE0_LOOP_END(lane)
 #define FA_PROBE_WAVE0_END(lane)
+#define FA_TR_TICK(k) // fa_train.hip phase marks
 #endif

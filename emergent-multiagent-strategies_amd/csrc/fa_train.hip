@@ -27,6 +27,8 @@
 
 #include "fa_train.h"
 #include "fa_mfma.h"
+#define FA_PROBE_TRAIN_TU
+#include "fa_probe.h"
 
 namespace {
 constexpr int TR = FA_TR_ROWS;
@@ -164,6 +166,7 @@ __global__ __launch_bounds__(256, 1) void fa_train_kernel(FaTrainArgs a) {
     __shared__ float sX[TR * 2 * FA_OBS_DIM];
     __shared__ __attribute__((aligned(16))) float sO[TR * SOW];
     __shared__ float sAttn[4][TR * 8]; // [opponent stage, round 0, 1, 2][row][key]
+    __shared__ __attribute__((aligned(16))) float sO2[TR * SOW]; // the opponent side's [x | 1] rows (encoder backward)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, hh = lane >> 5, q16 = lane & 15;
@@ -233,17 +236,17 @@ __global__ __launch_bounds__(256, 1) void fa_train_kernel(FaTrainArgs a) {
         gemm_cb<64, 1>(B0 + ((wave >> 1) * 32 + li) * LDA + hh * 32, wp, acc, lane, hd);
         store_acc<false>(B1 + 64 + (wave & 1) * 32, wave >> 1, acc[0], 0.0f, lane);
     };
-    // g = h A_m: B0 -> dst (all 128 columns; wave = column block)
-    auto project_team = [&](float *dst) {
-        BHead<128> hd;
-        const float4 *wp = Wq + FA_POFF_AM / 4 + wave * 16 * 64;
-        prefetch_b<128>(wp, lane, hd);
+    // g = h A_m: B0 -> dst (all 128 columns; wave = column block); `hd`: the first weights, requested earlier
+    const float4 *wp_am = Wq + FA_POFF_AM / 4 + wave * 16 * 64;
+    auto project_team = [&](float *dst, const BHead<128> &hd) {
+        const float4 *wp = wp_am;
         f32x16 acc[2] = {};
         gemm_cb<128, 2>(B0 + li * LDA + hh * 64, wp, acc, lane, hd);
         store_acc<false>(dst + wave * 32, 0, acc[0], 0.0f, lane);
         store_acc<false>(dst + wave * 32, 1, acc[1], 0.0f, lane);
     };
 
+    FA_TR_TICK(0)
     // ================================ forward ==========================================================
     for (int k = tid; k < ET * N * FA_OBS_DIM; k += 256)
         sX[k] = k < ne * N * FA_OBS_DIM ? a.obs[(size_t)e0 * N * FA_OBS_DIM + k] : 0.0f;
@@ -263,10 +266,17 @@ __global__ __launch_bounds__(256, 1) void fa_train_kernel(FaTrainArgs a) {
         gemm_cb<64, 1>(B1 + ((wave >> 1) * 32 + li) * LDA + 64 + hh * 32, wp, acc, lane, hd);
         store_acc<false>(B0 + 64 + (wave & 1) * 32, wave >> 1, acc[0], 0.0f, lane);
     }
+    FA_TR_TICK(1)
+    BHead<128> hd_am; // the first weights of the next 128-deep layer, requested a phase ahead (an L2 round trip)
+    prefetch_b<128>(wp_am, lane, hd_am);
     __syncthreads();
     save_tile(B0, hsave);
+    const float4 *wpp = Wq + FA_POFF_W8 / 4 + wave * 16 * 64, *wpv = Wq + FA_POFF_W8 / 4 + (4 + wave) * 16 * 64;
     for (int round = 0; round < 3; ++round) {
-        project_team(B1);
+        project_team(B1, hd_am);
+        BHead<256> hd_u;
+        const float4 *wp_u = Wq + FA_POFF_W7 / 4 + wave * 32 * 64;
+        prefetch_b<256>(wp_u, lane, hd_u);
         __syncthreads();
         for (int r = wave * 4 + (lane >> 4); r < TR; r += 16) { // team attention, self excluded (mpnn.py:250-332)
             const int el = r / n;
@@ -274,11 +284,9 @@ __global__ __launch_bounds__(256, 1) void fa_train_kernel(FaTrainArgs a) {
         }
         __syncthreads();
         {   // h' = relu([h | hmix] W7 + bu)
-            BHead<256> hd;
-            const float4 *wp = Wq + FA_POFF_W7 / 4 + wave * 32 * 64;
-            prefetch_b<256>(wp, lane, hd);
             f32x16 acc[2] = {};
-            gemm_cb<256, 2>((hh ? B1 : B0) + li * LDA, wp, acc, lane, hd);
+            gemm_cb<256, 2>((hh ? B1 : B0) + li * LDA, wp_u, acc, lane, hd_u);
+            prefetch_b<128>(round < 2 ? wp_am : wpp, lane, hd_am); // next: the following round's g, or the policy head
             const float bias = W[FA_POFF_BU + wave * 32 + li];
             __syncthreads();
             store_acc<true>(B0 + wave * 32, 0, acc[0], bias, lane);
@@ -287,10 +295,10 @@ __global__ __launch_bounds__(256, 1) void fa_train_kernel(FaTrainArgs a) {
         __syncthreads();
         if (round < 2) save_tile(B0, hsave + (round + 1) * TR * 128);
     }
+    FA_TR_TICK(2)
     {   // heads: P = relu(h Wp0 + b) -> B1, V = relu(h Wv0 + b) -> B2
-        BHead<128> hp, hv;
-        const float4 *wpp = Wq + FA_POFF_W8 / 4 + wave * 16 * 64, *wpv = Wq + FA_POFF_W8 / 4 + (4 + wave) * 16 * 64;
-        prefetch_b<128>(wpp, lane, hp);
+        BHead<128> hv;
+        const BHead<128> &hp = hd_am;
         prefetch_b<128>(wpv, lane, hv);
         f32x16 accp[2] = {}, accv[2] = {};
         gemm_cb<128, 2>(B0 + li * LDA + hh * 64, wpp, accp, lane, hp);
@@ -315,6 +323,7 @@ __global__ __launch_bounds__(256, 1) void fa_train_kernel(FaTrainArgs a) {
     }
     __syncthreads();
 
+    FA_TR_TICK(3)
     // ================================ losses (ppo.py:150-187) and dL/d[logits | value] -> sO ==============
     if (wave == 0) {
         const int r = lane;
@@ -382,6 +391,7 @@ __global__ __launch_bounds__(256, 1) void fa_train_kernel(FaTrainArgs a) {
     }
     __syncthreads();
 
+    FA_TR_TICK(4)
     // ================================ backward =========================================================
     // ---- heads --------------------------------------------------------------------------------------
     {   // dW9 = [P | V]^T dOUT (256 x 32): 8 k-blocks, two per wave;  db9 = column sums of dOUT
@@ -456,14 +466,19 @@ __global__ __launch_bounds__(256, 1) void fa_train_kernel(FaTrainArgs a) {
     }
     __syncthreads();
 
+    FA_TR_TICK(5)
     // ---- the three rounds, last first: B0 = the round's output h, B3 = dL/d(output) ---------------------
-    f32x16 acc_w7[8], acc_am[4]; // dW7 (256 x 128: column block = wave, 8 k-blocks), dA_m (128 x 128: 4 k-blocks)
+    // dW7 (256 x 128: column block = wave, 8 k-blocks) and dA_m (128 x 128: 4 k-blocks) accumulate in registers
+    // across the three rounds (a read-modify-write of the slab per round instead cost 60-110 k cycles per round:
+    // its loads serialise in front of every tile's MFMA chain)
+    f32x16 acc_w7[8], acc_am[4];
 #pragma unroll
     for (int t = 0; t < 8; ++t) acc_w7[t] = f32x16{};
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc_am[t] = f32x16{};
     float dbu = 0.0f; // threads 0..127: their column of the update bias gradient
     for (int round = 2; round >= 0; --round) {
+        FA_TR_TICK(6 + (2 - round) * 8)
         // dZ = dL/dh_out through the relu (in place in B3); the bias gradient
         for (int k = tid; k < TR * 128; k += 256) {
             const int r = k >> 7, c = k & 127;
@@ -475,10 +490,13 @@ __global__ __launch_bounds__(256, 1) void fa_train_kernel(FaTrainArgs a) {
             for (int r = 0; r < TR; ++r) sum += B3[r * LDA + tid];
             dbu += sum;
         }
+        FA_TR_TICK(7 + (2 - round) * 8)
         // h_in -> B0, g = h_in A_m -> B2 (recomputed), hmix -> B1 (recomputed from the saved weights)
+        BHead<128> hd_g;
+        prefetch_b<128>(wp_am, lane, hd_g);
         load_tile(B0, hsave + round * TR * 128);
         __syncthreads();
-        project_team(B2);
+        project_team(B2, hd_g);
         for (int r = wave * 4 + (lane >> 4); r < TR; r += 16) {
             if (r < RU) mix_row<128>(sAttn[1 + round] + r * 8, B0 + ((r / n) * n) * LDA, n, B1 + r * LDA, q16);
             else {
@@ -487,14 +505,16 @@ __global__ __launch_bounds__(256, 1) void fa_train_kernel(FaTrainArgs a) {
             }
         }
         __syncthreads();
-        // dW7 += [h_in | hmix]^T dZ
+        FA_TR_TICK(8 + (2 - round) * 8)
+        // dW7 += [h_in | hmix]^T dZ  (the transposed weights of the next GEMM are requested first)
+        BHead<128> ha, hm;
+        const float4 *wpa = Tq + FA_TOFF_W7T / 4 + wave * 16 * 64, *wpm = Tq + FA_TOFF_W7T / 4 + (4 + wave) * 16 * 64;
+        prefetch_b<128>(wpa, lane, ha);
+        prefetch_b<128>(wpm, lane, hm);
 #pragma unroll
         for (int kb = 0; kb < 8; ++kb) gemm_tn((kb < 4 ? B0 : B1) + (kb & 3) * 32, LDA, B3 + wave * 32, LDA, acc_w7[kb], lane);
+        FA_TR_TICK(9 + (2 - round) * 8)
         {   // [dh_a | dhmix] = dZ W7^T (K = 128 -> 256 columns)
-            BHead<128> ha, hm;
-            const float4 *wpa = Tq + FA_TOFF_W7T / 4 + wave * 16 * 64, *wpm = Tq + FA_TOFF_W7T / 4 + (4 + wave) * 16 * 64;
-            prefetch_b<128>(wpa, lane, ha);
-            prefetch_b<128>(wpm, lane, hm);
             f32x16 aa[2] = {}, am[2] = {};
             gemm_cb<128, 2>(B3 + li * LDA + hh * 64, wpa, aa, lane, ha);
             gemm_cb<128, 2>(B3 + li * LDA + hh * 64, wpm, am, lane, hm);
@@ -506,6 +526,7 @@ __global__ __launch_bounds__(256, 1) void fa_train_kernel(FaTrainArgs a) {
             }
         }
         __syncthreads();
+        FA_TR_TICK(10 + (2 - round) * 8)
         // attention backward per env: dhmix (B1), g (B2) -> dg (B2 in place), dkeys added into B3.  The rows
         // beyond the tile's envs hold a recomputed g of padding rows: their dg is zero
         if (tid < 32)
@@ -514,13 +535,14 @@ __global__ __launch_bounds__(256, 1) void fa_train_kernel(FaTrainArgs a) {
             attend_env_bwd<128, true>(B1 + (el * n) * LDA, B2 + (el * n) * LDA, B0 + (el * n) * LDA, B3 + (el * n) * LDA,
                                       sAttn[1 + round] + (el * n) * 8, n, n, q16);
         __syncthreads();
+        FA_TR_TICK(11 + (2 - round) * 8)
         // dA_m += h_in^T dg ;  dh += dg A_m^T
+        BHead<128> hd;
+        const float4 *wp = Tq + FA_TOFF_AMT / 4 + wave * 16 * 64;
+        prefetch_b<128>(wp, lane, hd);
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) gemm_tn(B0 + kb * 32, LDA, B2 + wave * 32, LDA, acc_am[kb], lane);
         {
-            BHead<128> hd;
-            const float4 *wp = Tq + FA_TOFF_AMT / 4 + wave * 16 * 64;
-            prefetch_b<128>(wp, lane, hd);
             f32x16 acc[2] = {};
             gemm_cb<128, 2>(B2 + li * LDA + hh * 64, wp, acc, lane, hd);
             store_acc_add(B3 + wave * 32, 0, acc[0], lane);
@@ -534,6 +556,7 @@ __global__ __launch_bounds__(256, 1) void fa_train_kernel(FaTrainArgs a) {
     for (int kb = 0; kb < 4; ++kb) store_tile_global(slab + FA_POFF_AM + kb * 32 * 128 + wave * 32, 128, acc_am[kb], lane);
     if (tid < 128) slab[FA_POFF_BU + tid] = dbu;
 
+    FA_TR_TICK(30)
     // ---- opponent stage: B0 = [h1 | e_opp], B3 = [dh1 (so far) | de_opp] --------------------------------
     encoders(nullptr, B2); // ho -> B2[:, 0:64] (opponent rows), recomputed
     __syncthreads();
@@ -574,26 +597,38 @@ __global__ __launch_bounds__(256, 1) void fa_train_kernel(FaTrainArgs a) {
         store_acc_add(B3 + (wave & 1) * 32, wave >> 1, acc2[0], lane);
     }
     __syncthreads();
-    // ---- encoders: through the relus, then dW = x^T dpre (6 x 64) and the bias gradients ----------------
-    for (int o = tid; o < 2 * 7 * 64; o += 256) {
-        const int side = o / (7 * 64), oo = o - side * 7 * 64, k = oo >> 6, c = oo & 63;
-        float sum = 0.0f;
-        if (side == 0) {
-            for (int r = 0; r < RU; ++r) {
-                const float d = B0[r * LDA + c] > 0.0f ? B3[r * LDA + c] : 0.0f;
-                const int el = r / n, i = r - el * n;
-                sum += d * (k < 6 ? sX[(el * N + own0 + i) * FA_OBS_DIM + k] : 1.0f);
-            }
-            slab[(k < 6 ? FA_POFF_WE + k * 64 : FA_POFF_BE) + c] = sum;
-        } else {
-            for (int r = 0; r < RO; ++r) {
-                const float d = B2[r * LDA + c] > 0.0f ? B1[r * LDA + c] : 0.0f;
-                const int el = r / m, j = r - el * m;
-                sum += d * (k < 6 ? sX[(el * N + opp0 + j) * FA_OBS_DIM + k] : 1.0f);
-            }
-            slab[(k < 6 ? FA_POFF_WOE + k * 64 : FA_POFF_BOE) + c] = sum;
+    FA_TR_TICK(31)
+    // ---- encoders: through the relus, then [dW ; db] = [x | 1]^T dpre as one 32 x 32 MFMA tile per 32 columns ----
+    // (own side: waves 0, 1; opponent side: waves 2, 3).  [x | 1 | 0...] rows go to sO / sO2.
+    for (int k = tid; k < 2 * TR * 64; k += 256) {
+        const int side = k / (TR * 64), kk = k - side * TR * 64, r = kk >> 6, c = kk & 63;
+        if (side == 0) { if (!(B0[r * LDA + c] > 0.0f)) B3[r * LDA + c] = 0.0f; }
+        else if (!(B2[r * LDA + c] > 0.0f)) B1[r * LDA + c] = 0.0f;
+    }
+    for (int k = tid; k < 2 * TR * SOW; k += 256) {
+        const int side = k / (TR * SOW), kk = k - side * TR * SOW, r = kk / SOW, c = kk - r * SOW;
+        const int per = side == 0 ? n : m, first = side == 0 ? own0 : opp0, used = side == 0 ? RU : RO;
+        float v = 0.0f;
+        if (r < used) {
+            const int el = r / per, i = r - el * per;
+            v = c < FA_OBS_DIM ? sX[(el * N + first + i) * FA_OBS_DIM + c] : (c == FA_OBS_DIM ? 1.0f : 0.0f);
+        }
+        (side == 0 ? sO : sO2)[kk] = v;
+    }
+    __syncthreads();
+    {
+        const int side = wave >> 1, cb = wave & 1;
+        f32x16 acc = {};
+        gemm_tn(side == 0 ? sO : sO2, SOW, (side == 0 ? B3 : B1) + cb * 32, LDA, acc, lane);
+        float *dw = slab + (side == 0 ? FA_POFF_WE : FA_POFF_WOE), *db = slab + (side == 0 ? FA_POFF_BE : FA_POFF_BOE);
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int row = (reg & 3) + 8 * (reg >> 2) + 4 * hh; // = k of [x | 1]
+            if (row < FA_OBS_DIM) dw[row * 64 + cb * 32 + li] = acc[reg];
+            else if (row == FA_OBS_DIM) db[cb * 32 + li] = acc[reg];
         }
     }
+    FA_TR_TICK(32)
 }
 
 // out[k] = sum_t slabs[t][k] in tile order

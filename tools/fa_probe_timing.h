@@ -2,6 +2,7 @@
 // built by tools/make_timing_build.py, read by tools/timing_probe.py).  Sections accumulate
 // shader-clock ticks per wave role into g_dbg; g_hw records where the hardware placed each wave.
 #pragma once
+#ifndef FA_PROBE_TRAIN_TU // ---- the step kernels' translation unit (fa_step.hip)
 #ifndef FA_TICK_WAVE1
 #define FA_TICK_WAVE1 0 // 1: report pair wave 1 instead of the last pair wave
 #endif
@@ -24,3 +25,11 @@ extern "C" int fa_dbg_read(unsigned long long *out, int reset) {
     return 0;
 }
 extern "C" int fa_dbg_hw(unsigned *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_hw), sizeof(unsigned) * 4096); }
+
+#define FA_TR_TICK(k)
+#else // ---- fa_train.hip
+// fa_train.hip: workgroup 0 / thread 0 records the shader clock at phase marks
+__device__ unsigned long long g_tr[64];
+#define FA_TR_TICK(k) if (threadIdx.x == 0 && blockIdx.x == 7) g_tr[k] = clock64();
+extern "C" int fa_dbg_train(unsigned long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tr), sizeof(unsigned long long) * 64); }
+#endif
