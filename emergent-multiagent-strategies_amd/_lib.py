@@ -55,6 +55,12 @@ class PPOGradIO(C.Structure):
                 ("clipped_value_loss", C.c_int32)]
 
 
+class Task(C.Structure):
+    _fields_ = [("C", c_p), ("A", c_p), ("B", c_p), ("ldc", C.c_int32), ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
+                ("a_rs", C.c_int32), ("a_cs", C.c_int32), ("b_rs", C.c_int32), ("b_cs", C.c_int32), ("alpha", C.c_float),
+                ("type", C.c_int32)]
+
+
 class StateHost(C.Structure):
     _fields_ = [(n, c_p) for n in (
         "pos_x", "pos_y", "vel_x", "vel_y", "ang", "prev_dist", "alive", "time_step", "num_hit",
@@ -97,6 +103,8 @@ EXPORTS = {
     "fa_ppo_grad_floats": (C.c_int64, []),
     "fa_ppo_grad_scratch": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "fa_policy_weight_t_floats": (C.c_int64, []),
+    "fa_run_tasks": (C.c_int, [c_p, C.c_int32, c_p]),
+    "fa_pack_weights": (C.c_int, [c_p, c_p, c_p, c_p]),
     "fa_get_state": (C.c_int, [c_p, C.POINTER(StateHost)]),
     "fa_set_state": (C.c_int, [c_p, C.POINTER(StateHost)]),
     "fa_selftest_math": (C.c_int, [c_p, C.c_uint64, C.c_uint64, c_p]),

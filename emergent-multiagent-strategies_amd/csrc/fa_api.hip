@@ -627,6 +627,18 @@ int fa_ppo_grad(const fa_ppo_grad_io *io, void *stream) {
     return FA_OK;
 }
 
+int fa_run_tasks(const fa_task *tasks, int32_t n, void *stream) {
+    if (!tasks || n < 0) return fail(FA_ERR_INVALID, "fa_run_tasks: null task list");
+    FA_HIP(fa_launch_tasks(tasks, n, static_cast<hipStream_t>(stream)));
+    return FA_OK;
+}
+
+int fa_pack_weights(const float *plain, float *weights, float *weights_t, void *stream) {
+    if (!plain || !weights || !weights_t) return fail(FA_ERR_INVALID, "fa_pack_weights: null argument");
+    FA_HIP(fa_launch_pack(plain, weights, weights_t, static_cast<hipStream_t>(stream)));
+    return FA_OK;
+}
+
 static int attend_check(const char *who, int B, int n, int nk, int width) {
     if (B < 1 || n < 1 || nk < 1 || n > FA_POLICY_MAX_TEAM || nk > FA_POLICY_MAX_TEAM)
         return fail(FA_ERR_INVALID, std::string(who) + ": need B >= 1 and 1 <= n, nk <= 8");

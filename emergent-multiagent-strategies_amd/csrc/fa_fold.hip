@@ -1,0 +1,73 @@
+// fa_fold.hip -- the small dense algebra around the fused PPO step, as two kernels instead of ~120 tiny
+// PyTorch launches per optimizer step (each ~5 us inside a hipGraph: a third of the step):
+//   * fa_task_kernel: a list of strided matrix products / copies C = alpha * op(A) op(B), one workgroup per
+//     task.  The host (mpnn_pack.FlatPolicy) writes the lists once: FOLD the module's parameters into the
+//     kernel-facing matrices (A_o = norm W_key W_query^T, ... see mpnn_pack.py) and UNFOLD the gradients of
+//     those matrices back onto the parameters (the chain rule of the same products).
+//   * fa_pack_kernel: plain row-major matrices -> the MFMA B-operand lane order of fa_policy.h, forward and
+//     transposed packs in one launch.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "fa_train.h"
+
+namespace {
+// C[i*ldc + j] = alpha * sum_k A[i*a_rs + k*a_cs] * B[k*b_rs + j*b_cs]   (type 0)
+// C[i*ldc + j] = alpha * A[i*a_rs + j*a_cs]                               (type 1)
+__global__ __launch_bounds__(256) void fa_task_kernel(const fa_task *__restrict__ tasks) {
+    const fa_task t = tasks[blockIdx.x];
+    const int total = t.M * t.N;
+    for (int o = threadIdx.x; o < total; o += 256) {
+        const int i = o / t.N, j = o - i * t.N;
+        float acc;
+        if (t.type == 1) {
+            acc = t.A[(size_t)i * t.a_rs + (size_t)j * t.a_cs];
+        } else {
+            const float *a = t.A + (size_t)i * t.a_rs, *b = t.B + (size_t)j * t.b_cs;
+            acc = 0.0f;
+            for (int k = 0; k < t.K; ++k) acc = fmaf(a[(size_t)k * t.a_cs], b[(size_t)k * t.b_rs], acc);
+        }
+        t.C[(size_t)i * t.ldc + j] = t.alpha * acc;
+    }
+}
+
+struct PackSpec { int src, K, C, dst; }; // plain offset, rows, columns, packed offset
+__device__ __forceinline__ void pack_one(const float *__restrict__ plain, float *__restrict__ out, PackSpec s, bool transpose, int idx) {
+    // element idx of the packed (K x C) matrix W (or of W^T when `transpose`): float4 index (cb*K/8 + t4)*64 + lane,
+    // component q  <->  W[k = (lane >> 5)*K/2 + 4*t4 + q][c = 32*cb + (lane & 31)]
+    const int K = transpose ? s.C : s.K, C = transpose ? s.K : s.C;
+    const int q = idx & 3, f4 = idx >> 2, lane = f4 & 63, rest = f4 >> 6, t4 = rest % (K / 8), cb = rest / (K / 8);
+    const int k = (lane >> 5) * (K / 2) + 4 * t4 + q, c = 32 * cb + (lane & 31);
+    out[s.dst + idx] = transpose ? plain[s.src + c * s.C + k] : plain[s.src + k * s.C + c];
+}
+__global__ __launch_bounds__(256) void fa_pack_kernel(const float *__restrict__ plain, float *__restrict__ w, float *__restrict__ wt) {
+    const PackSpec fwd[6] = {{FA_POFF_AO, 64, 64, FA_POFF_AO}, {FA_POFF_BO, 64, 64, FA_POFF_BO}, {FA_POFF_AM, 128, 128, FA_POFF_AM},
+                             {FA_POFF_W7, 256, 128, FA_POFF_W7}, {FA_POFF_W8, 128, 256, FA_POFF_W8}, {FA_POFF_W9, 256, 32, FA_POFF_W9}};
+    const int tdst[6] = {FA_TOFF_AOT, FA_TOFF_BOT, FA_TOFF_AMT, FA_TOFF_W7T, FA_TOFF_W8T, FA_TOFF_W9T};
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    // the un-packed sections (encoders, biases) are copied as they are
+    if (g < FA_POFF_AO) w[g] = plain[g];
+    if (g >= FA_POFF_BU && g < FA_POFF_BU + 128) w[g] = plain[g];
+    if (g >= FA_POFF_B8 && g < FA_POFF_B8 + 256) w[g] = plain[g];
+    if (g >= FA_POFF_B9 && g < FA_POFF_B9 + 32) w[g] = plain[g];
+#pragma unroll
+    for (int m = 0; m < 6; ++m) {
+        const int n = fwd[m].K * fwd[m].C;
+        if (g >= fwd[m].src && g < fwd[m].src + n) {
+            pack_one(plain, w, fwd[m], false, g - fwd[m].src);
+            PackSpec ts = fwd[m];
+            ts.dst = tdst[m];
+            pack_one(plain, wt, ts, true, g - fwd[m].src);
+        }
+    }
+}
+} // namespace
+
+hipError_t fa_launch_tasks(const fa_task *tasks, int n, hipStream_t st) {
+    if (n > 0) hipLaunchKernelGGL(fa_task_kernel, dim3(n), dim3(256), 0, st, tasks);
+    return hipGetLastError();
+}
+hipError_t fa_launch_pack(const float *plain, float *w, float *wt, hipStream_t st) {
+    hipLaunchKernelGGL(fa_pack_kernel, dim3((FA_POLICY_WEIGHT_FLOATS + 255) / 256), dim3(256), 0, st, plain, w, wt);
+    return hipGetLastError();
+}

@@ -5,6 +5,7 @@
 #include <stdint.h>
 
 #include "fa_policy.h"
+#include "fortattack.h"
 
 #define FA_TR_ROWS 64 // (env, agent) rows per workgroup tile: four 64 x 132-float LDS buffers
 
@@ -46,6 +47,8 @@ struct FaTrainArgs {
     int32_t clipped_value_loss;
 };
 
+hipError_t fa_launch_tasks(const fa_task *tasks, int n, hipStream_t st);
+hipError_t fa_launch_pack(const float *plain, float *w, float *wt, hipStream_t st);
 int fa_train_tile_envs(int G, int A);
 hipError_t fa_launch_train(const FaTrainArgs &a, hipStream_t st);
 // out[k] = sum over tiles of slabs[t][k], k < FA_SLAB_FLOATS (fixed order: reproducible)

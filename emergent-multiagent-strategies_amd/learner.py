@@ -75,7 +75,7 @@ class GraphedPPOStep(object):
     before the first real step."""
 
     def __init__(self, pol, opt, own_sl, opp_sl, rows, mb, clip_param, value_loss_coef, entropy_coef, max_grad_norm,
-                 clipped_value_loss, group, fused=False):
+                 clipped_value_loss, group, fused=False, flat=None):
         self.pol, self.opt, self.group, self.world = pol, opt, group, _world(group)
         self.params = [p for p in pol.parameters()]
         self.static = [torch.empty((mb,) + tuple(r.shape[1:]), dtype=r.dtype, device=r.device) for r in rows]
@@ -88,37 +88,36 @@ class GraphedPPOStep(object):
             N = rows[0].shape[1]
             n_own = own_sl.stop - own_sl.start
             team, G = (0, n_own) if own_sl.start == 0 else (1, N - n_own)
-            self._w = torch.zeros(mpnn_pack.WEIGHT_FLOATS, device=dev)
-            self._wt = torch.zeros(mpnn_pack.TRANS_FLOATS, device=dev)
+            self.fp = flat if flat is not None else mpnn_pack.FlatPolicy(pol)
             self._scale = torch.zeros(2, device=dev)
             self._out = torch.zeros(mpnn_pack.SLAB_FLOATS, device=dev)
             self._scratch = None
-            keys = list(mpnn_pack.PLAIN_SHAPES)
             inv_count = 1.0 / (mb * n_own)
+            PF = mpnn_pack.PF_FLOATS
 
         def fused_fwd_bwd():
-            """kernel-facing matrices from the parameters (inside autograd) -> packed -> fa_ppo_grad -> the chain
-            rule back to the parameters by torch.autograd.backward on those matrices"""
+            """parameters -> weight packs (fold: 3 launches) -> fa_ppo_grad (2) -> gradients of the parameters (unfold:
+            2): no PyTorch autograd, no PyTorch GEMM; what is left to torch is the alive-mask mean, clip and Adam"""
             obs_b, act_b, vp_b, ret_b, olp_b, adv_b = self.static
-            P = mpnn_pack.kernel_params(pol)
-            mpnn_pack.pack_from_params(P, self._w, self._wt)
+            fp = self.fp
+            w, wt = fp.fold_pack()
             mm = obs_b[:, own_sl, 0].mean()
             mmp = torch.where(mm != 0, mm, torch.ones_like(mm))
             # one rank: every loss divided by the mask mean here; several: after the all-reduce (finish())
             self._scale.copy_(torch.stack((inv_count / mmp if world == 1 else torch.full_like(mmp, inv_count), mmp)))
-            _, self._scratch = ppo_grad(obs_b, act_b, vp_b, ret_b, olp_b, adv_b, self._w, self._wt, self._scale, team, G,
+            _, self._scratch = ppo_grad(obs_b, act_b, vp_b, ret_b, olp_b, adv_b, w, wt, self._scale, team, G,
                                         N - G, clip_param, value_loss_coef, entropy_coef, clipped_value_loss,
                                         scratch=self._scratch, out=self._out)
-            opt.zero_grad(set_to_none=True)
-            g = mpnn_pack.split_plain(self._out)
-            torch.autograd.backward([P[k] for k in keys], [g[k] for k in keys])
+            fp.attach_grads()               # every parameter's .grad is its slice of fp.gflat
+            fp.unfold(self._out)
             sums = self._out[mpnn_pack.WEIGHT_FLOATS:mpnn_pack.WEIGHT_FLOATS + 3] * inv_count
             if not clipped_value_loss:      # the scalar-MSE value loss is not masked (ppo.py:178-182)
                 sums = sums * torch.stack((mmp, torch.ones_like(mmp), torch.ones_like(mmp)))
             if world == 1:
                 return sums / mmp, None
-            grads = [p.grad for p in self.params if p.grad is not None]
-            return sums, torch.cat([gr.reshape(-1) for gr in grads] + [sums, mm.reshape(1)])
+            fp.gflat[PF:PF + 3].copy_(sums)  # the flat gradient buffer carries the loss sums and the mask mean
+            fp.gflat[PF + 3].copy_(mm)
+            return sums, fp.gflat
 
         def fwd_bwd():
             if self.fused:
@@ -135,7 +134,12 @@ class GraphedPPOStep(object):
             return losses, torch.cat([g.reshape(-1) for g in grads] + [losses, out[3].detach().reshape(1)])
 
         def finish(losses, flat):
-            if flat is not None:                              # after the all-reduce (sum over ranks)
+            if flat is not None and self.fused:               # in place: flat IS the gradients (fp.gflat)
+                flat.div_(world)
+                mm = flat[PF + 3].clone()
+                flat.div_(torch.where(mm != 0, mm, torch.ones_like(mm)))
+                losses = flat[PF:PF + 3]
+            elif flat is not None:                            # after the all-reduce (sum over ranks)
                 flat = flat / world
                 mm = flat[-1]
                 flat = flat / torch.where(mm != 0, mm, torch.ones_like(mm))
@@ -145,7 +149,11 @@ class GraphedPPOStep(object):
                     if p.grad is not None:
                         p.grad.copy_(flat[off:off + p.grad.numel()].view_as(p.grad))
                         off += p.grad.numel()
-            nn.utils.clip_grad_norm_(self.params, max_grad_norm)
+            if self.fused:      # the parameters' gradients are one buffer: the global norm is one reduction
+                gall = self.fp.gflat[:PF]
+                gall.mul_(torch.clamp(max_grad_norm / (torch.linalg.vector_norm(gall) + 1e-6), max=1.0))
+            else:
+                nn.utils.clip_grad_norm_(self.params, max_grad_norm)
             opt.step()
             return losses.clone()
 
@@ -236,7 +244,8 @@ def joint_ppo_update(pol, opt, own_sl, opp_sl, rows, clip_param, ppo_epoch, num_
                 if key not in graphs:
                     graphs[key] = GraphedPPOStep(pol, opt, own_sl, opp_sl, rows, mb, clip_param, value_loss_coef,
                                                  entropy_coef, max_grad_norm, clipped_value_loss, group,
-                                                 fused=graphs.get("fused", False) and mpnn_pack.supported(pol))
+                                                 fused=graphs.get("fused", False) and mpnn_pack.supported(pol),
+                                                 flat=graphs.get(("flat", id(pol))))
                 acc += graphs[key].run(rows, idx)
                 continue
             obs_b = obs_f[idx]
@@ -294,6 +303,7 @@ class BatchedLearner(object):
         if update_backend not in ("auto", "fused", "torch"):
             raise ValueError("update_backend must be 'auto', 'fused' or 'torch'")
         self._update_graphs = {"fused": update_backend != "torch"} if use_graph else None
+        self._update_backend = update_backend
         self.storage = JointRolloutStorage(num_steps, self.E, self.N, device=self.device)
         eng.bind_storage(self.storage)
         self.team_slices = [slice(0, self.G), slice(self.G, self.N)]
@@ -310,7 +320,13 @@ class BatchedLearner(object):
             raise ValueError("the fused policy kernel needs hidden_dim = 128 and teams of <= 8 agents")
         self.policy_backend = "hip" if (policy_backend != "torch" and hip_ok) else "torch"
         # packed weights of the two policies (rewritten in place whenever the parameters may have moved)
-        self._packed = [mpnn_pack.pack_policy(p) for p in self.policies] if self.policy_backend == "hip" else None
+        # the parameters of each policy as one flat buffer + fold / unfold task lists (mpnn_pack.FlatPolicy): the
+        # rollout's weight packs and the fused update's gradients come from / go to it without a PyTorch op
+        self._flat = [mpnn_pack.FlatPolicy(p) for p in self.policies] if (hip_ok and self.device.type == "cuda") else None
+        self._packed = [fp.w for fp in self._flat] if (self.policy_backend == "hip" and self._flat) else None
+        if self._flat:
+            for fp in self._flat:
+                fp.fold_pack()
         self.sample_seed = int(torch.initial_seed() if sample_seed is None else sample_seed) & ((1 << 63) - 1)
         self._rollout_counter = torch.zeros(1, dtype=torch.int64, device=self.device)
 
@@ -495,9 +511,9 @@ class BatchedLearner(object):
     def refresh_policy_weights(self):
         """Bring every derived copy of the parameters up to date IN PLACE (captured graphs read them):
         the fused kernel's packed buffers, the torch path's fused / stacked operands."""
-        if self._packed is not None:
-            for pol, buf in zip(self.policies, self._packed):
-                mpnn_pack.pack_policy(pol, out=buf)
+        if self._flat:
+            for fp in self._flat:
+                fp.fold_pack()
         for pol in self.policies + list(self.attacker_pool):
             pol.refresh_fused_weights()
         if self._twin() is not None:

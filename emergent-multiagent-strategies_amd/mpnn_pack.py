@@ -184,3 +184,151 @@ def folded_ppo_reference(P, obs, own_sl, opp_sl, action, value_pred, ret, old_lo
         vl = 0.5 * (ret - value).pow(2).mean()
     en = (ent * mask).mean()
     return vl * c_value + al - en * c_entropy, vl, al, en, mask.mean()
+
+
+# ---- the module's parameters as ONE flat buffer + the fold / unfold task lists (csrc/fa_fold.hip) -----------------
+# (name, accessor, offset) in floats; what the forward uses (oppUpdate is created but never used, mpnn.py:44-45)
+_PF = (("ENC_W", lambda p: p.encoder[0].weight, 0), ("ENC_B", lambda p: p.encoder[0].bias, 384),
+       ("OENC_W", lambda p: p.oppEncoder[0].weight, 448), ("OENC_B", lambda p: p.oppEncoder[0].bias, 832),
+       ("OQ", lambda p: p.oppAttn.W_query, 896), ("OK", lambda p: p.oppAttn.W_key, 4992),
+       ("OV", lambda p: p.oppAttn.W_val, 9088), ("OO", lambda p: p.oppAttn.W_out, 13184),
+       ("MQ", lambda p: p.messages.W_query, 17280), ("MK", lambda p: p.messages.W_key, 33664),
+       ("MV", lambda p: p.messages.W_val, 50048), ("MO", lambda p: p.messages.W_out, 66432),
+       ("UW", lambda p: p.update[0].weight, 82816), ("UB", lambda p: p.update[0].bias, 115584),
+       ("V0W", lambda p: p.value_head[0].weight, 115712), ("V0B", lambda p: p.value_head[0].bias, 132096),
+       ("V2W", lambda p: p.value_head[2].weight, 132224), ("V2B", lambda p: p.value_head[2].bias, 132352),
+       ("P0W", lambda p: p.policy_head[0].weight, 132356), ("P0B", lambda p: p.policy_head[0].bias, 148740),
+       ("DW", lambda p: p.dist.linear.weight, 148868), ("DB", lambda p: p.dist.linear.bias, 149892))
+PF_FLOATS = 149900
+
+
+class FlatPolicy(object):
+    """An MPNN whose (used) parameters live in one flat device buffer `pflat` -- the module's tensors become views
+    of it, their .grad views of `gflat` -- plus the task lists that turn `pflat` into the fused kernels' weight
+    packs (`fold_pack`: 3 launches) and the kernel's plain-layout gradients into `gflat` (`unfold`: 2 launches):
+    the folding algebra of this file's header and its chain rule, without a PyTorch op.  torch optimizers and
+    clip_grad_norm_ work on the module's parameters as before."""
+
+    def __init__(self, pol):
+        import ctypes as C
+        from . import _lib
+        if not supported(pol):
+            raise ValueError("FlatPolicy needs hidden_dim = 128, 6 inputs, 8 actions and teams of <= 8")
+        self.pol, self._lib, self._C = pol, _lib, C
+        dev = pol.update[0].weight.device
+        z = lambda n: torch.zeros(n, device=dev, dtype=torch.float32)
+        self.pflat, self.gflat = z(PF_FLOATS), z(PF_FLOATS + 8)     # + 8: room for loss sums in one all-reduce
+        self.off = {}
+        with torch.no_grad():
+            for name, get, off in _PF:
+                p = get(pol)
+                n = p.numel()
+                self.pflat[off:off + n].copy_(p.data.reshape(-1))
+                p.data = self.pflat[off:off + n].view(p.shape)
+                self.off[name] = off
+        self.plain, self.mscr, self.dmscr = z(WEIGHT_FLOATS), z(128 * 128), z(128 * 128)
+        self.w, self.wt = z(WEIGHT_FLOATS), z(TRANS_FLOATS)
+        self._fold = [self._tasks(self._fold_stage1()), self._tasks(self._fold_stage2())]
+        self._unfold = None
+        self.attach_grads()
+
+    def attach_grads(self):
+        """(Re)point every parameter's .grad at its slice of gflat."""
+        for name, get, off in _PF:
+            p = get(self.pol)
+            p.grad = self.gflat[off:off + p.numel()].view(p.shape)
+
+    # -- task lists ---------------------------------------------------------------------------------------------
+    def _tasks(self, items):
+        C, L = self._C, self._lib
+        arr = (L.Task * len(items))()
+        for t, d in zip(arr, items):
+            t.C, t.A, t.B = d["C"], d["A"], d.get("B", 0)
+            t.ldc, t.M, t.N, t.K = d["ldc"], d["M"], d["N"], d.get("K", 1)
+            t.a_rs, t.a_cs, t.b_rs, t.b_cs = d["a"][0], d["a"][1], d.get("b", (0, 0))[0], d.get("b", (0, 0))[1]
+            t.alpha, t.type = d.get("alpha", 1.0), 0 if "B" in d else 1
+        buf = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.pflat.device)
+        return buf, len(items)
+
+    def _run(self, tl):
+        L, C = self._lib, self._C
+        L.check(L.load().fa_run_tasks(tl[0].data_ptr(), tl[1], C.c_void_p(torch.cuda.current_stream().cuda_stream)), "fa_run_tasks")
+
+    @staticmethod
+    def _mm(Cp, ldc, M, N, K, Ap, a, Bp, b, alpha=1.0, split=1):
+        """C (M x N) = alpha * A B as `split` row chunks (one workgroup each)."""
+        out, rows = [], M // split
+        for s in range(split):
+            out.append(dict(C=Cp + 4 * s * rows * ldc, ldc=ldc, M=rows, N=N, K=K, A=Ap + 4 * s * rows * a[0], a=a, B=Bp, b=b, alpha=alpha))
+        return out
+
+    def _fold_stage1(self):
+        th, P, o, po = self.pflat.data_ptr(), self.plain.data_ptr(), self.off, POFF
+        a = lambda name, extra=0: th + 4 * (o[name] + extra)
+        c = lambda name, extra=0: P + 4 * (po[name] + extra)
+        pol = self.pol
+        cp = lambda Cp, ldc, M, N, Ap, ars, acs: dict(C=Cp, ldc=ldc, M=M, N=N, A=Ap, a=(ars, acs))
+        t = [cp(c("WE"), 64, 6, 64, a("ENC_W"), 1, 6), cp(c("BE"), 64, 1, 64, a("ENC_B"), 0, 1),
+             cp(c("WOE"), 64, 6, 64, a("OENC_W"), 1, 6), cp(c("BOE"), 64, 1, 64, a("OENC_B"), 0, 1),
+             cp(c("W7"), 128, 128, 128, a("UW"), 1, 256), cp(c("BU"), 128, 1, 128, a("UB"), 0, 1),
+             cp(c("W8"), 256, 128, 128, a("P0W"), 1, 128), cp(c("W8", 128), 256, 128, 128, a("V0W"), 1, 128),
+             cp(c("B8"), 256, 1, 128, a("P0B"), 0, 1), cp(c("B8", 128), 256, 1, 128, a("V0B"), 0, 1),
+             cp(c("W9"), 32, 128, 8, a("DW"), 1, 128), cp(c("W9", 128 * 32 + 8), 32, 128, 1, a("V2W"), 1, 0),
+             cp(c("B9"), 32, 1, 8, a("DB"), 0, 1), cp(c("B9", 8), 32, 1, 1, a("V2B"), 0, 1)]
+        t += self._mm(c("AO"), 64, 64, 64, 64, a("OK"), (64, 1), a("OQ"), (1, 64), pol.oppAttn.norm_factor)
+        t += self._mm(c("BO"), 64, 64, 64, 64, a("OV"), (64, 1), a("OO"), (64, 1))
+        t += self._mm(c("AM"), 128, 128, 128, 128, a("MQ"), (128, 1), a("MK"), (1, 128), pol.messages.norm_factor, split=4)
+        t += self._mm(self.mscr.data_ptr(), 128, 128, 128, 128, a("MV"), (128, 1), a("MO"), (128, 1), split=4)
+        return t
+
+    def _fold_stage2(self):   # W7[128:] = (W_val W_out) update.weight[:, 128:]^T
+        th, P = self.pflat.data_ptr(), self.plain.data_ptr()
+        return self._mm(P + 4 * (POFF["W7"] + 128 * 128), 128, 128, 128, 128, self.mscr.data_ptr(), (128, 1),
+                        th + 4 * (self.off["UW"] + 128), (1, 256), split=4)
+
+    def fold_pack(self):
+        """parameters -> plain kernel-facing matrices -> forward + transposed packs (self.w, self.wt)."""
+        L, C = self._lib, self._C
+        self._run(self._fold[0])
+        self._run(self._fold[1])
+        L.check(L.load().fa_pack_weights(self.plain.data_ptr(), self.w.data_ptr(), self.wt.data_ptr(),
+                                         C.c_void_p(torch.cuda.current_stream().cuda_stream)), "fa_pack_weights")
+        return self.w, self.wt
+
+    def _build_unfold(self, gp):
+        """gp: data pointer of the plain-layout gradient buffer (the fa_ppo_grad slab sum)."""
+        th, g, o, po = self.pflat.data_ptr(), self.gflat.data_ptr(), self.off, POFF
+        a = lambda name, extra=0: th + 4 * (o[name] + extra)
+        gr = lambda name, extra=0: g + 4 * (o[name] + extra)
+        d = lambda name, extra=0: gp + 4 * (po[name] + extra)
+        pol = self.pol
+        no, nm = pol.oppAttn.norm_factor, pol.messages.norm_factor
+        cp = lambda Cp, ldc, M, N, Ap, ars, acs: dict(C=Cp, ldc=ldc, M=M, N=N, A=Ap, a=(ars, acs))
+        D = d("W7", 128 * 128)                      # dL/d(W7[128:]) (128 x 128)
+        s1 = [cp(gr("ENC_W"), 6, 64, 6, d("WE"), 1, 64), cp(gr("ENC_B"), 64, 1, 64, d("BE"), 0, 1),
+              cp(gr("OENC_W"), 6, 64, 6, d("WOE"), 1, 64), cp(gr("OENC_B"), 64, 1, 64, d("BOE"), 0, 1),
+              cp(gr("UW"), 256, 128, 128, d("W7"), 1, 128), cp(gr("UB"), 128, 1, 128, d("BU"), 0, 1),
+              cp(gr("P0W"), 128, 128, 128, d("W8"), 1, 256), cp(gr("V0W"), 128, 128, 128, d("W8", 128), 1, 256),
+              cp(gr("P0B"), 128, 1, 128, d("B8"), 0, 1), cp(gr("V0B"), 128, 1, 128, d("B8", 128), 0, 1),
+              cp(gr("DW"), 128, 8, 128, d("W9"), 1, 32), cp(gr("V2W"), 128, 1, 128, d("W9", 128 * 32 + 8), 0, 32),
+              cp(gr("DB"), 8, 1, 8, d("B9"), 0, 1), cp(gr("V2B"), 1, 1, 1, d("B9", 8), 0, 1)]
+        s1 += self._mm(gr("OK"), 64, 64, 64, 64, d("AO"), (64, 1), a("OQ"), (64, 1), no)        # dW_key = norm dA_o W_query
+        s1 += self._mm(gr("OQ"), 64, 64, 64, 64, d("AO"), (1, 64), a("OK"), (64, 1), no)        # dW_query = norm dA_o^T W_key
+        s1 += self._mm(gr("OV"), 64, 64, 64, 64, d("BO"), (64, 1), a("OO"), (1, 64))            # dW_val = dB_o W_out^T
+        s1 += self._mm(gr("OO"), 64, 64, 64, 64, a("OV"), (1, 64), d("BO"), (64, 1))            # dW_out = W_val^T dB_o
+        s1 += self._mm(gr("MQ"), 128, 128, 128, 128, d("AM"), (128, 1), a("MK"), (128, 1), nm, split=4)
+        s1 += self._mm(gr("MK"), 128, 128, 128, 128, d("AM"), (1, 128), a("MQ"), (128, 1), nm, split=4)
+        s1 += self._mm(self.dmscr.data_ptr(), 128, 128, 128, 128, D, (128, 1), a("UW", 128), (256, 1), split=4)   # dM = D Wu2
+        s1 += self._mm(gr("UW", 128), 256, 128, 128, 128, D, (1, 128), self.mscr.data_ptr(), (128, 1), split=4)   # dWu2 = D^T M
+        dm = self.dmscr.data_ptr()
+        s2 = self._mm(gr("MV"), 128, 128, 128, 128, dm, (128, 1), a("MO"), (1, 128), split=4)   # dW_val = dM W_out^T
+        s2 += self._mm(gr("MO"), 128, 128, 128, 128, a("MV"), (1, 128), dm, (128, 1), split=4)  # dW_out = W_val^T dM
+        return [self._tasks(s1), self._tasks(s2)]
+
+    def unfold(self, grads_plain):
+        """plain-layout gradients of the kernel-facing matrices (a FA_SLAB buffer) -> gflat (== every parameter's
+        .grad): the chain rule of the fold.  Uses M = W_val W_out of the LAST fold_pack()."""
+        if self._unfold is None or self._unfold[2] != grads_plain.data_ptr():
+            self._unfold = self._build_unfold(grads_plain.data_ptr()) + [grads_plain.data_ptr()]
+        self._run(self._unfold[0])
+        self._run(self._unfold[1])

@@ -319,6 +319,24 @@ int64_t fa_ppo_grad_floats(void);
 int fa_ppo_grad_scratch(int32_t B, int32_t num_guards, int32_t num_attackers, int64_t *slab_floats, int64_t *hsave_floats);
 int64_t fa_policy_weight_t_floats(void);
 
+/* The small dense algebra around fa_ppo_grad -- building the kernel-facing matrices from the module's
+ * parameters and carrying their gradients back (products of 64..128-wide matrices, transposes, slices) -- as a
+ * list of strided tasks run by ONE launch (one workgroup per task), and the packing of the plain matrices
+ * into fa_policy_act's layout (forward and transposed) by another.  type 0: C[i*ldc + j] = alpha * sum_k
+ * A[i*a_rs + k*a_cs] * B[k*b_rs + j*b_cs]; type 1: C[i*ldc + j] = alpha * A[i*a_rs + j*a_cs] (i < M, j < N).
+ * `tasks` is a DEVICE array; the pointers inside are device pointers. */
+typedef struct fa_task {
+    float *C;
+    const float *A, *B;
+    int32_t ldc, M, N, K, a_rs, a_cs, b_rs, b_cs;
+    float alpha;
+    int32_t type;
+} fa_task;
+int fa_run_tasks(const fa_task *tasks, int32_t n, void *stream);
+/* plain: fa_policy_weight_floats() floats, row-major matrices at the FA_POFF_* offsets (csrc/fa_policy.h) ->
+ * weights (fa_policy_weight_floats()) and weights_t (fa_policy_weight_t_floats()) */
+int fa_pack_weights(const float *plain, float *weights, float *weights_t, void *stream);
+
 /* ---- state access (synchronous; tests / checkpoint) ------------------------------ */
 int fa_get_state(fa_env *env, const fa_state_host *out);
 int fa_set_state(fa_env *env, const fa_state_host *in); /* pos/vel/ang/prev_dist/alive/time_step/num_hit/

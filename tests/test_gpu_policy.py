@@ -224,3 +224,46 @@ def test_fused_ppo_grad_matches_torch_autograd(fa, G, A, team, B, clipped):
         worst[k] = float((gk - ref).abs().max()) / scale_k
     print({k: "%.1e" % v for k, v in worst.items()})
     assert max(worst.values()) < 2e-3, worst
+
+
+@pytest.mark.parametrize("G,A", [(3, 3), (5, 2)])
+def test_flat_policy_fold_and_unfold_match_torch(fa, G, A):
+    """mpnn_pack.FlatPolicy: parameters as one flat buffer; fold_pack (task-list kernel + pack kernel) == the torch
+    packing of kernel_params(); unfold == torch autograd's chain rule through kernel_params(); the module still
+    computes the same function and optimizers see the same parameters."""
+    from emergent_multiagent_strategies_amd import mpnn_pack as mp_
+    pols, _ = _policies(fa, G, A, 21)
+    pol = pols[0]
+    obs = _obs(64, G + A, 5)
+    with torch.no_grad():
+        before = pol.logits_value(obs[:, :G], obs[:, G:])
+    P = mp_.kernel_params(pol)
+    w_ref, wt_ref = torch.zeros(mp_.WEIGHT_FLOATS, device="cuda"), torch.zeros(mp_.TRANS_FLOATS, device="cuda")
+    mp_.pack_from_params(P, w_ref, wt_ref)
+    fp = mp_.FlatPolicy(pol)
+    with torch.no_grad():
+        after = pol.logits_value(obs[:, :G], obs[:, G:])
+    assert torch.equal(before[0], after[0]) and torch.equal(before[1], after[1])
+    w, wt = fp.fold_pack()
+    assert (w - w_ref).abs().max() <= 2e-6 * max(1.0, float(w_ref.abs().max()))
+    assert (wt - wt_ref).abs().max() <= 2e-6 * max(1.0, float(wt_ref.abs().max()))
+    # chain rule: random plain-layout gradients through both routes
+    gplain = torch.randn(mp_.SLAB_FLOATS, device="cuda") * 0.1
+    views = mp_.split_plain(gplain)
+    views["W9"][:, 9:] = 0
+    views["B9"][9:] = 0
+    pol.zero_grad(set_to_none=True)
+    P = mp_.kernel_params(pol)
+    torch.autograd.backward([P[k] for k in mp_.PLAIN_SHAPES], [views[k] for k in mp_.PLAIN_SHAPES])
+    ref = {n: p.grad.clone() for n, p in pol.named_parameters() if p.grad is not None}
+    fp.attach_grads()
+    fp.unfold(gplain)
+    torch.cuda.synchronize()
+    for n, p in pol.named_parameters():
+        if n in ref:
+            assert (p.grad - ref[n]).abs().max() <= 5e-6 * max(1.0, float(ref[n].abs().max())), n
+    # an optimizer step through the views moves the flat buffer
+    opt = torch.optim.SGD(pol.parameters(), lr=0.1)
+    snap = fp.pflat.clone()
+    opt.step()
+    assert not torch.equal(snap, fp.pflat) and pol.update[0].weight.data_ptr() == fp.pflat[mp_._PF[12][2]:].data_ptr()
