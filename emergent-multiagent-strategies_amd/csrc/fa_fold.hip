@@ -11,21 +11,32 @@
 
 #include "fa_train.h"
 
+#define FA_TASK_SLICES 32
 namespace {
 // C[i*ldc + j] = alpha * sum_k A[i*a_rs + k*a_cs] * B[k*b_rs + j*b_cs]   (type 0)
 // C[i*ldc + j] = alpha * A[i*a_rs + j*a_cs]                               (type 1)
 __global__ __launch_bounds__(256) void fa_task_kernel(const fa_task *__restrict__ tasks) {
+    // blockIdx.y: FA_TASK_SLICES workgroups share a task's outputs (the largest, 128 x 128 x 128, is then 2 outputs
+    // of 128 terms per thread instead of 64: these launches are latency chains, not bandwidth)
     const fa_task t = tasks[blockIdx.x];
     const int total = t.M * t.N;
-    for (int o = threadIdx.x; o < total; o += 256) {
+    for (int o = blockIdx.y * 256 + threadIdx.x; o < total; o += 256 * FA_TASK_SLICES) {
         const int i = o / t.N, j = o - i * t.N;
         float acc;
         if (t.type == 1) {
             acc = t.A[(size_t)i * t.a_rs + (size_t)j * t.a_cs];
         } else {
             const float *a = t.A + (size_t)i * t.a_rs, *b = t.B + (size_t)j * t.b_cs;
-            acc = 0.0f;
-            for (int k = 0; k < t.K; ++k) acc = fmaf(a[(size_t)k * t.a_cs], b[(size_t)k * t.b_rs], acc);
+            float p0 = 0.0f, p1 = 0.0f, p2 = 0.0f, p3 = 0.0f; // four partial sums: four loads in flight per operand
+            int k = 0;
+            for (; k + 4 <= t.K; k += 4) {
+                p0 = fmaf(a[(size_t)k * t.a_cs], b[(size_t)k * t.b_rs], p0);
+                p1 = fmaf(a[(size_t)(k + 1) * t.a_cs], b[(size_t)(k + 1) * t.b_rs], p1);
+                p2 = fmaf(a[(size_t)(k + 2) * t.a_cs], b[(size_t)(k + 2) * t.b_rs], p2);
+                p3 = fmaf(a[(size_t)(k + 3) * t.a_cs], b[(size_t)(k + 3) * t.b_rs], p3);
+            }
+            for (; k < t.K; ++k) p0 = fmaf(a[(size_t)k * t.a_cs], b[(size_t)k * t.b_rs], p0);
+            acc = (p0 + p1) + (p2 + p3);
         }
         t.C[(size_t)i * t.ldc + j] = t.alpha * acc;
     }
@@ -64,7 +75,7 @@ __global__ __launch_bounds__(256) void fa_pack_kernel(const float *__restrict__ 
 } // namespace
 
 hipError_t fa_launch_tasks(const fa_task *tasks, int n, hipStream_t st) {
-    if (n > 0) hipLaunchKernelGGL(fa_task_kernel, dim3(n), dim3(256), 0, st, tasks);
+    if (n > 0) hipLaunchKernelGGL(fa_task_kernel, dim3(n, FA_TASK_SLICES), dim3(256), 0, st, tasks);
     return hipGetLastError();
 }
 hipError_t fa_launch_pack(const float *plain, float *w, float *wt, hipStream_t st) {

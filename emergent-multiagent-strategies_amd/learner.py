@@ -75,7 +75,7 @@ class GraphedPPOStep(object):
     before the first real step."""
 
     def __init__(self, pol, opt, own_sl, opp_sl, rows, mb, clip_param, value_loss_coef, entropy_coef, max_grad_norm,
-                 clipped_value_loss, group, fused=False, flat=None):
+                 clipped_value_loss, group, fused=False):
         self.pol, self.opt, self.group, self.world = pol, opt, group, _world(group)
         self.params = [p for p in pol.parameters()]
         self.static = [torch.empty((mb,) + tuple(r.shape[1:]), dtype=r.dtype, device=r.device) for r in rows]
@@ -88,7 +88,7 @@ class GraphedPPOStep(object):
             N = rows[0].shape[1]
             n_own = own_sl.stop - own_sl.start
             team, G = (0, n_own) if own_sl.start == 0 else (1, N - n_own)
-            self.fp = flat if flat is not None else mpnn_pack.FlatPolicy(pol)
+            self.fp = mpnn_pack.FlatPolicy.of(pol)
             self._scale = torch.zeros(2, device=dev)
             self._out = torch.zeros(mpnn_pack.SLAB_FLOATS, device=dev)
             self._scratch = None
@@ -244,8 +244,7 @@ def joint_ppo_update(pol, opt, own_sl, opp_sl, rows, clip_param, ppo_epoch, num_
                 if key not in graphs:
                     graphs[key] = GraphedPPOStep(pol, opt, own_sl, opp_sl, rows, mb, clip_param, value_loss_coef,
                                                  entropy_coef, max_grad_norm, clipped_value_loss, group,
-                                                 fused=graphs.get("fused", False) and mpnn_pack.supported(pol),
-                                                 flat=graphs.get(("flat", id(pol))))
+                                                 fused=graphs.get("fused", False) and mpnn_pack.supported(pol))
                 acc += graphs[key].run(rows, idx)
                 continue
             obs_b = obs_f[idx]
@@ -322,7 +321,7 @@ class BatchedLearner(object):
         # packed weights of the two policies (rewritten in place whenever the parameters may have moved)
         # the parameters of each policy as one flat buffer + fold / unfold task lists (mpnn_pack.FlatPolicy): the
         # rollout's weight packs and the fused update's gradients come from / go to it without a PyTorch op
-        self._flat = [mpnn_pack.FlatPolicy(p) for p in self.policies] if (hip_ok and self.device.type == "cuda") else None
+        self._flat = [mpnn_pack.FlatPolicy.of(p) for p in self.policies] if (hip_ok and self.device.type == "cuda") else None
         self._packed = [fp.w for fp in self._flat] if (self.policy_backend == "hip" and self._flat) else None
         if self._flat:
             for fp in self._flat:

@@ -209,6 +209,20 @@ class FlatPolicy(object):
     the folding algebra of this file's header and its chain rule, without a PyTorch op.  torch optimizers and
     clip_grad_norm_ work on the module's parameters as before."""
 
+    @classmethod
+    def of(cls, pol):
+        """The FlatPolicy of `pol` (one per module: a second one would re-point the parameters away from the first)."""
+        fp = pol.__dict__.get("_flat_policy")
+        if fp is None or fp.pol is not pol or not fp.attached():
+            fp = cls(pol)
+            pol.__dict__["_flat_policy"] = fp
+        return fp
+
+    def attached(self):
+        """Whether the module's parameters are still views of pflat (a .to() / .data assignment detaches them)."""
+        base = self.pflat.data_ptr()
+        return all(get(self.pol).data_ptr() == base + 4 * off for _, get, off in _PF)
+
     def __init__(self, pol):
         import ctypes as C
         from . import _lib
