@@ -49,10 +49,10 @@ class PolicyIO(C.Structure):
 
 class PPOGradIO(C.Structure):
     _fields_ = [("obs", c_p), ("action", c_p), ("value_pred", c_p), ("ret", c_p), ("old_log_prob", c_p), ("adv", c_p),
-                ("weights", c_p), ("weights_t", c_p), ("scale", c_p), ("slabs", c_p), ("hsave", c_p), ("out", c_p),
+                ("idx", c_p), ("weights", c_p), ("weights_t", c_p), ("scale", c_p), ("slabs", c_p), ("hsave", c_p), ("out", c_p),
                 ("B", C.c_int32), ("num_guards", C.c_int32), ("num_attackers", C.c_int32), ("team", C.c_int32),
                 ("clip_param", C.c_float), ("value_loss_coef", C.c_float), ("entropy_coef", C.c_float),
-                ("clipped_value_loss", C.c_int32)]
+                ("clipped_value_loss", C.c_int32), ("normalize", C.c_int32)]
 
 
 class Task(C.Structure):
@@ -103,6 +103,8 @@ EXPORTS = {
     "fa_ppo_grad_floats": (C.c_int64, []),
     "fa_ppo_grad_scratch": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "fa_policy_weight_t_floats": (C.c_int64, []),
+    "fa_adam_step": (C.c_int, [c_p, c_p, c_p, c_p, c_p, c_p, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float,
+                               C.c_float, c_p, c_p]),
     "fa_run_tasks": (C.c_int, [c_p, C.c_int32, c_p]),
     "fa_pack_weights": (C.c_int, [c_p, c_p, c_p, c_p]),
     "fa_get_state": (C.c_int, [c_p, C.POINTER(StateHost)]),

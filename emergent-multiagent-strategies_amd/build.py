@@ -6,6 +6,7 @@ import subprocess
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB = os.path.join(CSRC, "libfortattack_hip.so")
+OBJ = os.path.join(CSRC, "_obj")            # objects + assembly of the last build (git-ignored)
 SOURCES = ["fa_step.hip", "fa_collect.hip", "fa_policy.hip", "fa_attend.hip", "fa_train.hip", "fa_fold.hip", "fa_api.hip"]
 # -ffp-contract=off: the fp64 step must evaluate every operation as the reference does
 # (no fused multiply-add); no -ffast-math for the same reason.
@@ -24,11 +25,40 @@ def needs_build():
     return any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in deps)
 
 
+def _load_lint():
+    import importlib.util           # by path: this file is also loaded stand-alone (__graft_entry__.build)
+    spec = importlib.util.spec_from_file_location("_fa_isa_lint", os.path.join(os.path.dirname(os.path.abspath(__file__)), "isa_lint.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def _compile_one(src, verbose):
+    """One translation unit -> object file, plus its gfx950 assembly through isa_lint (the same flags: the same code)."""
+    isa_lint = _load_lint()
+    base = os.path.join(OBJ, os.path.splitext(src)[0])
+    common = [hipcc()] + [f for f in FLAGS if f != "-shared"] + ["-I", os.path.join(ROOT, "include")]
+    cmd = common + ["-c", os.path.join(CSRC, src), "-o", base + ".o"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    subprocess.check_call(common + ["-S", "--cuda-device-only", os.path.join(CSRC, src), "-o", base + ".s"])
+    bad = isa_lint.lint(base + ".s")
+    if bad:
+        raise RuntimeError("isa_lint: %s has %d vector instruction(s) ahead of an exec restore (a misplaced live-range "
+                           "split: lanes that skipped the region lose the value), first: %s %s line %d: %s"
+                           % (src, len(bad), bad[0][0], bad[0][1], bad[0][2][0], bad[0][2][1]))
+    return base + ".o"
+
+
 def build(force=False, verbose=False):
     if not force and not needs_build():
         return LIB
-    cmd = [hipcc()] + FLAGS + ["-I", os.path.join(ROOT, "include")] + \
-        [os.path.join(CSRC, f) for f in SOURCES] + ["-o", LIB]
+    from concurrent.futures import ThreadPoolExecutor
+    os.makedirs(OBJ, exist_ok=True)
+    with ThreadPoolExecutor(max_workers=4) as pool:
+        objs = list(pool.map(lambda f: _compile_one(f, verbose), SOURCES))
+    cmd = [hipcc(), "--offload-arch=gfx950", "-fPIC", "-shared"] + objs + ["-o", LIB]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

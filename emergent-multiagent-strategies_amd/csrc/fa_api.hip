@@ -607,8 +607,8 @@ int fa_ppo_grad_scratch(int32_t B, int32_t G, int32_t A, int64_t *slab_floats, i
 int fa_ppo_grad(const fa_ppo_grad_io *io, void *stream) {
     if (!io) return fail(FA_ERR_INVALID, "fa_ppo_grad: null io");
     if (!io->obs || !io->action || !io->value_pred || !io->ret || !io->old_log_prob || !io->adv || !io->weights ||
-        !io->weights_t || !io->scale || !io->slabs || !io->hsave || !io->out)
-        return fail(FA_ERR_INVALID, "fa_ppo_grad: every pointer is required");
+        !io->weights_t || !io->slabs || !io->hsave || !io->out)
+        return fail(FA_ERR_INVALID, "fa_ppo_grad: every pointer but idx and scale is required");
     if (io->B < 1 || io->num_guards < 1 || io->num_attackers < 1 || io->num_guards > FA_POLICY_MAX_TEAM ||
         io->num_attackers > FA_POLICY_MAX_TEAM || (io->team != 0 && io->team != 1))
         return fail(FA_ERR_INVALID, "fa_ppo_grad: need B >= 1, teams of 1..8, team 0 or 1");
@@ -616,14 +616,30 @@ int fa_ppo_grad(const fa_ppo_grad_io *io, void *stream) {
     std::memset(&a, 0, sizeof(a));
     a.obs = io->obs; a.action = io->action; a.value_pred = io->value_pred; a.ret = io->ret;
     a.old_logp = io->old_log_prob; a.adv = io->adv; a.w = io->weights; a.wt = io->weights_t;
-    a.slabs = io->slabs; a.hsave = io->hsave; a.scale = io->scale;
+    a.slabs = io->slabs; a.hsave = io->hsave; a.scale = io->scale; a.idx = io->idx;
     a.B = io->B; a.G = io->num_guards; a.A = io->num_attackers; a.team = io->team;
     a.clip = io->clip_param; a.c_value = io->value_loss_coef; a.c_entropy = io->entropy_coef;
     a.clipped_value_loss = io->clipped_value_loss;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (!a.scale) { // the scale pair lives behind the loss sums of `out` (the reduction leaves it alone)
+        float *sc = io->out + FA_SLAB_LOSS + 8;
+        FA_HIP(fa_launch_mask_scale(a, io->normalize != 0, sc, s));
+        a.scale = sc;
+    }
     FA_HIP(fa_launch_train(a, s));
     const int et = fa_train_tile_envs(a.G, a.A);
     FA_HIP(fa_launch_train_reduce(io->slabs, (a.B + et - 1) / et, io->out, s));
+    return FA_OK;
+}
+
+int fa_adam_step(float *params, float *grads, float *exp_avg, float *exp_avg_sq, float *steps, const int32_t *seg,
+                 int32_t nseg, int32_t n, float lr, float beta1, float beta2, float eps, float max_grad_norm, float *coef,
+                 void *stream) {
+    if (!params || !grads || !exp_avg || !exp_avg_sq || !steps || !seg || !coef)
+        return fail(FA_ERR_INVALID, "fa_adam_step: null argument");
+    if (nseg < 1 || nseg > 1024 || n < 1) return fail(FA_ERR_INVALID, "fa_adam_step: need 1 <= nseg <= 1024 and n >= 1");
+    FA_HIP(fa_launch_adam(params, grads, exp_avg, exp_avg_sq, steps, seg, nseg, n, lr, beta1, beta2, eps, max_grad_norm, coef,
+                          static_cast<hipStream_t>(stream)));
     return FA_OK;
 }
 

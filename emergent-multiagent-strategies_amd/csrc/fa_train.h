@@ -33,6 +33,7 @@ struct FaTrainArgs {
     const float *ret;          // (B, N) returns
     const float *old_logp;     // (B, N) action_log_probs of the rollout
     const float *adv;          // (B, N) normalised advantages
+    const int64_t *idx;        // the minibatch: sample b is row idx[b] of the six arrays above (null: row b)
     const float *w;            // forward pack (FA_POFF_*)
     const float *wt;           // transposed pack (FA_TOFF_*)
     float *slabs;              // [tiles][FA_SLAB_FLOATS]
@@ -51,5 +52,13 @@ hipError_t fa_launch_tasks(const fa_task *tasks, int n, hipStream_t st);
 hipError_t fa_launch_pack(const float *plain, float *w, float *wt, hipStream_t st);
 int fa_train_tile_envs(int G, int A);
 hipError_t fa_launch_train(const FaTrainArgs &a, hipStream_t st);
-// out[k] = sum over tiles of slabs[t][k], k < FA_SLAB_FLOATS (fixed order: reproducible)
+// scale[0..1] = {1 / (B n mm'), mm'} (normalize) or {1 / (B n), mm'}: mm' = the alive-mask mean of the minibatch's
+// own-team rows, 1 where that is 0 (ppo.py:150-187)
+hipError_t fa_launch_mask_scale(const FaTrainArgs &a, int normalize, float *scale, hipStream_t st);
+// Adam (torch.optim.Adam, no amsgrad / weight decay) on flat buffers after the global-norm clip of
+// nn.utils.clip_grad_norm_: two launches.  seg: nseg + 1 offsets; steps: nseg step counters (float)
+hipError_t fa_launch_adam(float *p, float *g, float *m, float *v, float *steps, const int32_t *seg, int nseg, int n, float lr,
+                          float beta1, float beta2, float eps, float max_norm, float *coef, hipStream_t st);
+// out[k] = sum over tiles of slabs[t][k], k < FA_SLAB_LOSS + 8 (fixed order: reproducible); out[FA_SLAB_LOSS + 8..9]
+// is where fa_ppo_grad keeps the scale pair when the caller passes none
 hipError_t fa_launch_train_reduce(const float *slabs, int tiles, float *out, hipStream_t st);

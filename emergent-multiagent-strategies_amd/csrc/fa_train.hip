@@ -94,11 +94,10 @@ __device__ __forceinline__ void mix_row(const float *attn_row, const float *key0
 // Backward of the attention of ONE env by a 16-lane sub-group (cf. fa_attend.hip): rows r0 .. r0+n-1 of
 // dout / g (g is overwritten by dg), the env's nk key rows at key0, their gradient ADDED into dkey0 rows
 // (ADD) or written (!ADD).  W floats per row.
-template <int W, bool ADD>
+template <int W, bool ADD, int MT>
 __device__ __forceinline__ void attend_env_bwd(const float *dout0, float *g0, const float *key0, float *dkey0, const float *attn0,
                                                int n, int nk, int q) {
     constexpr int C = W / 16;
-    constexpr int MT = FA_POLICY_MAX_TEAM;
     float kv[MT][C], dk[MT][C];
 #pragma unroll
     for (int j = 0; j < MT; ++j)
@@ -161,6 +160,8 @@ __device__ __forceinline__ void attend_env_bwd(const float *dout0, float *g0, co
         }
 }
 
+// GATHER: the minibatch is rows a.idx[.] of the rollout arrays (else rows 0..B)
+template <bool GATHER>
 __global__ __launch_bounds__(256, 1) void fa_train_kernel(FaTrainArgs a) {
     __shared__ __attribute__((aligned(16))) float B0[TR * LDA], B1[TR * LDA], B2[TR * LDA], B3[TR * LDA];
     __shared__ float sX[TR * 2 * FA_OBS_DIM];
@@ -168,7 +169,9 @@ __global__ __launch_bounds__(256, 1) void fa_train_kernel(FaTrainArgs a) {
     __shared__ float sAttn[4][TR * 8]; // [opponent stage, round 0, 1, 2][row][key]
     __shared__ __attribute__((aligned(16))) float sO2[TR * SOW]; // the opponent side's [x | 1] rows (encoder backward)
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // `wave` as a scalar: conditions on it become scalar branches, not exec-masked regions (cheaper, and see
+    // tools/isa_lint.py for why this kernel wants as few exec-masked joins as possible)
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, hh = lane >> 5, q16 = lane & 15;
     const int N = a.G + a.A;
     const int n = a.team == 0 ? a.G : a.A, m = N - n;
@@ -248,8 +251,16 @@ __global__ __launch_bounds__(256, 1) void fa_train_kernel(FaTrainArgs a) {
 
     FA_TR_TICK(0)
     // ================================ forward ==========================================================
-    for (int k = tid; k < ET * N * FA_OBS_DIM; k += 256)
-        sX[k] = k < ne * N * FA_OBS_DIM ? a.obs[(size_t)e0 * N * FA_OBS_DIM + k] : 0.0f;
+    if (GATHER) {
+        const int ow = N * FA_OBS_DIM;
+        for (int k = tid; k < ET * ow; k += 256) {
+            const int el = k / ow;
+            sX[k] = el < ne ? a.obs[(size_t)a.idx[e0 + el] * ow + (k - el * ow)] : 0.0f;
+        }
+    } else {
+        for (int k = tid; k < ET * N * FA_OBS_DIM; k += 256)
+            sX[k] = k < ne * N * FA_OBS_DIM ? a.obs[(size_t)e0 * N * FA_OBS_DIM + k] : 0.0f;
+    }
     __syncthreads();
     encoders(B0, B2);
     __syncthreads();
@@ -334,7 +345,7 @@ __global__ __launch_bounds__(256, 1) void fa_train_kernel(FaTrainArgs a) {
         for (int k = 0; k < FA_NUM_ACTIONS; ++k) dlg[k] = 0.0f;
         if (r < ne * n) {
             const int el = r / n, i = r - el * n;
-            const size_t o = (size_t)(e0 + el) * N + own0 + i;
+            const size_t o = (size_t)(GATHER ? a.idx[e0 + el] : (int64_t)(e0 + el)) * N + own0 + i;
             const float *lo = sO + r * SOW;
             mk = sX[(el * N + own0 + i) * FA_OBS_DIM]; // the alive flag (ppo.py:224)
             float lg[FA_NUM_ACTIONS], mx = -INFINITY;
@@ -402,7 +413,7 @@ __global__ __launch_bounds__(256, 1) void fa_train_kernel(FaTrainArgs a) {
             gemm_tn((kb < 4 ? B1 : B2) + (kb & 3) * 32, LDA, sO, SOW, acc, lane);
             store_tile_global(slab + FA_POFF_W9 + kb * 32 * 32, 32, acc, lane);
         }
-        if (tid < 32) {
+        if (wave == 0 && lane < 32) {
             float sum = 0.0f;
             for (int r = 0; r < TR; ++r) sum += sO[r * SOW + tid];
             slab[FA_POFF_B9 + tid] = sum;
@@ -449,7 +460,7 @@ __global__ __launch_bounds__(256, 1) void fa_train_kernel(FaTrainArgs a) {
             }
         }
         {
-            const float *src = (tid < 128 ? B1 : B2) + (tid & 127);
+            const float *src = (wave < 2 ? B1 : B2) + (tid & 127);
             float sum = 0.0f;
             for (int r = 0; r < TR; ++r) sum += src[r * LDA];
             slab[FA_POFF_B8 + tid] = sum;
@@ -485,7 +496,7 @@ __global__ __launch_bounds__(256, 1) void fa_train_kernel(FaTrainArgs a) {
             if (!(B0[r * LDA + c] > 0.0f)) B3[r * LDA + c] = 0.0f;
         }
         __syncthreads();
-        if (tid < 128) {
+        if (wave < 2) {
             float sum = 0.0f;
             for (int r = 0; r < TR; ++r) sum += B3[r * LDA + tid];
             dbu += sum;
@@ -529,11 +540,15 @@ __global__ __launch_bounds__(256, 1) void fa_train_kernel(FaTrainArgs a) {
         FA_TR_TICK(10 + (2 - round) * 8)
         // attention backward per env: dhmix (B1), g (B2) -> dg (B2 in place), dkeys added into B3.  The rows
         // beyond the tile's envs hold a recomputed g of padding rows: their dg is zero
-        if (tid < 32)
+        if (wave == 0 && lane < 32)
             for (int r = RU; r < TR; ++r) *reinterpret_cast<float4 *>(B2 + r * LDA + tid * 4) = float4{0, 0, 0, 0};
-        for (int el = wave * 4 + (lane >> 4); el < ET; el += 16)
-            attend_env_bwd<128, true>(B1 + (el * n) * LDA, B2 + (el * n) * LDA, B0 + (el * n) * LDA, B3 + (el * n) * LDA,
-                                      sAttn[1 + round] + (el * n) * 8, n, n, q16);
+        for (int el = wave * 4 + (lane >> 4); el < ET; el += 16) {
+            // (teams of up to 4: half the key / key-gradient registers)
+            if (n <= 4) attend_env_bwd<128, true, 4>(B1 + (el * n) * LDA, B2 + (el * n) * LDA, B0 + (el * n) * LDA, B3 + (el * n) * LDA,
+                                                     sAttn[1 + round] + (el * n) * 8, n, n, q16);
+            else attend_env_bwd<128, true, FA_POLICY_MAX_TEAM>(B1 + (el * n) * LDA, B2 + (el * n) * LDA, B0 + (el * n) * LDA,
+                                                               B3 + (el * n) * LDA, sAttn[1 + round] + (el * n) * 8, n, n, q16);
+        }
         __syncthreads();
         FA_TR_TICK(11 + (2 - round) * 8)
         // dA_m += h_in^T dg ;  dh += dg A_m^T
@@ -554,7 +569,7 @@ __global__ __launch_bounds__(256, 1) void fa_train_kernel(FaTrainArgs a) {
     for (int kb = 0; kb < 8; ++kb) store_tile_global(slab + FA_POFF_W7 + kb * 32 * 128 + wave * 32, 128, acc_w7[kb], lane);
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) store_tile_global(slab + FA_POFF_AM + kb * 32 * 128 + wave * 32, 128, acc_am[kb], lane);
-    if (tid < 128) slab[FA_POFF_BU + tid] = dbu;
+    if (wave < 2) slab[FA_POFF_BU + tid] = dbu;
 
     FA_TR_TICK(30)
     // ---- opponent stage: B0 = [h1 | e_opp], B3 = [dh1 (so far) | de_opp] --------------------------------
@@ -582,7 +597,7 @@ __global__ __launch_bounds__(256, 1) void fa_train_kernel(FaTrainArgs a) {
     __syncthreads();
     // opponent attention backward per env: dmix_o (B2[:, 64:]), g_o (B1[:, 64:]) -> dg_o in place; dho -> B1[:, 0:64]
     for (int el = wave * 4 + (lane >> 4); el < ET; el += 16)
-        attend_env_bwd<64, false>(B2 + (el * n) * LDA + 64, B1 + (el * n) * LDA + 64, B2 + (el * m) * LDA, B1 + (el * m) * LDA,
+        attend_env_bwd<64, false, FA_POLICY_MAX_TEAM>(B2 + (el * n) * LDA + 64, B1 + (el * n) * LDA + 64, B2 + (el * m) * LDA, B1 + (el * m) * LDA,
                                   sAttn[0] + (el * n) * 8, n, m, q16);
     __syncthreads();
     {   // dA_o = h1^T dg_o ;  dh1 += dg_o A_o^T
@@ -631,20 +646,82 @@ __global__ __launch_bounds__(256, 1) void fa_train_kernel(FaTrainArgs a) {
     FA_TR_TICK(32)
 }
 
-// out[k] = sum_t slabs[t][k] in tile order
+// out[k] = sum_t slabs[t][k] in tile order (sixteen interleaved partial sums: sixteen loads in flight per lane)
 __global__ void fa_train_reduce_kernel(const float *__restrict__ slabs, int tiles, float *__restrict__ out) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= FA_SLAB_FLOATS) return;
-    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+    if (k >= FA_SLAB_LOSS + 8) return;
+    float s[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) s[u] = 0.0f;
     int t = 0;
-    for (; t + 4 <= tiles; t += 4) {
-        s0 += slabs[(size_t)t * FA_SLAB_FLOATS + k];
-        s1 += slabs[(size_t)(t + 1) * FA_SLAB_FLOATS + k];
-        s2 += slabs[(size_t)(t + 2) * FA_SLAB_FLOATS + k];
-        s3 += slabs[(size_t)(t + 3) * FA_SLAB_FLOATS + k];
+    for (; t + 16 <= tiles; t += 16) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) s[u] += slabs[(size_t)(t + u) * FA_SLAB_FLOATS + k];
     }
-    for (; t < tiles; ++t) s0 += slabs[(size_t)t * FA_SLAB_FLOATS + k];
-    out[k] = (s0 + s1) + (s2 + s3);
+    for (; t < tiles; ++t) s[0] += slabs[(size_t)t * FA_SLAB_FLOATS + k];
+#pragma unroll
+    for (int w = 8; w >= 1; w >>= 1)
+#pragma unroll
+        for (int u = 0; u < w; ++u) s[u] += s[u + w];
+    out[k] = s[0];
+}
+
+// One workgroup: the alive-mask mean of the minibatch's own-team rows -> the scale pair of FaTrainArgs
+__global__ __launch_bounds__(1024) void fa_mask_scale_kernel(FaTrainArgs a, int normalize, float *__restrict__ scale) {
+    __shared__ float part[16];
+    const int N = a.G + a.A, n = a.team == 0 ? a.G : a.A, own0 = a.team == 0 ? 0 : a.G;
+    float s = 0.0f;
+    for (int b = threadIdx.x; b < a.B; b += 1024) {
+        const float *row = a.obs + (size_t)(a.idx ? a.idx[b] : b) * N * FA_OBS_DIM;
+        for (int i = 0; i < n; ++i) s += row[(own0 + i) * FA_OBS_DIM];
+    }
+    for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.0f;
+        for (int w = 0; w < 16; ++w) t += part[w];
+        const float cnt = (float)a.B * (float)n, mm = t / cnt, mmp = mm != 0.0f ? mm : 1.0f;
+        scale[0] = normalize ? 1.0f / (cnt * mmp) : 1.0f / cnt;
+        scale[1] = mmp;
+    }
+}
+
+// ---- clip_grad_norm_ + Adam on the flat parameter buffer -------------------------------------------------------
+// coef[0] = min(1, max_norm / (||g|| + 1e-6)) (torch.nn.utils.clip_grad_norm_); the step counters advance here
+__global__ __launch_bounds__(1024) void fa_clip_coef_kernel(const float *__restrict__ g, int n, float max_norm,
+                                                            float *__restrict__ coef, float *__restrict__ steps, int nseg) {
+    __shared__ double part[16];
+    double s = 0.0; // (fp64: 150 k squares summed by one workgroup; costs nothing here and the norm is exact to fp32)
+    for (int k = threadIdx.x; k < n; k += 1024) s += (double)g[k] * (double)g[k];
+    for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int w = 0; w < 16; ++w) t += part[w];
+        coef[0] = fminf(1.0f, max_norm / ((float)sqrt(t) + 1e-6f));
+    }
+    if (threadIdx.x < nseg) steps[threadIdx.x] += 1.0f;
+}
+
+__global__ __launch_bounds__(256) void fa_adam_kernel(float *__restrict__ p, float *__restrict__ g, float *__restrict__ m,
+                                                      float *__restrict__ v, const float *__restrict__ steps,
+                                                      const int32_t *__restrict__ seg, int nseg, float lr, float beta1,
+                                                      float beta2, float eps, const float *__restrict__ coef) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= seg[nseg]) return;
+    int sg = 0;
+    while (sg + 1 < nseg && k >= seg[sg + 1]) ++sg; // the parameter tensor this element belongs to: its step count
+    const float t = steps[sg];
+    const float bc1 = 1.0f - powf(beta1, t), bc2 = 1.0f - powf(beta2, t);
+    const float gr = g[k] * coef[0];
+    const float mk = m[k] + (gr - m[k]) * (1.0f - beta1); // exp_avg.lerp_(grad, 1 - beta1)
+    const float vk = v[k] * beta2 + (1.0f - beta2) * gr * gr;
+    g[k] = gr;
+    m[k] = mk;
+    v[k] = vk;
+    p[k] -= (lr / bc1) * mk / (sqrtf(vk) / sqrtf(bc2) + eps);
 }
 } // namespace
 
@@ -652,11 +729,25 @@ int fa_train_tile_envs(int G, int A) { return TR / (G > A ? G : A); }
 
 hipError_t fa_launch_train(const FaTrainArgs &a, hipStream_t st) {
     const int ET = fa_train_tile_envs(a.G, a.A);
-    hipLaunchKernelGGL(fa_train_kernel, dim3((a.B + ET - 1) / ET), dim3(256), 0, st, a);
+    if (a.idx) hipLaunchKernelGGL(fa_train_kernel<true>, dim3((a.B + ET - 1) / ET), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(fa_train_kernel<false>, dim3((a.B + ET - 1) / ET), dim3(256), 0, st, a);
     return hipGetLastError();
 }
 
 hipError_t fa_launch_train_reduce(const float *slabs, int tiles, float *out, hipStream_t st) {
-    hipLaunchKernelGGL(fa_train_reduce_kernel, dim3((FA_SLAB_FLOATS + 255) / 256), dim3(256), 0, st, slabs, tiles, out);
+    hipLaunchKernelGGL(fa_train_reduce_kernel, dim3((FA_SLAB_LOSS + 8 + 127) / 128), dim3(128), 0, st, slabs, tiles, out);
+    return hipGetLastError();
+}
+
+hipError_t fa_launch_mask_scale(const FaTrainArgs &a, int normalize, float *scale, hipStream_t st) {
+    hipLaunchKernelGGL(fa_mask_scale_kernel, dim3(1), dim3(1024), 0, st, a, normalize, scale);
+    return hipGetLastError();
+}
+
+hipError_t fa_launch_adam(float *p, float *g, float *m, float *v, float *steps, const int32_t *seg, int nseg, int n,
+                          float lr, float beta1, float beta2, float eps, float max_norm, float *coef, hipStream_t st) {
+    hipLaunchKernelGGL(fa_clip_coef_kernel, dim3(1), dim3(1024), 0, st, g, n, max_norm, coef, steps, nseg);
+    hipLaunchKernelGGL(fa_adam_kernel, dim3((n + 255) / 256), dim3(256), 0, st, p, g, m, v, steps, seg, nseg, lr, beta1, beta2,
+                       eps, coef);
     return hipGetLastError();
 }

@@ -516,16 +516,20 @@ def make_fortattack_env(num_steps, benchmark=False, num_guards=5, num_attackers=
 
 
 def ppo_grad(obs, action, value_pred, ret, old_logp, adv, w, wt, scale, team, G, A, clip, c_value, c_entropy,
-             clipped_value_loss=True, scratch=None, out=None):
+             clipped_value_loss=True, scratch=None, out=None, idx=None, normalize=True):
     """fa_ppo_grad: one team's PPO minibatch forward + losses + backward in one fused launch (+ reduction).
-    obs (B, N, 6) float32; action (B, N[, 1]) int64; value_pred / ret / old_logp / adv (B, N[, 1]) float32; w / wt the
-    packed weights and their transposes (mpnn_pack.pack_from_params); scale: device float32[2].  Returns
-    (out, scratch): out = FA_SLAB floats (plain-layout gradients + loss sums), scratch reusable."""
+    obs (rows, N, 6) float32; action (rows, N[, 1]) int64; value_pred / ret / old_logp / adv (rows, N[, 1]) float32;
+    idx: int64 row indices of the minibatch (None: every row); w / wt the packed weights and their transposes
+    (mpnn_pack.FlatPolicy.fold_pack / pack_from_params); scale: device float32[2], or None -> the library takes the
+    alive-mask mean itself and (normalize) divides by it.  Returns (out, scratch): out = FA_SLAB floats (plain-layout
+    gradients + loss sums), scratch reusable."""
     lib = _lib.load()
-    B, N = obs.shape[0], obs.shape[1]
-    for t in (obs, value_pred, ret, old_logp, adv, w, wt, scale):
+    N = obs.shape[1]
+    B = obs.shape[0] if idx is None else idx.numel()
+    for t in (obs, value_pred, ret, old_logp, adv, w, wt) + (() if scale is None else (scale,)):
         assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
     assert action.dtype == torch.int64 and action.is_contiguous() and N == G + A
+    assert idx is None or (idx.is_cuda and idx.dtype == torch.int64 and idx.is_contiguous())
     if scratch is None:
         sf, hf = C.c_int64(), C.c_int64()
         _lib.check(lib.fa_ppo_grad_scratch(B, G, A, C.byref(sf), C.byref(hf)), "fa_ppo_grad_scratch")
@@ -534,9 +538,11 @@ def ppo_grad(obs, action, value_pred, ret, old_logp, adv, w, wt, scale, team, G,
         out = torch.empty(lib.fa_ppo_grad_floats(), device=obs.device)
     io = _lib.PPOGradIO()
     io.obs, io.action, io.value_pred, io.ret, io.old_log_prob, io.adv = [_ptr(t) for t in (obs, action, value_pred, ret, old_logp, adv)]
-    io.weights, io.weights_t, io.scale, io.slabs, io.hsave, io.out = [_ptr(t) for t in (w, wt, scale, scratch[0], scratch[1], out)]
+    io.weights, io.weights_t, io.slabs, io.hsave, io.out = [_ptr(t) for t in (w, wt, scratch[0], scratch[1], out)]
+    io.scale = None if scale is None else _ptr(scale)
+    io.idx = None if idx is None else _ptr(idx)
     io.B, io.num_guards, io.num_attackers, io.team = B, G, A, team
     io.clip_param, io.value_loss_coef, io.entropy_coef = clip, c_value, c_entropy
-    io.clipped_value_loss = int(bool(clipped_value_loss))
+    io.clipped_value_loss, io.normalize = int(bool(clipped_value_loss)), int(bool(normalize))
     _lib.check(lib.fa_ppo_grad(C.byref(io), _stream()), "fa_ppo_grad")
     return out, scratch

@@ -78,10 +78,12 @@ class GraphedPPOStep(object):
                  clipped_value_loss, group, fused=False):
         self.pol, self.opt, self.group, self.world = pol, opt, group, _world(group)
         self.params = [p for p in pol.parameters()]
-        self.static = [torch.empty((mb,) + tuple(r.shape[1:]), dtype=r.dtype, device=r.device) for r in rows]
+        self.fused = bool(fused)
+        # torch path: the minibatch is gathered into static buffers; fused: the kernel reads rows idx of the rollout
+        self.static = None if self.fused else [torch.empty((mb,) + tuple(r.shape[1:]), dtype=r.dtype, device=r.device) for r in rows]
+        self.rows = tuple(rows)
         self.mb = mb
         world = self.world
-        self.fused = bool(fused)
         if self.fused:   # csrc/fa_train.hip: forward + losses + backward of the minibatch in one launch
             from .env import ppo_grad
             dev = rows[0].device
@@ -89,34 +91,33 @@ class GraphedPPOStep(object):
             n_own = own_sl.stop - own_sl.start
             team, G = (0, n_own) if own_sl.start == 0 else (1, N - n_own)
             self.fp = mpnn_pack.FlatPolicy.of(pol)
-            self._scale = torch.zeros(2, device=dev)
+            self.fp.bind_adam(opt)
+            self.idx = torch.zeros(mb, dtype=torch.int64, device=dev)
             self._out = torch.zeros(mpnn_pack.SLAB_FLOATS, device=dev)
             self._scratch = None
             inv_count = 1.0 / (mb * n_own)
-            PF = mpnn_pack.PF_FLOATS
+            PF, LOSS = mpnn_pack.PF_FLOATS, mpnn_pack.WEIGHT_FLOATS
+            self._unmask = torch.tensor([0.0, 1.0, 1.0], device=dev)
 
         def fused_fwd_bwd():
-            """parameters -> weight packs (fold: 3 launches) -> fa_ppo_grad (2) -> gradients of the parameters (unfold:
-            2): no PyTorch autograd, no PyTorch GEMM; what is left to torch is the alive-mask mean, clip and Adam"""
-            obs_b, act_b, vp_b, ret_b, olp_b, adv_b = self.static
+            """parameters -> weight packs (fold: 3 launches) -> fa_ppo_grad on rows idx of the rollout (mask mean,
+            forward + losses + backward, reduction: 3) -> gradients of the parameters (unfold: 2): no PyTorch
+            autograd, GEMM or gather; left to torch are four scalar ops on the loss sums"""
             fp = self.fp
             w, wt = fp.fold_pack()
-            mm = obs_b[:, own_sl, 0].mean()
-            mmp = torch.where(mm != 0, mm, torch.ones_like(mm))
-            # one rank: every loss divided by the mask mean here; several: after the all-reduce (finish())
-            self._scale.copy_(torch.stack((inv_count / mmp if world == 1 else torch.full_like(mmp, inv_count), mmp)))
-            _, self._scratch = ppo_grad(obs_b, act_b, vp_b, ret_b, olp_b, adv_b, w, wt, self._scale, team, G,
-                                        N - G, clip_param, value_loss_coef, entropy_coef, clipped_value_loss,
-                                        scratch=self._scratch, out=self._out)
+            _, self._scratch = ppo_grad(*self.rows, w, wt, None, team, G, N - G, clip_param, value_loss_coef, entropy_coef,
+                                        clipped_value_loss, scratch=self._scratch, out=self._out, idx=self.idx,
+                                        normalize=(world == 1))
             fp.attach_grads()               # every parameter's .grad is its slice of fp.gflat
             fp.unfold(self._out)
-            sums = self._out[mpnn_pack.WEIGHT_FLOATS:mpnn_pack.WEIGHT_FLOATS + 3] * inv_count
+            sums = self._out[LOSS:LOSS + 3] * inv_count
+            mmp = self._out[LOSS + 9]       # the alive-mask mean of the minibatch (1 where that is 0)
             if not clipped_value_loss:      # the scalar-MSE value loss is not masked (ppo.py:178-182)
-                sums = sums * torch.stack((mmp, torch.ones_like(mmp), torch.ones_like(mmp)))
+                sums = sums * (self._unmask + (1.0 - self._unmask) * mmp)
             if world == 1:
                 return sums / mmp, None
             fp.gflat[PF:PF + 3].copy_(sums)  # the flat gradient buffer carries the loss sums and the mask mean
-            fp.gflat[PF + 3].copy_(mm)
+            fp.gflat[PF + 3].copy_(self._out[LOSS + 3] * inv_count)
             return sums, fp.gflat
 
         def fwd_bwd():
@@ -149,12 +150,11 @@ class GraphedPPOStep(object):
                     if p.grad is not None:
                         p.grad.copy_(flat[off:off + p.grad.numel()].view_as(p.grad))
                         off += p.grad.numel()
-            if self.fused:      # the parameters' gradients are one buffer: the global norm is one reduction
-                gall = self.fp.gflat[:PF]
-                gall.mul_(torch.clamp(max_grad_norm / (torch.linalg.vector_norm(gall) + 1e-6), max=1.0))
+            if self.fused:      # parameters, gradients and Adam state are flat buffers: clip + Adam = 2 launches
+                self.fp.adam_step(opt, max_grad_norm)
             else:
                 nn.utils.clip_grad_norm_(self.params, max_grad_norm)
-            opt.step()
+                opt.step()
             return losses.clone()
 
         def eager():
@@ -164,8 +164,11 @@ class GraphedPPOStep(object):
             return finish(losses, flat)
 
         # ---- warm-up on a side stream, then undo it -------------------------------------------------------
-        for st, src in zip(self.static, rows):
-            st.copy_(src[:mb])
+        if self.fused:
+            self.idx.copy_(torch.arange(mb, device=rows[0].device))
+        else:
+            for st, src in zip(self.static, rows):
+                st.copy_(src[:mb])
         saved_p = [p.detach().clone() for p in self.params]
         had_state = len(opt.state) > 0
         saved_s = {p: {k: v.clone() for k, v in opt.state[p].items() if torch.is_tensor(v)} for p in self.params if p in opt.state}
@@ -196,8 +199,12 @@ class GraphedPPOStep(object):
                 self.losses = finish(l0, self.flat)
 
     def run(self, rows, idx):
-        for st, src in zip(self.static, rows):
-            torch.index_select(src, 0, idx, out=st)
+        if self.fused:
+            assert all(a.data_ptr() == b.data_ptr() for a, b in zip(rows, self.rows)), "the captured step reads the rollout in place"
+            self.idx.copy_(idx)
+        else:
+            for st, src in zip(self.static, rows):
+                torch.index_select(src, 0, idx, out=st)
         self.g1.replay()
         if self.g2 is not None:
             dist.all_reduce(self.flat, group=self.group)

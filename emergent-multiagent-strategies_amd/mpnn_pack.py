@@ -346,3 +346,44 @@ class FlatPolicy(object):
             self._unfold = self._build_unfold(grads_plain.data_ptr()) + [grads_plain.data_ptr()]
         self._run(self._unfold[0])
         self._run(self._unfold[1])
+
+    # -- optimizer --------------------------------------------------------------------------------------------------
+    def bind_adam(self, opt):
+        """Make a torch.optim.Adam over this module keep its state in flat buffers (exp_avg / exp_avg_sq of every
+        parameter = views of mflat / vflat, the step counters = views of `steps`), so adam_step() below and the
+        optimizer's own step() advance the same state."""
+        if getattr(self, "_opt", None) is opt:
+            return
+        g = opt.param_groups[0]
+        assert len(opt.param_groups) == 1 and not g.get("amsgrad") and not g.get("weight_decay") and not g.get("maximize"), \
+            "fa_adam_step is plain Adam: one group, no amsgrad / weight decay / maximize"
+        dev = self.pflat.device
+        self.mflat, self.vflat = torch.zeros_like(self.pflat), torch.zeros_like(self.pflat)
+        self.steps = torch.zeros(len(_PF), device=dev, dtype=torch.float32)
+        seg = []
+        for k, (name, get, off) in enumerate(_PF):
+            p = get(self.pol)
+            n = p.numel()
+            seg.append(off)
+            st = opt.state[p]
+            views = {"step": self.steps[k], "exp_avg": self.mflat[off:off + n].view(p.shape),
+                     "exp_avg_sq": self.vflat[off:off + n].view(p.shape)}
+            for key, view in views.items():
+                if key in st and torch.is_tensor(st[key]):
+                    view.copy_(st[key].to(dev))
+                st[key] = view
+        assert seg == sorted(seg) and seg[0] == 0
+        self._seg = torch.tensor(seg + [PF_FLOATS], dtype=torch.int32, device=dev)
+        self._coef = torch.zeros(1, device=dev)
+        self._opt = opt
+
+    def adam_step(self, opt, max_grad_norm):
+        """clip_grad_norm_(max_grad_norm) + Adam over the flat buffers: fa_adam_step (two launches)."""
+        self.bind_adam(opt)
+        g = opt.param_groups[0]
+        L, C = self._lib, self._C
+        vp = lambda t: C.c_void_p(t.data_ptr())
+        L.check(L.load().fa_adam_step(vp(self.pflat), vp(self.gflat), vp(self.mflat), vp(self.vflat), vp(self.steps), vp(self._seg),
+                                      len(_PF), PF_FLOATS, float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]),
+                                      float(g["eps"]), float(max_grad_norm), vp(self._coef),
+                                      C.c_void_p(torch.cuda.current_stream().cuda_stream)), "fa_adam_step")

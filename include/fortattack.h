@@ -295,16 +295,21 @@ int fa_attend_backward(const float *g, const float *keys, const float *attn, con
  * (csrc/fa_policy.h FA_POFF_*: encoders, A_o, B_o, A_m, W7, W8, W9 and the biases -- the host applies the
  * chain rule to the module's own parameters, mpnn_pack.KernelParams), followed at fa_ppo_grad_floats() - 16
  * by the sums over the minibatch of {value loss, action loss, entropy * mask, mask}.
- * scale: device float[2] = {1 / (B n mask_mean'), mask_mean'}, mask_mean' = the minibatch's alive-mask mean
- * (ppo.py:150-187 divides every loss by it; pass {1 / (B n), 1} to normalise later, e.g. across ranks).
- * obs (B, N, 6); action / value_pred / ret / old_log_prob / adv (B, N), of which the team's columns are read.
+ * The minibatch is rows idx[0..B) of the arrays (magent_feed_forward_generator's index set, ppo.py:213-246; idx
+ * NULL: rows 0..B): obs (rows, N, 6); action / value_pred / ret / old_log_prob / adv (rows, N), of which the team's
+ * columns are read.
+ * scale: NULL -> the library takes the minibatch's alive-mask mean itself (one small launch) and divides every loss
+ * by it as ppo.py:150-187 does (`normalize` = 1), or leaves the division to the caller (`normalize` = 0: several
+ * ranks divide by the all-rank mean after the gradient exchange; the mask sum is the 4th loss float).  Otherwise
+ * a device float[2] = {1 / (B n mask_mean'), mask_mean'} supplied by the caller (mask_mean' = 1 where the mean is 0).
  * slabs / hsave: scratch of fa_ppo_grad_scratch() floats.  Bitwise reproducible (no atomics). */
 typedef struct fa_ppo_grad_io {
     const float *obs;
     const int64_t *action;
     const float *value_pred, *ret, *old_log_prob, *adv;
+    const int64_t *idx;        /* B row indices, or NULL */
     const float *weights, *weights_t;
-    const float *scale;
+    const float *scale;        /* or NULL */
     float *slabs, *hsave;      /* scratch */
     float *out;                /* fa_ppo_grad_floats() floats */
     int32_t B;                 /* envs in the minibatch */
@@ -312,6 +317,7 @@ typedef struct fa_ppo_grad_io {
     int32_t team;              /* 0: the guards' policy on the guards' rows, 1: the attackers' */
     float clip_param, value_loss_coef, entropy_coef;
     int32_t clipped_value_loss;
+    int32_t normalize;         /* with scale == NULL: 1 = divide by the alive-mask mean here, 0 = the caller will */
 } fa_ppo_grad_io;
 int fa_ppo_grad(const fa_ppo_grad_io *io, void *stream);
 int64_t fa_ppo_grad_floats(void);
@@ -336,6 +342,16 @@ int fa_run_tasks(const fa_task *tasks, int32_t n, void *stream);
 /* plain: fa_policy_weight_floats() floats, row-major matrices at the FA_POFF_* offsets (csrc/fa_policy.h) ->
  * weights (fa_policy_weight_floats()) and weights_t (fa_policy_weight_t_floats()) */
 int fa_pack_weights(const float *plain, float *weights, float *weights_t, void *stream);
+
+/* One optimizer step on a flat parameter buffer: nn.utils.clip_grad_norm_(max_grad_norm) over all n gradients,
+ * then torch.optim.Adam's update (rlcore/algo/ppo.py:35 optim.Adam(lr, eps); no amsgrad, no weight decay) -- two
+ * launches instead of ~70 (the multi-tensor kernels plus one pow kernel per parameter tensor and moment).
+ * params / grads / exp_avg / exp_avg_sq: n floats; grads are left clipped.  seg: nseg + 1 int32 offsets of the
+ * parameter tensors inside the buffer (seg[nseg] = n), steps: their nseg step counters (float, advanced here);
+ * coef: one float of scratch (receives the clip coefficient).  All device pointers. */
+int fa_adam_step(float *params, float *grads, float *exp_avg, float *exp_avg_sq, float *steps, const int32_t *seg,
+                 int32_t nseg, int32_t n, float lr, float beta1, float beta2, float eps, float max_grad_norm, float *coef,
+                 void *stream);
 
 /* ---- state access (synchronous; tests / checkpoint) ------------------------------ */
 int fa_get_state(fa_env *env, const fa_state_host *out);
