@@ -105,6 +105,7 @@ EXPORTS = {
     "fa_policy_weight_t_floats": (C.c_int64, []),
     "fa_adam_step": (C.c_int, [c_p, c_p, c_p, c_p, c_p, c_p, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float,
                                C.c_float, c_p, c_p]),
+    "fa_adam_scratch_floats": (C.c_int64, []),
     "fa_run_tasks": (C.c_int, [c_p, C.c_int32, c_p]),
     "fa_pack_weights": (C.c_int, [c_p, c_p, c_p, c_p]),
     "fa_get_state": (C.c_int, [c_p, C.POINTER(StateHost)]),

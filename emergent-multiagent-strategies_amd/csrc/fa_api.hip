@@ -592,6 +592,7 @@ int fa_collect_act(fa_env *env, int32_t step, const fa_policy_io *io, void *stre
 int64_t fa_policy_weight_floats(void) { return FA_POLICY_WEIGHT_FLOATS; }
 
 int64_t fa_ppo_grad_floats(void) { return FA_SLAB_FLOATS; }
+int64_t fa_adam_scratch_floats(void) { return FA_ADAM_SCRATCH; }
 int64_t fa_policy_weight_t_floats(void) { return FA_TRANS_FLOATS; }
 
 int fa_ppo_grad_scratch(int32_t B, int32_t G, int32_t A, int64_t *slab_floats, int64_t *hsave_floats) {
@@ -599,7 +600,7 @@ int fa_ppo_grad_scratch(int32_t B, int32_t G, int32_t A, int64_t *slab_floats, i
         return fail(FA_ERR_INVALID, "fa_ppo_grad_scratch: need B >= 1 and teams of 1..8");
     const int et = fa_train_tile_envs(G, A);
     const int64_t tiles = (B + et - 1) / et;
-    if (slab_floats) *slab_floats = tiles * FA_SLAB_FLOATS;
+    if (slab_floats) *slab_floats = tiles * FA_SLAB_FLOATS + FA_MASK_PARTS;
     if (hsave_floats) *hsave_floats = tiles * FA_TR_SAVE_FLOATS;
     return FA_OK;
 }
@@ -621,24 +622,27 @@ int fa_ppo_grad(const fa_ppo_grad_io *io, void *stream) {
     a.clip = io->clip_param; a.c_value = io->value_loss_coef; a.c_entropy = io->entropy_coef;
     a.clipped_value_loss = io->clipped_value_loss;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (!a.scale) { // the scale pair lives behind the loss sums of `out` (the reduction leaves it alone)
-        float *sc = io->out + FA_SLAB_LOSS + 8;
-        FA_HIP(fa_launch_mask_scale(a, io->normalize != 0, sc, s));
-        a.scale = sc;
+    const int et = fa_train_tile_envs(a.G, a.A);
+    if (!a.scale) { // partial mask sums behind the tiles' slabs; the scale pair is left behind the loss sums of `out`
+        float *part = io->slabs + (size_t)((a.B + et - 1) / et) * FA_SLAB_FLOATS;
+        FA_HIP(fa_launch_mask_parts(a, part, s));
+        a.mask_part = part;
+        a.scale_out = io->out + FA_SLAB_LOSS + 8;
+        a.normalize = io->normalize != 0;
     }
     FA_HIP(fa_launch_train(a, s));
-    const int et = fa_train_tile_envs(a.G, a.A);
     FA_HIP(fa_launch_train_reduce(io->slabs, (a.B + et - 1) / et, io->out, s));
     return FA_OK;
 }
 
 int fa_adam_step(float *params, float *grads, float *exp_avg, float *exp_avg_sq, float *steps, const int32_t *seg,
-                 int32_t nseg, int32_t n, float lr, float beta1, float beta2, float eps, float max_grad_norm, float *coef,
+                 int32_t nseg, int32_t n, float lr, float beta1, float beta2, float eps, float max_grad_norm, float *scratch,
                  void *stream) {
-    if (!params || !grads || !exp_avg || !exp_avg_sq || !steps || !seg || !coef)
+    if (!params || !grads || !exp_avg || !exp_avg_sq || !steps || !seg || !scratch)
         return fail(FA_ERR_INVALID, "fa_adam_step: null argument");
-    if (nseg < 1 || nseg > 1024 || n < 1) return fail(FA_ERR_INVALID, "fa_adam_step: need 1 <= nseg <= 1024 and n >= 1");
-    FA_HIP(fa_launch_adam(params, grads, exp_avg, exp_avg_sq, steps, seg, nseg, n, lr, beta1, beta2, eps, max_grad_norm, coef,
+    if (nseg < 1 || n < 1) return fail(FA_ERR_INVALID, "fa_adam_step: need nseg >= 1 and n >= 1");
+    if (reinterpret_cast<uintptr_t>(scratch) & 15) return fail(FA_ERR_INVALID, "fa_adam_step: scratch must be 16-byte aligned");
+    FA_HIP(fa_launch_adam(params, grads, exp_avg, exp_avg_sq, steps, seg, nseg, n, lr, beta1, beta2, eps, max_grad_norm, scratch,
                           static_cast<hipStream_t>(stream)));
     return FA_OK;
 }

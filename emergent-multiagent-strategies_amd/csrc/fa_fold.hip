@@ -11,34 +11,43 @@
 
 #include "fa_train.h"
 
-#define FA_TASK_SLICES 32
+#define FA_TASK_SLICES 64
 namespace {
 // C[i*ldc + j] = alpha * sum_k A[i*a_rs + k*a_cs] * B[k*b_rs + j*b_cs]   (type 0)
 // C[i*ldc + j] = alpha * A[i*a_rs + j*a_cs]                               (type 1)
 __global__ __launch_bounds__(256) void fa_task_kernel(const fa_task *__restrict__ tasks) {
-    // blockIdx.y: FA_TASK_SLICES workgroups share a task's outputs (the largest, 128 x 128 x 128, is then 2 outputs
-    // of 128 terms per thread instead of 64: these launches are latency chains, not bandwidth)
+    // blockIdx.y: FA_TASK_SLICES workgroups share a task's outputs.  A product's output is owned by EIGHT adjacent
+    // lanes, lane q taking the terms k = q (mod 8): the dependent chain of loads per lane is K / 8 long instead of
+    // K (these launches are latency chains, not bandwidth: the largest product is 128 x 128 x 128), and the eight
+    // partial sums meet in a fixed order (three xor-shuffles): reproducible.
     const fa_task t = tasks[blockIdx.x];
     const int total = t.M * t.N;
-    for (int o = blockIdx.y * 256 + threadIdx.x; o < total; o += 256 * FA_TASK_SLICES) {
-        const int i = o / t.N, j = o - i * t.N;
-        float acc;
-        if (t.type == 1) {
-            acc = t.A[(size_t)i * t.a_rs + (size_t)j * t.a_cs];
-        } else {
-            const float *a = t.A + (size_t)i * t.a_rs, *b = t.B + (size_t)j * t.b_cs;
-            float p0 = 0.0f, p1 = 0.0f, p2 = 0.0f, p3 = 0.0f; // four partial sums: four loads in flight per operand
-            int k = 0;
-            for (; k + 4 <= t.K; k += 4) {
-                p0 = fmaf(a[(size_t)k * t.a_cs], b[(size_t)k * t.b_rs], p0);
-                p1 = fmaf(a[(size_t)(k + 1) * t.a_cs], b[(size_t)(k + 1) * t.b_rs], p1);
-                p2 = fmaf(a[(size_t)(k + 2) * t.a_cs], b[(size_t)(k + 2) * t.b_rs], p2);
-                p3 = fmaf(a[(size_t)(k + 3) * t.a_cs], b[(size_t)(k + 3) * t.b_rs], p3);
-            }
-            for (; k < t.K; ++k) p0 = fmaf(a[(size_t)k * t.a_cs], b[(size_t)k * t.b_rs], p0);
-            acc = (p0 + p1) + (p2 + p3);
+    const int gid = blockIdx.y * 256 + threadIdx.x;
+    if (t.type == 1) {
+        for (int o = gid; o < total; o += 256 * FA_TASK_SLICES) {
+            const int i = o / t.N, j = o - i * t.N;
+            t.C[(size_t)i * t.ldc + j] = t.alpha * t.A[(size_t)i * t.a_rs + (size_t)j * t.a_cs];
         }
-        t.C[(size_t)i * t.ldc + j] = t.alpha * acc;
+        return;
+    }
+    const int q = gid & 7;
+    for (int o0 = 0; o0 < total; o0 += 32 * FA_TASK_SLICES) { // (uniform trip count: the shuffles see whole groups)
+        const int o = o0 + (gid >> 3);
+        const bool live = o < total;
+        const int i = live ? o / t.N : 0, j = live ? o - i * t.N : 0;
+        const float *a = t.A + (size_t)i * t.a_rs, *b = t.B + (size_t)j * t.b_cs;
+        float p0 = 0.0f, p1 = 0.0f;
+        int k = q;
+        for (; k + 8 < t.K; k += 16) {
+            p0 = fmaf(a[(size_t)k * t.a_cs], b[(size_t)k * t.b_rs], p0);
+            p1 = fmaf(a[(size_t)(k + 8) * t.a_cs], b[(size_t)(k + 8) * t.b_rs], p1);
+        }
+        if (k < t.K) p0 = fmaf(a[(size_t)k * t.a_cs], b[(size_t)k * t.b_rs], p0);
+        float acc = p0 + p1;
+        acc += __shfl_xor(acc, 1);
+        acc += __shfl_xor(acc, 2);
+        acc += __shfl_xor(acc, 4);
+        if (live && q == 0) t.C[(size_t)i * t.ldc + j] = t.alpha * acc;
     }
 }
 

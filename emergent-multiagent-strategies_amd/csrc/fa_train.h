@@ -24,6 +24,9 @@
 // | bu | W8 (128x256) | b8 | W9 (256x32) | b9), then the tile's loss sums.
 #define FA_SLAB_LOSS FA_POLICY_WEIGHT_FLOATS // [value_loss sum, action_loss sum, entropy*mask sum, mask sum]
 #define FA_SLAB_FLOATS (FA_POLICY_WEIGHT_FLOATS + 16)
+#define FA_MASK_PARTS 64
+#define FA_NORM_PARTS 64
+#define FA_ADAM_SCRATCH (4 + 2 * FA_NORM_PARTS)
 #define FA_TR_SAVE_FLOATS (3 * FA_TR_ROWS * 128) // per tile: h after the opponent stage and after rounds 1, 2
 
 struct FaTrainArgs {
@@ -39,6 +42,9 @@ struct FaTrainArgs {
     float *slabs;              // [tiles][FA_SLAB_FLOATS]
     float *hsave;              // [tiles][FA_TR_SAVE_FLOATS]
     int32_t B, G, A, team;     // team 0: the guards' policy on the guards' rows; 1: the attackers'
+    const float *mask_part;    // with scale == null: FA_MASK_PARTS partial alive-mask sums (fa_launch_mask_parts); the
+    float *scale_out;          // kernel derives the scale pair itself (`normalize`: divide by the mask mean) and
+    int32_t normalize;         // workgroup 0 leaves it at scale_out[0..1]
     const float *scale;        // device float[2]: {1 / (B n mask_mean'), mask_mean'} with mask_mean' = the alive-mask
                                // mean of the minibatch (1 where that is 0, or when the caller normalises later:
                                // several ranks).  [0] multiplies every loss gradient; [1] undoes it for the
@@ -52,13 +58,13 @@ hipError_t fa_launch_tasks(const fa_task *tasks, int n, hipStream_t st);
 hipError_t fa_launch_pack(const float *plain, float *w, float *wt, hipStream_t st);
 int fa_train_tile_envs(int G, int A);
 hipError_t fa_launch_train(const FaTrainArgs &a, hipStream_t st);
-// scale[0..1] = {1 / (B n mm'), mm'} (normalize) or {1 / (B n), mm'}: mm' = the alive-mask mean of the minibatch's
-// own-team rows, 1 where that is 0 (ppo.py:150-187)
-hipError_t fa_launch_mask_scale(const FaTrainArgs &a, int normalize, float *scale, hipStream_t st);
+// FA_MASK_PARTS partial sums of the alive mask over the minibatch's own-team rows (FaTrainArgs::mask_part)
+hipError_t fa_launch_mask_parts(const FaTrainArgs &a, float *part, hipStream_t st);
 // Adam (torch.optim.Adam, no amsgrad / weight decay) on flat buffers after the global-norm clip of
-// nn.utils.clip_grad_norm_: two launches.  seg: nseg + 1 offsets; steps: nseg step counters (float)
+// nn.utils.clip_grad_norm_: two launches.  seg: nseg + 1 offsets; steps: nseg step counters (float);
+// scratch: FA_ADAM_SCRATCH floats, 16-byte aligned ([0] receives the clip coefficient)
 hipError_t fa_launch_adam(float *p, float *g, float *m, float *v, float *steps, const int32_t *seg, int nseg, int n, float lr,
-                          float beta1, float beta2, float eps, float max_norm, float *coef, hipStream_t st);
+                          float beta1, float beta2, float eps, float max_norm, float *scratch, hipStream_t st);
 // out[k] = sum over tiles of slabs[t][k], k < FA_SLAB_LOSS + 8 (fixed order: reproducible); out[FA_SLAB_LOSS + 8..9]
 // is where fa_ppo_grad keeps the scale pair when the caller passes none
 hipError_t fa_launch_train_reduce(const float *slabs, int tiles, float *out, hipStream_t st);

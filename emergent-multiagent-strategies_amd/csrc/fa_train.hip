@@ -338,7 +338,18 @@ __global__ __launch_bounds__(256, 1) void fa_train_kernel(FaTrainArgs a) {
     // ================================ losses (ppo.py:150-187) and dL/d[logits | value] -> sO ==============
     if (wave == 0) {
         const int r = lane;
-        const float inv_count = a.scale[0], unmask = a.scale[1];
+        float inv_count, unmask;
+        if (a.scale) {
+            inv_count = a.scale[0];
+            unmask = a.scale[1];
+        } else { // the library's own alive-mask mean: fold the partial sums (every workgroup, the same order)
+            float t = a.mask_part[lane];
+            for (int d = 32; d >= 1; d >>= 1) t += __shfl_xor(t, d);
+            const float cnt = (float)a.B * (float)n, mm = t / cnt;
+            unmask = mm != 0.0f ? mm : 1.0f;
+            inv_count = a.normalize ? 1.0f / (cnt * unmask) : 1.0f / cnt;
+            if (blockIdx.x == 0 && lane == 0) { a.scale_out[0] = inv_count; a.scale_out[1] = unmask; }
+        }
         float vl = 0.0f, al = 0.0f, en = 0.0f, mk = 0.0f;
         float dlg[FA_NUM_ACTIONS], dval = 0.0f;
 #pragma unroll
@@ -666,56 +677,53 @@ __global__ void fa_train_reduce_kernel(const float *__restrict__ slabs, int tile
     out[k] = s[0];
 }
 
-// One workgroup: the alive-mask mean of the minibatch's own-team rows -> the scale pair of FaTrainArgs
-__global__ __launch_bounds__(1024) void fa_mask_scale_kernel(FaTrainArgs a, int normalize, float *__restrict__ scale) {
-    __shared__ float part[16];
+// The alive-mask sum of the minibatch's own-team rows as FA_MASK_PARTS partial sums (one workgroup each; the
+// train kernel's workgroups fold them in a fixed order: reproducible, and no single-workgroup latency chain)
+__global__ __launch_bounds__(256) void fa_mask_part_kernel(FaTrainArgs a, float *__restrict__ part) {
+    __shared__ float wsum[4];
     const int N = a.G + a.A, n = a.team == 0 ? a.G : a.A, own0 = a.team == 0 ? 0 : a.G;
     float s = 0.0f;
-    for (int b = threadIdx.x; b < a.B; b += 1024) {
+    for (int b = blockIdx.x * 256 + threadIdx.x; b < a.B; b += FA_MASK_PARTS * 256) {
         const float *row = a.obs + (size_t)(a.idx ? a.idx[b] : b) * N * FA_OBS_DIM;
         for (int i = 0; i < n; ++i) s += row[(own0 + i) * FA_OBS_DIM];
     }
     for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d);
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        float t = 0.0f;
-        for (int w = 0; w < 16; ++w) t += part[w];
-        const float cnt = (float)a.B * (float)n, mm = t / cnt, mmp = mm != 0.0f ? mm : 1.0f;
-        scale[0] = normalize ? 1.0f / (cnt * mmp) : 1.0f / cnt;
-        scale[1] = mmp;
-    }
+    if (threadIdx.x == 0) part[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
 }
 
 // ---- clip_grad_norm_ + Adam on the flat parameter buffer -------------------------------------------------------
-// coef[0] = min(1, max_norm / (||g|| + 1e-6)) (torch.nn.utils.clip_grad_norm_); the step counters advance here
-__global__ __launch_bounds__(1024) void fa_clip_coef_kernel(const float *__restrict__ g, int n, float max_norm,
-                                                            float *__restrict__ coef, float *__restrict__ steps, int nseg) {
-    __shared__ double part[16];
-    double s = 0.0; // (fp64: 150 k squares summed by one workgroup; costs nothing here and the norm is exact to fp32)
-    for (int k = threadIdx.x; k < n; k += 1024) s += (double)g[k] * (double)g[k];
+// ||g||^2 as FA_NORM_PARTS fp64 partial sums (scratch + 4, 16-byte aligned); the step counters advance here.
+__global__ __launch_bounds__(256) void fa_sqnorm_part_kernel(const float *__restrict__ g, int n, double *__restrict__ part,
+                                                             float *__restrict__ steps, int nseg) {
+    __shared__ double wsum[4];
+    double s = 0.0;
+    for (int k = blockIdx.x * 256 + threadIdx.x; k < n; k += FA_NORM_PARTS * 256) s += (double)g[k] * (double)g[k];
     for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d);
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        double t = 0.0;
-        for (int w = 0; w < 16; ++w) t += part[w];
-        coef[0] = fminf(1.0f, max_norm / ((float)sqrt(t) + 1e-6f));
-    }
-    if (threadIdx.x < nseg) steps[threadIdx.x] += 1.0f;
+    if (threadIdx.x == 0) part[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+    if (blockIdx.x == 0)
+        for (int k = threadIdx.x; k < nseg; k += 256) steps[k] += 1.0f;
 }
 
+// coef = min(1, max_norm / (||g|| + 1e-6)) (torch.nn.utils.clip_grad_norm_), then torch.optim.Adam's update
 __global__ __launch_bounds__(256) void fa_adam_kernel(float *__restrict__ p, float *__restrict__ g, float *__restrict__ m,
                                                       float *__restrict__ v, const float *__restrict__ steps,
                                                       const int32_t *__restrict__ seg, int nseg, float lr, float beta1,
-                                                      float beta2, float eps, const float *__restrict__ coef) {
+                                                      float beta2, float eps, float max_norm, float *__restrict__ scratch) {
+    double t = reinterpret_cast<const double *>(scratch + 4)[threadIdx.x & 63];
+    for (int d = 32; d >= 1; d >>= 1) t += __shfl_xor(t, d);
+    const float coef = fminf(1.0f, max_norm / ((float)sqrt(t) + 1e-6f));
     const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k == 0) scratch[0] = coef;
     if (k >= seg[nseg]) return;
     int sg = 0;
     while (sg + 1 < nseg && k >= seg[sg + 1]) ++sg; // the parameter tensor this element belongs to: its step count
-    const float t = steps[sg];
-    const float bc1 = 1.0f - powf(beta1, t), bc2 = 1.0f - powf(beta2, t);
-    const float gr = g[k] * coef[0];
+    const float st = steps[sg];
+    const float bc1 = 1.0f - powf(beta1, st), bc2 = 1.0f - powf(beta2, st);
+    const float gr = g[k] * coef;
     const float mk = m[k] + (gr - m[k]) * (1.0f - beta1); // exp_avg.lerp_(grad, 1 - beta1)
     const float vk = v[k] * beta2 + (1.0f - beta2) * gr * gr;
     g[k] = gr;
@@ -739,15 +747,16 @@ hipError_t fa_launch_train_reduce(const float *slabs, int tiles, float *out, hip
     return hipGetLastError();
 }
 
-hipError_t fa_launch_mask_scale(const FaTrainArgs &a, int normalize, float *scale, hipStream_t st) {
-    hipLaunchKernelGGL(fa_mask_scale_kernel, dim3(1), dim3(1024), 0, st, a, normalize, scale);
+hipError_t fa_launch_mask_parts(const FaTrainArgs &a, float *part, hipStream_t st) {
+    hipLaunchKernelGGL(fa_mask_part_kernel, dim3(FA_MASK_PARTS), dim3(256), 0, st, a, part);
     return hipGetLastError();
 }
 
 hipError_t fa_launch_adam(float *p, float *g, float *m, float *v, float *steps, const int32_t *seg, int nseg, int n,
-                          float lr, float beta1, float beta2, float eps, float max_norm, float *coef, hipStream_t st) {
-    hipLaunchKernelGGL(fa_clip_coef_kernel, dim3(1), dim3(1024), 0, st, g, n, max_norm, coef, steps, nseg);
+                          float lr, float beta1, float beta2, float eps, float max_norm, float *scratch, hipStream_t st) {
+    hipLaunchKernelGGL(fa_sqnorm_part_kernel, dim3(FA_NORM_PARTS), dim3(256), 0, st, g, n, reinterpret_cast<double *>(scratch + 4),
+                       steps, nseg);
     hipLaunchKernelGGL(fa_adam_kernel, dim3((n + 255) / 256), dim3(256), 0, st, p, g, m, v, steps, seg, nseg, lr, beta1, beta2,
-                       eps, coef);
+                       eps, max_norm, scratch);
     return hipGetLastError();
 }

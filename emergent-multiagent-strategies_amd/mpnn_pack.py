@@ -374,7 +374,7 @@ class FlatPolicy(object):
                 st[key] = view
         assert seg == sorted(seg) and seg[0] == 0
         self._seg = torch.tensor(seg + [PF_FLOATS], dtype=torch.int32, device=dev)
-        self._coef = torch.zeros(1, device=dev)
+        self._coef = torch.zeros(int(self._lib.load().fa_adam_scratch_floats()), device=dev)   # [0]: the clip coefficient
         self._opt = opt
 
     def adam_step(self, opt, max_grad_norm):

@@ -348,10 +348,12 @@ int fa_pack_weights(const float *plain, float *weights, float *weights_t, void *
  * launches instead of ~70 (the multi-tensor kernels plus one pow kernel per parameter tensor and moment).
  * params / grads / exp_avg / exp_avg_sq: n floats; grads are left clipped.  seg: nseg + 1 int32 offsets of the
  * parameter tensors inside the buffer (seg[nseg] = n), steps: their nseg step counters (float, advanced here);
- * coef: one float of scratch (receives the clip coefficient).  All device pointers. */
+ * scratch: fa_adam_scratch_floats() floats, 16-byte aligned ([0] receives the clip coefficient).  All device
+ * pointers.  The squared norm is accumulated in fp64 in a fixed order: reproducible. */
 int fa_adam_step(float *params, float *grads, float *exp_avg, float *exp_avg_sq, float *steps, const int32_t *seg,
-                 int32_t nseg, int32_t n, float lr, float beta1, float beta2, float eps, float max_grad_norm, float *coef,
+                 int32_t nseg, int32_t n, float lr, float beta1, float beta2, float eps, float max_grad_norm, float *scratch,
                  void *stream);
+int64_t fa_adam_scratch_floats(void);
 
 /* ---- state access (synchronous; tests / checkpoint) ------------------------------ */
 int fa_get_state(fa_env *env, const fa_state_host *out);
