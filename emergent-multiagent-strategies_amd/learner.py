@@ -185,6 +185,7 @@ class GraphedPPOStep(object):
                 for k, v in opt.state.get(p, {}).items():
                     if torch.is_tensor(v):
                         v.copy_(saved_s[p][k]) if had_state and p in saved_s else v.zero_()
+        self._eager = eager
         # ---- capture -----------------------------------------------------------------------------------
         self.g1 = torch.cuda.CUDAGraph()
         self.g2 = None
@@ -209,6 +210,33 @@ class GraphedPPOStep(object):
         if self.g2 is not None:
             dist.all_reduce(self.flat, group=self.group)
             self.g2.replay()
+        return self.losses
+
+
+class GraphedTeamsStep(object):
+    """One optimizer step of BOTH teams as one hipGraph with two parallel branches (the teams' policies, optimizers
+    and minibatch index sets are independent; the rollout rows are only read).  Why: a team's fa_ppo_grad launch is
+    781 workgroup tiles on 256 CUs at 3v3 x 16 384 samples -- three full rounds and a fourth with 13 tiles; with the
+    other team's launch in flight the idle CUs of that tail take its tiles (1 562 tiles: 6.1 -> 7 rounds, not 8)."""
+
+    def __init__(self, steps):
+        assert all(st.fused and st.world == 1 for st in steps)
+        self.steps = steps
+        self.side = torch.cuda.Stream(steps[0].idx.device)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, pool=steps[0].g1.pool()):
+            main = torch.cuda.current_stream()
+            self.side.wait_stream(main)                          # fork
+            l0 = steps[0]._eager()
+            with torch.cuda.stream(self.side):
+                l1 = steps[1]._eager()
+            main.wait_stream(self.side)                          # join
+            self.losses = (l0, l1)
+
+    def run(self, idx_pair):
+        for st, idx in zip(self.steps, idx_pair):
+            st.idx.copy_(idx)
+        self.graph.replay()
         return self.losses
 
 
@@ -555,6 +583,8 @@ class BatchedLearner(object):
                 flat(st.action_log_probs), flat(self.adv))
         out = []
         teams = [0] if train_guards_only else [0, 1]             # learner.py:177
+        if len(teams) == 2 and sampler is None and self._teams_step_ok(rows):
+            return self._update_teams_together(rows)
         for ti in teams:
             out.append(joint_ppo_update(
                 self.policies[ti], self.optimizers[ti], self.team_slices[ti], self.team_slices[1 - ti], rows,
@@ -562,6 +592,41 @@ class BatchedLearner(object):
                 self.max_grad_norm, self.clipped_value_loss, self.group, sampler,
                 graphs=None if sampler is not None else self._update_graphs))
         return torch.stack(out)
+
+    def _teams_step_ok(self, rows):
+        g = self._update_graphs
+        batch = rows[0].shape[0]
+        mb = int(batch / self.num_mini_batch) if batch >= self.num_mini_batch else 0
+        return (g is not None and g.get("fused", False) and g.get("teams_together", True) and _world(self.group) == 1
+                and mb > 0 and batch % mb == 0 and all(mpnn_pack.supported(p) for p in self.policies))
+
+    def _update_teams_together(self, rows):
+        """Both teams' JointPPO.update (learner.py:175-188 runs them one after the other; they share nothing but the
+        read-only rollout) with the optimizer steps of the two paired up, one hipGraph replay per pair
+        (GraphedTeamsStep).  The minibatch permutations are drawn in the sequential order -- all of the guards'
+        epochs, then all of the attackers' -- so the result is the sequential update's, step for step."""
+        g, batch, dev = self._update_graphs, rows[0].shape[0], rows[0].device
+        mb = int(batch / self.num_mini_batch)
+        perms = [[torch.randperm(batch, device=dev) for _ in range(self.ppo_epoch)] for _ in range(2)]
+        steps = []
+        for ti in range(2):
+            key = (id(self.policies[ti]), mb)
+            if key not in g:
+                g[key] = GraphedPPOStep(self.policies[ti], self.optimizers[ti], self.team_slices[ti], self.team_slices[1 - ti],
+                                        rows, mb, self.clip_param, self.value_loss_coef, self.entropy_coef, self.max_grad_norm,
+                                        self.clipped_value_loss, self.group, fused=True)
+            steps.append(g[key])
+            assert all(a.data_ptr() == b.data_ptr() for a, b in zip(rows, g[key].rows)), "the captured step reads the rollout in place"
+        if ("teams", mb) not in g:
+            g[("teams", mb)] = GraphedTeamsStep(steps)
+        pair = g[("teams", mb)]
+        acc = torch.zeros(2, 3, device=dev)
+        for epoch in range(self.ppo_epoch):
+            for k in range(0, batch, mb):
+                l0, l1 = pair.run((perms[0][epoch][k:k + mb], perms[1][epoch][k:k + mb]))
+                acc[0] += l0
+                acc[1] += l1
+        return acc / (self.ppo_epoch * self.num_mini_batch)
 
     def after_update(self):
         self.eng.after_update()

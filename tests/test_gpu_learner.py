@@ -216,3 +216,26 @@ def test_fused_update_follows_the_torch_update(fa, G, A, clipped):
     worst = max(float((x - y).abs().max()) for x, y in zip(p0, p1))
     print("max parameter distance fused vs torch: %.2e" % worst)
     assert worst < 4e-4                             # 8 Adam steps of 1e-4
+
+
+def test_update_of_both_teams_in_one_graph_is_the_sequential_update(fa):
+    """GraphedTeamsStep (the two teams' optimizer steps as parallel branches of one hipGraph, so that one launch's
+    tail round overlaps the other's tiles) against the same steps replayed one team after the other: identical
+    parameters and losses, bit for bit (the steps share nothing but the read-only rollout; no atomics anywhere)."""
+    res = []
+    for together in (False, True):
+        torch.manual_seed(5)
+        eng = fa.BatchedFortAttack(256, 3, 3, 12, base_seed=2)
+        L = fa.BatchedLearner(eng, num_steps=16, num_mini_batch=4, ppo_epoch=2, use_graph=True, update_backend="fused")
+        L._update_graphs["teams_together"] = together
+        L.reset()
+        for _ in range(2):
+            L.collect()
+            torch.manual_seed(41)
+            losses = L.update()
+            L.after_update()
+        torch.cuda.synchronize()
+        assert (("teams", 1024) in L._update_graphs) == together
+        res.append((losses.clone(), [p.detach().clone() for pol in L.policies for p in pol.parameters()]))
+    assert torch.equal(res[0][0], res[1][0])
+    assert all(torch.equal(a, b) for a, b in zip(res[0][1], res[1][1]))
