@@ -10,6 +10,7 @@ bash tools/profile_gpu.sh ${TAG}_perstep "--steps 20 --warmup 3 --no-cpu-baselin
 bash tools/pmc_probe.sh > gpurun_out/pmc_probe.txt 2>&1
 bash tools/pmc_policy.sh > gpurun_out/pmc_policy.txt 2>&1
 bash tools/prof_policy.sh ${TAG}_closed > gpurun_out/${TAG}_closed.txt 2>&1
+bash tools/prof_update.sh ${TAG}_update > gpurun_out/${TAG}_update.txt 2>&1
 python tools/sweep.py > gpurun_out/${TAG}_esweep.jsonl 2> gpurun_out/esweep.err
 python tools/perstep_probe.py > gpurun_out/${TAG}_perstep_probe.jsonl 2> gpurun_out/perstep_probe.err
 python bench.py > gpurun_out/${TAG}_bench_fused.json 2> gpurun_out/bench_fused.err
