@@ -185,6 +185,12 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args))
 
+    # The contract is ONE JSON line on stdout: anything a library prints there from C (gloo's connection banner
+    # does) goes to stderr instead; the real stdout comes back for the result line.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
 
@@ -364,7 +370,9 @@ def main():
             res["closed_loop"] = closed
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(E, G, A, T)
-        print(json.dumps(res))
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
+        print(json.dumps(res), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

@@ -1,0 +1,71 @@
+"""isa_lint (build.py runs it on every translation unit's gfx950 assembly): flags vector instructions placed ahead
+of the exec restore of a join block that waves / lanes reach by skipping a divergent region, and only those."""
+import importlib.util
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _lint():
+    spec = importlib.util.spec_from_file_location("_isa_lint", os.path.join(ROOT, "emergent-multiagent-strategies_amd", "isa_lint.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+BAD = """
+_Z6kernelv:
+	v_mov_b32_e32 v1, v0
+	s_and_saveexec_b64 s[2:3], vcc
+	s_cbranch_execz .LBB0_2
+; %bb.1:
+	global_store_dword v[6:7], v0, off
+.LBB0_2:
+	v_accvgpr_write_b32 a132, v186
+	s_mov_b32 s86, s77
+	s_or_b64 exec, exec, s[2:3]
+	v_readlane_b32 s0, v255, 33
+	s_endpgm
+"""
+
+GOOD = """
+_Z6kernelv:
+	s_and_saveexec_b64 s[2:3], vcc
+	s_cbranch_execz .LBB0_2
+; %bb.1:
+	v_add_f32_e32 v0, v0, v1
+	global_store_dword v[6:7], v0, off
+.LBB0_2:
+	v_writelane_b32 v255, s12, 35
+	s_or_b64 exec, exec, s[2:3]
+	v_accvgpr_write_b32 a132, v186
+.LBB0_3:
+	v_mul_f32_e32 v166, v166, v158
+	s_or_b64 exec, exec, s[4:5]
+	s_endpgm
+"""
+
+
+def test_misplaced_split_copy_is_flagged(tmp_path):
+    lint = _lint()
+    p = tmp_path / "bad.s"
+    p.write_text(BAD)
+    bad = lint.lint(str(p))
+    assert len(bad) == 1
+    kernel, block, (ln, line) = bad[0]
+    assert kernel == "_Z6kernelv" and block == ".LBB0_2" and line.startswith("v_accvgpr_write_b32 a132")
+    assert lint.lint(str(p), only="other_kernel") == []
+
+
+def test_clean_patterns_pass(tmp_path):
+    """Lane ops that ignore exec ahead of the restore, vector code after it, and an if-body that falls through
+    into its own exec restore (a block no execz branch targets) are all fine."""
+    lint = _lint()
+    p = tmp_path / "good.s"
+    p.write_text(GOOD)
+    assert lint.lint(str(p)) == []
+
+
+def test_build_runs_the_lint_on_every_source():
+    src = open(os.path.join(ROOT, "emergent-multiagent-strategies_amd", "build.py")).read()
+    assert "isa_lint.lint(" in src and "--cuda-device-only" in src and "raise RuntimeError" in src
