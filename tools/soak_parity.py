@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """One-off soak (run on the GPU box): the fused pipelined step kernel against the CPU oracle over many
 rollouts of shoot-heavy random actions -- counts differing flags / fp64 values.  usage: soak_parity.py [rollouts] [E] [G] [A]"""
-import os, sys, time
+import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import numpy as np, torch
@@ -35,5 +35,5 @@ for r in range(R):
         deaths += int(ref["was_hit"].sum()); ends += int(ref["done"].sum())
     if bad_flags:   # resynchronise would hide nothing: stop at the first divergence
         break
-print({"variant": eng.step_variant(T), "config": "%dv%d, E=%d, T=%d, max_time_steps=%d, P(shoot)=0.39" % (G, A, E, T, max_t), "env_steps": (r + 1) * T * E, "deaths": deaths, "episodes": ends, "differing_flags": bad_flags,
-       "differing_fp64_values": bad_f64, "worst_abs_diff": worst, "seconds": round(time.time() - t0, 1)})
+print(json.dumps({"variant": eng.step_variant(T), "config": "%dv%d, E=%d, T=%d, max_time_steps=%d, P(shoot)=0.39" % (G, A, E, T, max_t), "env_steps": (r + 1) * T * E, "deaths": deaths, "episodes": ends, "differing_flags": bad_flags,
+       "differing_fp64_values": bad_f64, "worst_abs_diff": worst, "seconds": round(time.time() - t0, 1)}))
