@@ -547,6 +547,9 @@ class BatchedLearner(object):
         the fused kernel's packed buffers, the torch path's fused / stacked operands."""
         if self._flat:
             for fp in self._flat:
+                if not fp.attached():   # e.g. a .to() / .data assignment after construction: the kernels would see stale weights
+                    raise RuntimeError("a policy's parameters no longer live in its flat buffer (mpnn_pack.FlatPolicy); "
+                                       "load weights in place (load_state_dict / copy_) instead of re-pointing them")
                 fp.fold_pack()
         for pol in self.policies + list(self.attacker_pool):
             pol.refresh_fused_weights()

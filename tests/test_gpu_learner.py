@@ -265,3 +265,19 @@ def test_fused_update_at_config3_size_follows_the_torch_update_and_is_reproducib
     worst = max(float((x - y).abs().max()) for x, y in zip(p_t, p_f))
     print("max parameter distance fused vs torch after 32 steps at 16 384 x 3 samples: %.2e" % worst)
     assert worst < 1.5e-3                           # 32 Adam steps of 1e-4, signs of near-zero gradients may differ
+
+
+def test_detached_parameters_are_refused(fa):
+    """The fused kernels read the policies through mpnn_pack.FlatPolicy's flat buffer: re-pointing a parameter
+    (instead of loading in place) must fail loudly, not run the rollout on stale weights."""
+    eng = fa.BatchedFortAttack(64, 3, 3, 10)
+    L = fa.BatchedLearner(eng, num_steps=8, num_mini_batch=2, ppo_epoch=1, use_graph=True)
+    L.reset()
+    L.collect()
+    sd = {k: v.clone() + 0.01 for k, v in L.policies[0].state_dict().items()}
+    L.policies[0].load_state_dict(sd)                       # in place: fine
+    L.collect()
+    p = next(L.policies[0].parameters())
+    p.data = p.data.clone()                                 # re-pointed
+    with pytest.raises(RuntimeError, match="flat buffer"):
+        L.collect()
