@@ -620,15 +620,33 @@ class BatchedLearner(object):
                                         self.clipped_value_loss, self.group, fused=True)
             steps.append(g[key])
             assert all(a.data_ptr() == b.data_ptr() for a, b in zip(rows, g[key].rows)), "the captured step reads the rollout in place"
-        if ("teams", mb) not in g:
-            g[("teams", mb)] = GraphedTeamsStep(steps)
-        pair = g[("teams", mb)]
         acc = torch.zeros(2, 3, device=dev)
+        if g.get("teams_mode", "streams") == "pairs":   # one graph per pair of steps, joined at its end
+            if ("teams", mb) not in g:
+                g[("teams", mb)] = GraphedTeamsStep(steps)
+            pair = g[("teams", mb)]
+            for epoch in range(self.ppo_epoch):
+                for k in range(0, batch, mb):
+                    l0, l1 = pair.run((perms[0][epoch][k:k + mb], perms[1][epoch][k:k + mb]))
+                    acc[0] += l0
+                    acc[1] += l1
+            return acc / (self.ppo_epoch * self.num_mini_batch)
+        # Two free-running chains, one stream per team: a team's step is its own graph, nothing joins the teams
+        # until the update is over.  While one chain is in the serial part of a step (reduction, unfold, clip,
+        # Adam, fold: ~0.2 ms in which it cannot use the GPU) or in the last round of its 781 tiles, the other's
+        # tiles fill the CUs.
+        if "team_streams" not in g:
+            g["team_streams"] = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
+        main = torch.cuda.current_stream()
+        for st in g["team_streams"]:
+            st.wait_stream(main)
         for epoch in range(self.ppo_epoch):
             for k in range(0, batch, mb):
-                l0, l1 = pair.run((perms[0][epoch][k:k + mb], perms[1][epoch][k:k + mb]))
-                acc[0] += l0
-                acc[1] += l1
+                for ti, st in enumerate(g["team_streams"]):      # (enqueued alternately: both chains start at once)
+                    with torch.cuda.stream(st):
+                        acc[ti] += steps[ti].run(rows, perms[ti][epoch][k:k + mb])
+        for st in g["team_streams"]:
+            main.wait_stream(st)
         return acc / (self.ppo_epoch * self.num_mini_batch)
 
     def after_update(self):

@@ -235,7 +235,7 @@ def test_update_of_both_teams_in_one_graph_is_the_sequential_update(fa):
             losses = L.update()
             L.after_update()
         torch.cuda.synchronize()
-        assert (("teams", 1024) in L._update_graphs) == together
+        assert ("team_streams" in L._update_graphs) == together
         res.append((losses.clone(), [p.detach().clone() for pol in L.policies for p in pol.parameters()]))
     assert torch.equal(res[0][0], res[1][0])
     assert all(torch.equal(a, b) for a, b in zip(res[0][1], res[1][1]))
