@@ -1,7 +1,7 @@
 // fa_fold.hip -- the small dense algebra around the fused PPO step, as two kernels instead of ~120 tiny
 // PyTorch launches per optimizer step (each ~5 us inside a hipGraph: a third of the step):
-//   * fa_task_kernel: a list of strided matrix products / copies C = alpha * op(A) op(B), one workgroup per
-//     task.  The host (mpnn_pack.FlatPolicy) writes the lists once: FOLD the module's parameters into the
+//   * fa_task_kernel: a list of strided matrix products / copies C = alpha * op(A) op(B), FA_TASK_SLICES
+//     workgroups per task.  The host (mpnn_pack.FlatPolicy) writes the lists once: FOLD the module's parameters into the
 //     kernel-facing matrices (A_o = norm W_key W_query^T, ... see mpnn_pack.py) and UNFOLD the gradients of
 //     those matrices back onto the parameters (the chain rule of the same products).
 //   * fa_pack_kernel: plain row-major matrices -> the MFMA B-operand lane order of fa_policy.h, forward and

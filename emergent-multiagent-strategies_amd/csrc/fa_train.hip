@@ -12,9 +12,10 @@
 //
 // Weight gradients: a tile writes its partial dW set to its own slab (plain row-major, 390 KB); a second small
 // kernel sums the slabs in tile order -- no atomics, bitwise reproducible.  dA_m, dW7 (shared by the three
-// message-passing rounds) are accumulated in registers across the rounds.  What the host does with the result
-// (chain rule from the folded matrices to the module's parameters, loss normalisation by the alive-mask mean,
-// clip, Adam) is a handful of small torch ops: see learner.FusedPPOStep.
+// message-passing rounds) are accumulated in registers across the rounds.  Around it (learner.GraphedPPOStep):
+// fa_fold.hip builds the weight packs from the module's parameters and carries the gradients back to them; the
+// alive-mask mean (fa_mask_part_kernel, folded by every workgroup here), the gradient-norm clip and Adam
+// (fa_sqnorm_part_kernel, fa_adam_kernel) are at the end of this file.
 //
 // Saved for the backward: the hidden state after the opponent stage and after rounds 1 and 2 (global scratch,
 // 96 KB per tile), all attention weights (LDS); g = h A, the attention mixes and the opponents' encodings are
