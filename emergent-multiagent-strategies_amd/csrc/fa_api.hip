@@ -621,6 +621,7 @@ int fa_ppo_grad(const fa_ppo_grad_io *io, void *stream) {
     a.B = io->B; a.G = io->num_guards; a.A = io->num_attackers; a.team = io->team;
     a.clip = io->clip_param; a.c_value = io->value_loss_coef; a.c_entropy = io->entropy_coef;
     a.clipped_value_loss = io->clipped_value_loss;
+    a.share_cu = io->share_cu != 0 && io->idx != nullptr;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int et = fa_train_tile_envs(a.G, a.A);
     if (!a.scale) { // partial mask sums behind the tiles' slabs; the scale pair is left behind the loss sums of `out`

@@ -45,6 +45,7 @@ struct FaTrainArgs {
     const float *mask_part;    // with scale == null: FA_MASK_PARTS partial alive-mask sums (fa_launch_mask_parts); the
     float *scale_out;          // kernel derives the scale pair itself (`normalize`: divide by the mask mean) and
     int32_t normalize;         // workgroup 0 leaves it at scale_out[0..1]
+    int32_t share_cu;          // leave 48 registers per lane of every CU to concurrent small launches (fa_train.hip)
     const float *scale;        // device float[2]: {1 / (B n mask_mean'), mask_mean'} with mask_mean' = the alive-mask
                                // mean of the minibatch (1 where that is 0, or when the caller normalises later:
                                // several ranks).  [0] multiplies every loss gradient; [1] undoes it for the

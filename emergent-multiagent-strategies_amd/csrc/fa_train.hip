@@ -162,8 +162,18 @@ __device__ __forceinline__ void attend_env_bwd(const float *dout0, float *g0, co
 }
 
 // GATHER: the minibatch is rows a.idx[.] of the rollout arrays (else rows 0..B)
+// SHARE: amdgpu_num_vgpr(232) = 464 of a SIMD's 512 registers per lane (the compiler takes 256 + 208 accumulation
+// registers).  The kernel would use all 512 -- and then NOTHING else fits on a CU it occupies: when the two teams'
+// updates run as concurrent chains, the other team's small launches (fold / unfold tasks at 48 registers, the
+// slab reduction, clip, Adam) waited for whole tiles to retire (fa_task_kernel 134 us in flight instead of 11).
+// 48 registers per lane left free cost this kernel 2-3 % and bring the update from 0.276 to 0.260 s (a sweep:
+// 240 -> 0.284, 232 -> 0.260, 224 -> 0.263, 216 -> 0.261, 208 -> 0.270, 192 -> 0.279); a lone chain
+// (guards-only training, FaTrainArgs::share_cu = 0) runs the uncapped build.
+#ifndef FA_TRAIN_NUM_VGPR
+#define FA_TRAIN_NUM_VGPR 232
+#endif
 template <bool GATHER>
-__global__ __launch_bounds__(256, 1) void fa_train_kernel(FaTrainArgs a) {
+__device__ __forceinline__ void fa_train_body(const FaTrainArgs &a) {
     __shared__ __attribute__((aligned(16))) float B0[TR * LDA], B1[TR * LDA], B2[TR * LDA], B3[TR * LDA];
     __shared__ float sX[TR * 2 * FA_OBS_DIM];
     __shared__ __attribute__((aligned(16))) float sO[TR * SOW];
@@ -658,21 +668,33 @@ __global__ __launch_bounds__(256, 1) void fa_train_kernel(FaTrainArgs a) {
     FA_TR_TICK(32)
 }
 
-// out[k] = sum_t slabs[t][k] in tile order (sixteen interleaved partial sums: sixteen loads in flight per lane)
-__global__ void fa_train_reduce_kernel(const float *__restrict__ slabs, int tiles, float *__restrict__ out) {
+template <bool GATHER>
+__global__ __launch_bounds__(256, 1) void fa_train_kernel(FaTrainArgs a) { fa_train_body<GATHER>(a); }
+// (the attribute takes a literal, not a template argument: hence a second kernel and not a third parameter)
+__global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(FA_TRAIN_NUM_VGPR))) void fa_train_share_kernel(FaTrainArgs a) {
+    fa_train_body<true>(a);
+}
+
+// out[k] = sum_t slabs[t][k] in tile order (FA_RED_U interleaved partial sums = loads in flight per lane.  With 8
+// it would fit beside fa_train_share_kernel on a CU -- measured: 0.265 s per update instead of 0.260; this is the
+// one bandwidth-heavy launch of a step and does better waiting for whole CUs)
+#ifndef FA_RED_U
+#define FA_RED_U 16
+#endif
+__global__ __launch_bounds__(128) void fa_train_reduce_kernel(const float *__restrict__ slabs, int tiles, float *__restrict__ out) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= FA_SLAB_LOSS + 8) return;
-    float s[16];
+    float s[FA_RED_U];
 #pragma unroll
-    for (int u = 0; u < 16; ++u) s[u] = 0.0f;
+    for (int u = 0; u < FA_RED_U; ++u) s[u] = 0.0f;
     int t = 0;
-    for (; t + 16 <= tiles; t += 16) {
+    for (; t + FA_RED_U <= tiles; t += FA_RED_U) {
 #pragma unroll
-        for (int u = 0; u < 16; ++u) s[u] += slabs[(size_t)(t + u) * FA_SLAB_FLOATS + k];
+        for (int u = 0; u < FA_RED_U; ++u) s[u] += slabs[(size_t)(t + u) * FA_SLAB_FLOATS + k];
     }
     for (; t < tiles; ++t) s[0] += slabs[(size_t)t * FA_SLAB_FLOATS + k];
 #pragma unroll
-    for (int w = 8; w >= 1; w >>= 1)
+    for (int w = FA_RED_U / 2; w >= 1; w >>= 1)
 #pragma unroll
         for (int u = 0; u < w; ++u) s[u] += s[u + w];
     out[k] = s[0];
@@ -680,33 +702,28 @@ __global__ void fa_train_reduce_kernel(const float *__restrict__ slabs, int tile
 
 // The alive-mask sum of the minibatch's own-team rows as FA_MASK_PARTS partial sums (one workgroup each; the
 // train kernel's workgroups fold them in a fixed order: reproducible, and no single-workgroup latency chain)
-__global__ __launch_bounds__(256) void fa_mask_part_kernel(FaTrainArgs a, float *__restrict__ part) {
-    __shared__ float wsum[4];
+__global__ __launch_bounds__(64) void fa_mask_part_kernel(FaTrainArgs a, float *__restrict__ part) {
+    // (one wave, no LDS: a CU busy with fa_train_kernel has 1 KB of LDS left, below the allocation granule)
     const int N = a.G + a.A, n = a.team == 0 ? a.G : a.A, own0 = a.team == 0 ? 0 : a.G;
     float s = 0.0f;
-    for (int b = blockIdx.x * 256 + threadIdx.x; b < a.B; b += FA_MASK_PARTS * 256) {
+    for (int b = blockIdx.x * 64 + threadIdx.x; b < a.B; b += FA_MASK_PARTS * 64) {
         const float *row = a.obs + (size_t)(a.idx ? a.idx[b] : b) * N * FA_OBS_DIM;
         for (int i = 0; i < n; ++i) s += row[(own0 + i) * FA_OBS_DIM];
     }
     for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d);
-    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) part[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+    if (threadIdx.x == 0) part[blockIdx.x] = s;
 }
 
 // ---- clip_grad_norm_ + Adam on the flat parameter buffer -------------------------------------------------------
 // ||g||^2 as FA_NORM_PARTS fp64 partial sums (scratch + 4, 16-byte aligned); the step counters advance here.
-__global__ __launch_bounds__(256) void fa_sqnorm_part_kernel(const float *__restrict__ g, int n, double *__restrict__ part,
-                                                             float *__restrict__ steps, int nseg) {
-    __shared__ double wsum[4];
-    double s = 0.0;
-    for (int k = blockIdx.x * 256 + threadIdx.x; k < n; k += FA_NORM_PARTS * 256) s += (double)g[k] * (double)g[k];
+__global__ __launch_bounds__(64) void fa_sqnorm_part_kernel(const float *__restrict__ g, int n, double *__restrict__ part,
+                                                            float *__restrict__ steps, int nseg) {
+    double s = 0.0; // (one wave, no LDS: see fa_mask_part_kernel)
+    for (int k = blockIdx.x * 64 + threadIdx.x; k < n; k += FA_NORM_PARTS * 64) s += (double)g[k] * (double)g[k];
     for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d);
-    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) part[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+    if (threadIdx.x == 0) part[blockIdx.x] = s;
     if (blockIdx.x == 0)
-        for (int k = threadIdx.x; k < nseg; k += 256) steps[k] += 1.0f;
+        for (int k = threadIdx.x; k < nseg; k += 64) steps[k] += 1.0f;
 }
 
 // coef = min(1, max_norm / (||g|| + 1e-6)) (torch.nn.utils.clip_grad_norm_), then torch.optim.Adam's update
@@ -738,8 +755,10 @@ int fa_train_tile_envs(int G, int A) { return TR / (G > A ? G : A); }
 
 hipError_t fa_launch_train(const FaTrainArgs &a, hipStream_t st) {
     const int ET = fa_train_tile_envs(a.G, a.A);
-    if (a.idx) hipLaunchKernelGGL(fa_train_kernel<true>, dim3((a.B + ET - 1) / ET), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(fa_train_kernel<false>, dim3((a.B + ET - 1) / ET), dim3(256), 0, st, a);
+    const dim3 grid((a.B + ET - 1) / ET), block(256);
+    if (a.idx && a.share_cu) hipLaunchKernelGGL(fa_train_share_kernel, grid, block, 0, st, a);
+    else if (a.idx) hipLaunchKernelGGL(fa_train_kernel<true>, grid, block, 0, st, a);
+    else hipLaunchKernelGGL(fa_train_kernel<false>, grid, block, 0, st, a);
     return hipGetLastError();
 }
 
@@ -749,13 +768,13 @@ hipError_t fa_launch_train_reduce(const float *slabs, int tiles, float *out, hip
 }
 
 hipError_t fa_launch_mask_parts(const FaTrainArgs &a, float *part, hipStream_t st) {
-    hipLaunchKernelGGL(fa_mask_part_kernel, dim3(FA_MASK_PARTS), dim3(256), 0, st, a, part);
+    hipLaunchKernelGGL(fa_mask_part_kernel, dim3(FA_MASK_PARTS), dim3(64), 0, st, a, part);
     return hipGetLastError();
 }
 
 hipError_t fa_launch_adam(float *p, float *g, float *m, float *v, float *steps, const int32_t *seg, int nseg, int n,
                           float lr, float beta1, float beta2, float eps, float max_norm, float *scratch, hipStream_t st) {
-    hipLaunchKernelGGL(fa_sqnorm_part_kernel, dim3(FA_NORM_PARTS), dim3(256), 0, st, g, n, reinterpret_cast<double *>(scratch + 4),
+    hipLaunchKernelGGL(fa_sqnorm_part_kernel, dim3(FA_NORM_PARTS), dim3(64), 0, st, g, n, reinterpret_cast<double *>(scratch + 4),
                        steps, nseg);
     hipLaunchKernelGGL(fa_adam_kernel, dim3((n + 255) / 256), dim3(256), 0, st, p, g, m, v, steps, seg, nseg, lr, beta1, beta2,
                        eps, max_norm, scratch);

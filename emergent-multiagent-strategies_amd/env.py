@@ -516,7 +516,7 @@ def make_fortattack_env(num_steps, benchmark=False, num_guards=5, num_attackers=
 
 
 def ppo_grad(obs, action, value_pred, ret, old_logp, adv, w, wt, scale, team, G, A, clip, c_value, c_entropy,
-             clipped_value_loss=True, scratch=None, out=None, idx=None, normalize=True):
+             clipped_value_loss=True, scratch=None, out=None, idx=None, normalize=True, share_cu=False):
     """fa_ppo_grad: one team's PPO minibatch forward + losses + backward in one fused launch (+ reduction).
     obs (rows, N, 6) float32; action (rows, N[, 1]) int64; value_pred / ret / old_logp / adv (rows, N[, 1]) float32;
     idx: int64 row indices of the minibatch (None: every row); w / wt the packed weights and their transposes
@@ -544,5 +544,6 @@ def ppo_grad(obs, action, value_pred, ret, old_logp, adv, w, wt, scale, team, G,
     io.B, io.num_guards, io.num_attackers, io.team = B, G, A, team
     io.clip_param, io.value_loss_coef, io.entropy_coef = clip, c_value, c_entropy
     io.clipped_value_loss, io.normalize = int(bool(clipped_value_loss)), int(bool(normalize))
+    io.share_cu = int(bool(share_cu))    # leave room on the CUs for another stream's small launches (fa_train.hip)
     _lib.check(lib.fa_ppo_grad(C.byref(io), _stream()), "fa_ppo_grad")
     return out, scratch

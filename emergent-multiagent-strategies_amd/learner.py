@@ -75,7 +75,7 @@ class GraphedPPOStep(object):
     before the first real step."""
 
     def __init__(self, pol, opt, own_sl, opp_sl, rows, mb, clip_param, value_loss_coef, entropy_coef, max_grad_norm,
-                 clipped_value_loss, group, fused=False):
+                 clipped_value_loss, group, fused=False, share_cu=False):
         self.pol, self.opt, self.group, self.world = pol, opt, group, _world(group)
         self.params = [p for p in pol.parameters()]
         self.fused = bool(fused)
@@ -107,7 +107,7 @@ class GraphedPPOStep(object):
             w, wt = fp.fold_pack()
             _, self._scratch = ppo_grad(*self.rows, w, wt, None, team, G, N - G, clip_param, value_loss_coef, entropy_coef,
                                         clipped_value_loss, scratch=self._scratch, out=self._out, idx=self.idx,
-                                        normalize=(world == 1))
+                                        normalize=(world == 1), share_cu=share_cu)
             fp.attach_grads()               # every parameter's .grad is its slice of fp.gflat
             fp.unfold(self._out)
             sums = self._out[LOSS:LOSS + 3] * inv_count
@@ -613,11 +613,11 @@ class BatchedLearner(object):
         perms = [[torch.randperm(batch, device=dev) for _ in range(self.ppo_epoch)] for _ in range(2)]
         steps = []
         for ti in range(2):
-            key = (id(self.policies[ti]), mb)
+            key = (id(self.policies[ti]), mb, "shared")     # (the build of fa_train_kernel that leaves room on its CUs)
             if key not in g:
                 g[key] = GraphedPPOStep(self.policies[ti], self.optimizers[ti], self.team_slices[ti], self.team_slices[1 - ti],
                                         rows, mb, self.clip_param, self.value_loss_coef, self.entropy_coef, self.max_grad_norm,
-                                        self.clipped_value_loss, self.group, fused=True)
+                                        self.clipped_value_loss, self.group, fused=True, share_cu=True)
             steps.append(g[key])
             assert all(a.data_ptr() == b.data_ptr() for a, b in zip(rows, g[key].rows)), "the captured step reads the rollout in place"
         acc = torch.zeros(2, 3, device=dev)
