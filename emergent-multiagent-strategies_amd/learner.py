@@ -64,15 +64,20 @@ def _world(group=None):
 
 class GraphedPPOStep(object):
     """One optimizer step of joint_ppo_update -- minibatch forward, backward, (gradient exchange,) clip, Adam --
-    captured as hipGraph(s) and replayed.  `fused`: forward, losses and backward are ONE launch of the fa_ppo_grad
-    kernel (csrc/fa_train.hip) instead of PyTorch autograd.  Why graphs: the step is ~300 small kernels and its Python / dispatcher time
-    (4 ms) exceeds its GPU time (2.7 ms at 16 384 x 3 samples); replayed, only the GPU time is left.
+    captured as hipGraph(s) and replayed with a new minibatch index set.
 
-    The minibatch is gathered into static buffers (index_select, outside the graph); parameters, gradients
-    and Adam state are the live tensors (the optimizer must be `capturable`).  One rank: one graph.  Several
-    ranks: two graphs around the eager all-reduce of the flat buffer (see joint_ppo_update).  Capture needs
-    warm-up iterations; they run on this minibatch and are undone (parameters and optimizer state restored)
-    before the first real step."""
+    `fused` (csrc/fa_train.hip, fa_fold.hip): fold the parameters into weight packs, fa_ppo_grad on rows
+    idx of the rollout read in place (forward + losses + backward in one launch), unfold the gradients, fa_adam_step
+    on the flat parameter / gradient / moment buffers of mpnn_pack.FlatPolicy: ~16 graph nodes, no autograd.
+    `share_cu`: the build of the kernel that leaves room on its CUs (two teams updated concurrently).
+    Otherwise PyTorch autograd on a minibatch gathered into static buffers (index_select, outside the graph): ~300
+    small kernels whose Python / dispatcher time (4 ms) exceeded their GPU time (2.7 ms at 16 384 x 3 samples)
+    before they were replayed from a graph.
+
+    Parameters, gradients and Adam state are the live tensors (the optimizer must be `capturable`).  One rank: one
+    graph.  Several ranks: two graphs around the eager all-reduce of the flat buffer (see joint_ppo_update).
+    Capture needs warm-up iterations; they run on the first mb rows and are undone (parameters and optimizer state
+    restored) before the first real step."""
 
     def __init__(self, pol, opt, own_sl, opp_sl, rows, mb, clip_param, value_loss_coef, entropy_coef, max_grad_norm,
                  clipped_value_loss, group, fused=False, share_cu=False):
