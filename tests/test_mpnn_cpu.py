@@ -201,3 +201,36 @@ def test_folded_training_trunk_equals_reference_shaped_trunk(n, m):
     for k in set(grads[0][1]) | set(grads[1][1]):
         a, b = [g[1].get(k, torch.zeros_like(dict(pol.named_parameters())[k])) for g in grads]
         assert (a - b).abs().max() <= 1e-4 * max(1.0, float(a.abs().max())), k
+
+
+def test_flat_policy_layout_on_cpu():
+    """mpnn_pack.FlatPolicy (construction needs no GPU): every parameter the kernels use lives in ONE buffer, in
+    disjoint slices that cover it exactly, the module keeps working on them, in-place loads keep the aliasing and a
+    re-pointed parameter is detected."""
+    import torch
+    from emergent_multiagent_strategies_amd import mpnn_pack as mp_
+    from emergent_multiagent_strategies_amd.mpnn import MPNN
+    torch.manual_seed(0)
+    pol = MPNN(num_agents=3, num_opp_agents=3, hidden_dim=128, num_actions=8)
+    ref = {k: v.clone() for k, v in pol.state_dict().items()}
+    x_own, x_opp = torch.randn(5, 3, 6), torch.randn(5, 3, 6)
+    before = pol.evaluate_actions(x_own, x_opp, torch.zeros(5, 3, 1, dtype=torch.int64))
+    fp = mp_.FlatPolicy.of(pol)
+    assert mp_.FlatPolicy.of(pol) is fp and fp.attached()
+    spans = sorted((off, off + get(pol).numel()) for _, get, off in mp_._PF)
+    assert spans[0][0] == 0 and spans[-1][1] == mp_.PF_FLOATS
+    assert all(0 <= b[0] - a[1] < 4 for a, b in zip(spans, spans[1:]))     # disjoint; holes only to keep 16-byte alignment
+    assert all(a[0] % 4 == 0 for a in spans)
+    for k, v in pol.state_dict().items():
+        assert torch.equal(v, ref[k])                                      # the values moved with the parameters
+    after = pol.evaluate_actions(x_own, x_opp, torch.zeros(5, 3, 1, dtype=torch.int64))
+    assert all(torch.equal(a, b) for a, b in zip(before, after))
+    for _, get, off in mp_._PF:                                            # gradients alias the flat gradient buffer
+        p = get(pol)
+        assert p.grad.data_ptr() == fp.gflat.data_ptr() + 4 * off
+    pol.load_state_dict({k: v + 1.0 for k, v in ref.items()})              # in place: still attached
+    assert fp.attached() and float(fp.pflat[0]) == float(next(iter(mp_._PF))[1](pol).reshape(-1)[0])
+    p = mp_._PF[0][1](pol)
+    p.data = p.data.clone()
+    assert not fp.attached()
+    assert mp_.FlatPolicy.of(pol) is not fp                                # a detached one is rebuilt, not reused
