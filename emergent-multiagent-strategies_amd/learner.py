@@ -190,7 +190,6 @@ class GraphedPPOStep(object):
                 for k, v in opt.state.get(p, {}).items():
                     if torch.is_tensor(v):
                         v.copy_(saved_s[p][k]) if had_state and p in saved_s else v.zero_()
-        self._eager = eager
         # ---- capture -----------------------------------------------------------------------------------
         self.g1 = torch.cuda.CUDAGraph()
         self.g2 = None
@@ -215,33 +214,6 @@ class GraphedPPOStep(object):
         if self.g2 is not None:
             dist.all_reduce(self.flat, group=self.group)
             self.g2.replay()
-        return self.losses
-
-
-class GraphedTeamsStep(object):
-    """One optimizer step of BOTH teams as one hipGraph with two parallel branches (the teams' policies, optimizers
-    and minibatch index sets are independent; the rollout rows are only read).  Why: a team's fa_ppo_grad launch is
-    781 workgroup tiles on 256 CUs at 3v3 x 16 384 samples -- three full rounds and a fourth with 13 tiles; with the
-    other team's launch in flight the idle CUs of that tail take its tiles (1 562 tiles: 6.1 -> 7 rounds, not 8)."""
-
-    def __init__(self, steps):
-        assert all(st.fused and st.world == 1 for st in steps)
-        self.steps = steps
-        self.side = torch.cuda.Stream(steps[0].idx.device)
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph, pool=steps[0].g1.pool()):
-            main = torch.cuda.current_stream()
-            self.side.wait_stream(main)                          # fork
-            l0 = steps[0]._eager()
-            with torch.cuda.stream(self.side):
-                l1 = steps[1]._eager()
-            main.wait_stream(self.side)                          # join
-            self.losses = (l0, l1)
-
-    def run(self, idx_pair):
-        for st, idx in zip(self.steps, idx_pair):
-            st.idx.copy_(idx)
-        self.graph.replay()
         return self.losses
 
 
@@ -610,9 +582,9 @@ class BatchedLearner(object):
 
     def _update_teams_together(self, rows):
         """Both teams' JointPPO.update (learner.py:175-188 runs them one after the other; they share nothing but the
-        read-only rollout) with the optimizer steps of the two paired up, one hipGraph replay per pair
-        (GraphedTeamsStep).  The minibatch permutations are drawn in the sequential order -- all of the guards'
-        epochs, then all of the attackers' -- so the result is the sequential update's, step for step."""
+        read-only rollout) as two concurrent chains of optimizer steps.  The minibatch permutations are drawn in the
+        sequential order -- all of the guards' epochs, then all of the attackers' -- so the result is the
+        sequential update's, step for step."""
         g, batch, dev = self._update_graphs, rows[0].shape[0], rows[0].device
         mb = int(batch / self.num_mini_batch)
         perms = [[torch.randperm(batch, device=dev) for _ in range(self.ppo_epoch)] for _ in range(2)]
@@ -626,16 +598,6 @@ class BatchedLearner(object):
             steps.append(g[key])
             assert all(a.data_ptr() == b.data_ptr() for a, b in zip(rows, g[key].rows)), "the captured step reads the rollout in place"
         acc = torch.zeros(2, 3, device=dev)
-        if g.get("teams_mode", "streams") == "pairs":   # one graph per pair of steps, joined at its end
-            if ("teams", mb) not in g:
-                g[("teams", mb)] = GraphedTeamsStep(steps)
-            pair = g[("teams", mb)]
-            for epoch in range(self.ppo_epoch):
-                for k in range(0, batch, mb):
-                    l0, l1 = pair.run((perms[0][epoch][k:k + mb], perms[1][epoch][k:k + mb]))
-                    acc[0] += l0
-                    acc[1] += l1
-            return acc / (self.ppo_epoch * self.num_mini_batch)
         # Two free-running chains, one stream per team: a team's step is its own graph, nothing joins the teams
         # until the update is over.  While one chain is in the serial part of a step (reduction, unfold, clip,
         # Adam, fold: ~0.2 ms in which it cannot use the GPU) or in the last round of its 781 tiles, the other's

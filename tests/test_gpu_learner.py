@@ -219,9 +219,9 @@ def test_fused_update_follows_the_torch_update(fa, G, A, clipped):
 
 
 def test_update_of_both_teams_in_one_graph_is_the_sequential_update(fa):
-    """GraphedTeamsStep (the two teams' optimizer steps as parallel branches of one hipGraph, so that one launch's
-    tail round overlaps the other's tiles) against the same steps replayed one team after the other: identical
-    parameters and losses, bit for bit (the steps share nothing but the read-only rollout; no atomics anywhere)."""
+    """The two teams' updates as concurrent chains on two streams (BatchedLearner._update_teams_together, with the
+    register-capped build of the train kernel) against the same steps replayed one team after the other: identical
+    parameters and losses, bit for bit (the chains share nothing but the read-only rollout; no atomics anywhere)."""
     res = []
     for together in (False, True):
         torch.manual_seed(5)
