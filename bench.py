@@ -425,9 +425,10 @@ def closed_loop(fa, args, rank, local_rank, world, dev, barrier):
         "rollout_env_steps_per_s": world * E * T / per_rollout, "rollout_ms": per_rollout * 1e3,
         "ms_per_env_step_launch": per_rollout * 1e3 / T, "rollouts_timed": R,
         "update_s": t_upd, "train_env_steps_per_s": world * E * T / (per_rollout + t_upd),
-        "update": "JointPPO: 4 epochs x 32 minibatches x 2 teams, Adam, grad-clip; every optimizer step replayed from a "
-                  "hipGraph%s" % (
-            "" if world == 1 else ", flat gradient all-reduce per optimizer step"),
+        "update": "JointPPO: 4 epochs x 32 minibatches x 2 teams, Adam, grad-clip; every optimizer step (fused forward + "
+                  "losses + backward kernel, fold / unfold, clip + Adam on flat buffers) replayed from a hipGraph, %s" % (
+            "the two teams as concurrent chains on two streams" if world == 1 else
+            "flat gradient all-reduce per optimizer step, teams one after the other"),
         "dtype": "f32 policy / f64 env", "unit": "env-steps/s"}
 
 
