@@ -10,9 +10,9 @@ all-gather of N x 3 doubles when --gpus > 1).  Inputs are in HBM before the time
 That is BASELINE config 2 ("random policy, step-kernel only") plus the collector: `value`.
 
 The same JSON line carries a second record, `closed_loop` = BASELINE config 3 (config 4 when
---gpus > 1): the MPNN actor-critic (PyTorch-ROCm) in the loop -- per env-step one two-team forward,
-sampling and one fa_collect_step, then V(obs[T]), GAE and the advantage statistics -- and the
-PPO update after it.
+--gpus > 1): the MPNN actor-critic in the loop (fa_collect_act: the fused forward + sampling kernel; the
+PyTorch module is its definition and fallback) -- per env-step one two-team forward, sampling and one
+fa_collect_step, then V(obs[T]), GAE and the advantage statistics -- and the PPO update after it.
 
     python bench.py --gpus 1 --steps 20 --warmup 3
     python bench.py --gpus 8                      # spawns 8 ranks itself (torch.distributed.run)
