@@ -218,14 +218,15 @@ def test_fused_update_follows_the_torch_update(fa, G, A, clipped):
     assert worst < 4e-4                             # 8 Adam steps of 1e-4
 
 
-def test_update_of_both_teams_in_one_graph_is_the_sequential_update(fa):
+@pytest.mark.parametrize("G,A", [(3, 3), (5, 5), (2, 4)])
+def test_update_of_both_teams_in_one_graph_is_the_sequential_update(fa, G, A):
     """The two teams' updates as concurrent chains on two streams (BatchedLearner._update_teams_together, with the
     register-capped build of the train kernel) against the same steps replayed one team after the other: identical
     parameters and losses, bit for bit (the chains share nothing but the read-only rollout; no atomics anywhere)."""
     res = []
     for together in (False, True):
         torch.manual_seed(5)
-        eng = fa.BatchedFortAttack(256, 3, 3, 12, base_seed=2)
+        eng = fa.BatchedFortAttack(256, G, A, 12, base_seed=2)
         L = fa.BatchedLearner(eng, num_steps=16, num_mini_batch=4, ppo_epoch=2, use_graph=True, update_backend="fused")
         L._update_graphs["teams_together"] = together
         L.reset()
