@@ -28,10 +28,16 @@ def main():
     ap.add_argument("--update-backend", default="auto", choices=["auto", "fused", "torch"])
     ap.add_argument("--ensemble", type=int, default=0, help="K frozen attacker strategies, one per env, re-drawn at "
                                                               "every reset (BASELINE config 5); guards only are trained")
+    ap.add_argument("--epochs", type=int, default=4, help="ppo_epoch (4 = the reference's default)")
+    ap.add_argument("--sequential-teams", action="store_true", help="update the teams one after the other (profiling: "
+                                                                    "every launch then has the GPU to itself)")
     a = ap.parse_args()
     torch.manual_seed(0)
     eng = fa.BatchedFortAttack(a.envs, a.guards, a.attackers, 100, base_seed=0, track_counters=False)
-    L = fa.BatchedLearner(eng, num_steps=a.rollout, use_graph=bool(a.graph), policy_backend=a.backend, update_backend=a.update_backend)
+    L = fa.BatchedLearner(eng, num_steps=a.rollout, use_graph=bool(a.graph), policy_backend=a.backend, update_backend=a.update_backend,
+                          ppo_epoch=a.epochs)
+    if a.sequential_teams and L._update_graphs is not None:
+        L._update_graphs["teams_together"] = False
     if a.ensemble:
         L.load_attacker_ensemble([fa.MPNN(num_agents=a.attackers, num_opp_agents=a.guards, num_actions=8).state_dict()
                                   for _ in range(a.ensemble)])
