@@ -35,6 +35,27 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~4.7 TB/s measured copy
 
 
+MFMA_F32_PEAK_TFLOPS = 157.3  # v_mfma_f32_32x32x2_f32: 256 CUs x 4 SIMDs x 64 flop/cycle x 2.4 GHz (MI355X_MICROARCH.md)
+
+
+def policy_flops_per_row(n, m):
+    """Algorithmic flops of the MPNN actor-critic forward (mpnn.py:117-205, folded as DESIGN.md 3.5) per (env, agent)
+    row of a team of n facing m opponents: encoders 6x64 (own; the opponents' m rows shared by the n own rows), the
+    opponent stage (64x64 projection, m scores + mix over 64, 64x64 output), three rounds of (128x128 projection,
+    n-1 scores + mix over 128, 256x128 update), the two 128x128 heads, 128x8 logits + 128x1 value.  2 flop per MAC."""
+    mac = 6 * 64 + 6 * 64 * m / n + 64 * 64 + 2 * m * 64 + 64 * 64
+    mac += 3 * (128 * 128 + 2 * (n - 1) * 128 + 256 * 128)
+    mac += 128 * 256 + 128 * 8 + 128
+    return 2.0 * mac
+
+
+def train_flops_per_row(n, m):
+    """fa_train_kernel: forward as above + the backward (two GEMMs per forward GEMM: dX and dW) + the
+    recomputed g = h A_m of the three rounds."""
+    fwd = policy_flops_per_row(n, m)
+    return 3.0 * fwd + 2.0 * 3 * 128 * 128
+
+
 def measured_stream():
     """What plain streaming kernels sustain on the box (tools/ubench_hbm.hip, committed record):
     context for `peak` (the 8 TB/s vendor figure the roofline is priced against)."""
@@ -126,6 +147,16 @@ def cpu_baseline(E, G, A, T, budget_s=20.0):
     best = max(runs, key=lambda r: r["env_steps_per_s"])
     single = next((r for r in runs if r["threads"] == 1), best)
     per_step = run(best["threads"], "step", best.get("envs", E))   # one parallel region per env-step (round-1 form)
+    # BASELINE config 1's counterpart: ONE env on ONE thread, 128-step rollout -- the C oracle env alone,
+    # and with this repo's MPNN (h = 128) on the CPU + the numpy collector oracle in the loop (train_fortattack.py:51-110's
+    # shape); the reference's own Python on a Xeon thread: 2 580 env-only / 278 rollout env-steps/s
+    one_env = run(1, "rollout", 1)
+    try:
+        c1 = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_config1_cpu.py")], capture_output=True, text=True,
+                            timeout=300, env=dict(os.environ, OMP_NUM_THREADS="1"))
+        config1 = json.loads(c1.stdout.strip().splitlines()[-1])
+    except Exception as exc:
+        config1 = {"error": repr(exc)}
     return {"value": best["env_steps_per_s"], "unit": "env-steps/s", "cores": best["threads"], "kind": "port",
             "cpu_model": model, "physical_cores": phys_cores, "hardware_threads": hw_threads,
             "cgroup_cpu_quota": quota,   # CPUs' worth of time this container may use (None = unlimited)
@@ -138,6 +169,8 @@ def cpu_baseline(E, G, A, T, budget_s=20.0):
                           [(r["threads"], int(r["env_steps_per_s"])) for r in runs], avail,
                           single["env_steps_per_s"], per_step["env_steps_per_s"]),
             "single_thread": single["env_steps_per_s"],
+            "single_env_single_thread": {"env_only_c_oracle_env_steps_per_s": one_env["env_steps_per_s"],
+                                         "config1_counterpart": config1},
             "reference_python_note": "the reference's own Python env.step, measured in the survey container on "
                                      "1 Xeon 2.1 GHz thread: 2580 env-steps/s at 3v3 (BASELINE.md section 3); "
                                      "it cannot run on the GPU box"}
@@ -175,7 +208,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-collector", action="store_true", help="time the step kernel only")
     ap.add_argument("--no-closed-loop", action="store_true", help="skip the closed_loop record (MPNN in the loop)")
-    ap.add_argument("--closed-loop-rollouts", type=int, default=3)
+    ap.add_argument("--closed-loop-rollouts", type=int, default=20)
+    ap.add_argument("--closed-loop-updates", type=int, default=3)
+    ap.add_argument("--no-esweep", action="store_true", help="skip the E-sweep record (fused launch at 32 768 ... 1 048 576 envs)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL on ROCm)")
     ap.add_argument("--share-devices", action="store_true",
                     help="map ranks onto the visible GPUs round-robin (smoke-testing the multi-rank "
@@ -366,8 +401,16 @@ def main():
                     steps * launches_per_rollout)},
             "env_rollout_ms": roll_ms,
         }
+        # which exchange carried the advantage statistics (and the closed loop's gradients), seen by how many ranks
+        res["collective"] = {"ranks": dist.get_world_size() if world > 1 else 1,
+                             "backend": dist.get_backend() if world > 1 else None,
+                             "rccl_ranks": (dist.get_world_size() if (world > 1 and dist.get_backend() == "nccl") else 0),
+                             "per_rollout": "one all_gather_into_tensor of N x 3 f64 (advantage moments) + exact merge",
+                             "per_optimizer_step": "one all_reduce of the flat f32 gradient buffer (149 908 floats) per team"}
         if closed is not None:
             res["closed_loop"] = closed
+        if world == 1 and not args.no_esweep and (G, A) == (3, 3):
+            res["esweep"] = esweep(fa, G, A, dev)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(E, G, A, T)
         sys.stdout.flush()
@@ -375,6 +418,37 @@ def main():
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def esweep(fa, G, A, dev):
+    """BASELINE.md section 5 / SURVEY 8(d): the same fused launch on more envs per GPU (the bandwidth regime).
+    T = 128 up to 262 144 envs; 32 steps at 1 048 576 envs (12 GB of rollout buffers instead of 48)."""
+    import torch
+    N, out = G + A, []
+    for E, T in ((32768, 128), (262144, 128), (1048576, 32)):
+        eng = fa.BatchedFortAttack(E, G, A, 100, base_seed=0, device=dev.index, track_counters=True)
+        st = fa.JointRolloutStorage(T, E, N, device=dev)
+        eng.bind_storage(st)
+        gen = torch.Generator(device=dev).manual_seed(E)
+        st.actions.copy_(torch.randint(0, 8, st.actions.shape, device=dev, generator=gen))
+        eng.collect_reset()
+        for _ in range(2):
+            eng.collect_rollout(0, T)
+        torch.cuda.synchronize()
+        iters = 5
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(iters):
+            eng.collect_rollout(0, T)
+        b.record()
+        torch.cuda.synchronize()
+        sec = a.elapsed_time(b) * 1e-3 / iters
+        gbps = algorithmic_bytes_per_env_step(N) * E * T / sec / 1e9
+        out.append({"envs": E, "rollout_steps": T, "kernel": eng.step_variant(T), "launch_us": sec * 1e6,
+                    "env_steps_per_s": E * T / sec, "algorithmic_GBps": gbps, "frac": gbps / HBM_PEAK_GBPS})
+        del eng, st
+        torch.cuda.empty_cache()
+    return out
 
 
 def closed_loop(fa, args, rank, local_rank, world, dev, barrier):
@@ -407,11 +481,14 @@ def closed_loop(fa, args, rank, local_rank, world, dev, barrier):
     L.collect()
     torch.cuda.synchronize()
     barrier()
+    U = max(1, args.closed_loop_updates)
     t0 = time.perf_counter()
-    L.update()
+    for _ in range(U):                                        # (each a full JointPPO update of both teams from this rollout)
+        L.update()
     torch.cuda.synchronize()
     barrier()
-    t_upd = time.perf_counter() - t0
+    t_upd = (time.perf_counter() - t0) / U
+    roof = closed_loop_rooflines(fa, L, E, G, A, T) if rank == 0 else None
     if world > 1:
         tt = torch.tensor([t_roll, t_upd], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -423,13 +500,76 @@ def closed_loop(fa, args, rank, local_rank, world, dev, barrier):
                     "a hipGraph, V(obs[T]), GAE, advantage moments%s" % (
                         G, A, E, T, "3" if world == 1 else "4", "" if world == 1 else " all-gathered over the ranks"),
         "rollout_env_steps_per_s": world * E * T / per_rollout, "rollout_ms": per_rollout * 1e3,
-        "ms_per_env_step_launch": per_rollout * 1e3 / T, "rollouts_timed": R,
+        "ms_per_env_step_launch": per_rollout * 1e3 / T, "rollouts_timed": R, "updates_timed": U,
         "update_s": t_upd, "train_env_steps_per_s": world * E * T / (per_rollout + t_upd),
+        "roofline": roof["policy"] if roof else None, "update_roofline": roof["train"] if roof else None,
         "update": "JointPPO: 4 epochs x 32 minibatches x 2 teams, Adam, grad-clip; every optimizer step (fused forward + "
                   "losses + backward kernel, fold / unfold, clip + Adam on flat buffers) replayed from a hipGraph, %s" % (
             "the two teams as concurrent chains on two streams" if world == 1 else
             "flat gradient all-reduce per optimizer step, teams one after the other"),
         "dtype": "f32 policy / f64 env", "unit": "env-steps/s"}
+
+
+def closed_loop_rooflines(fa, L, E, G, A, T):
+    """The two MFMA kernels of the closed loop against the fp32 MFMA peak, timed live with HIP events on the launch
+    stream: fa_policy_kernel (one launch = both teams' forward + sampling for every env: the dominant kernel of the
+    rollout) and fa_ppo_grad (mask sums + fa_train_kernel + slab reduction: the dominant launches of the update), each
+    as eager back-to-back launches of the SAME shape the hipGraphs replay."""
+    import torch
+    from emergent_multiagent_strategies_amd import mpnn_pack
+    from emergent_multiagent_strategies_amd.env import ppo_grad
+    N = G + A
+
+    def timed(fn, iters):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(iters):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) * 1e-3 / iters
+
+    out = {}
+    if L.policy_backend == "hip":
+        sec = timed(lambda: L._hip_act(0), 200)
+        flops = E * (G * policy_flops_per_row(G, A) + A * policy_flops_per_row(A, G))
+        out["policy"] = {"bound": "mfma", "kernel": "fa_policy_kernel<%d>" % max(G, A), "achieved": flops / sec / 1e12,
+                         "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": flops / sec / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                         "traffic": None, "flops_per_launch": flops, "avg_launch_us": sec * 1e6,
+                         "timed_by": "hipEvents on the launch stream, 200 eager launches of fa_collect_act",
+                         "share_of_env_step": "one launch per env-step next to one fa_step_kernel launch (~6 us)"}
+    else:
+        out["policy"] = None
+    st = L.storage
+    flat = lambda t: t.view(T * E, *t.shape[2:])
+    rows = (flat(st.obs[:-1]), flat(st.actions), flat(st.value_preds[:-1]), flat(st.returns[:-1]),
+            flat(st.action_log_probs), flat(L.adv))
+    mb = (T * E) // L.num_mini_batch
+    if L._flat and mb > 0:
+        fp = L._flat[0]
+        w, wt = fp.fold_pack()
+        idx = torch.randperm(T * E, device=rows[0].device)[:mb]
+        outbuf = torch.zeros(mpnn_pack.SLAB_FLOATS, device=rows[0].device)
+        scratch = [None]
+
+        def grad():
+            _, scratch[0] = ppo_grad(*rows, w, wt, None, 0, G, A, L.clip_param, L.value_loss_coef, L.entropy_coef,
+                                     L.clipped_value_loss, scratch=scratch[0], out=outbuf, idx=idx, normalize=True)
+
+        sec = timed(grad, 20)
+        flops = mb * G * train_flops_per_row(G, A)
+        out["train"] = {"bound": "mfma", "kernel": "fa_ppo_grad = fa_mask_part_kernel + fa_train_kernel<true> + fa_train_reduce_kernel",
+                        "achieved": flops / sec / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": flops / sec / 1e12 / MFMA_F32_PEAK_TFLOPS, "traffic": None, "flops_per_launch": flops,
+                        "avg_launch_us": sec * 1e6, "minibatch_rows": mb * G,
+                        "timed_by": "hipEvents on the launch stream, 20 eager fa_ppo_grad calls (three launches each; the "
+                                    "train kernel alone is in profiles/ rocprofv3 stats)"}
+    else:
+        out["train"] = None
+    return out
 
 
 if __name__ == "__main__":

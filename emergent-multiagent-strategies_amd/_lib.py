@@ -105,9 +105,18 @@ EXPORTS = {
     "fa_policy_weight_t_floats": (C.c_int64, []),
     "fa_adam_step": (C.c_int, [c_p, c_p, c_p, c_p, c_p, c_p, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float,
                                C.c_float, c_p, c_p]),
+    "fa_adam_step_dev": (C.c_int, [c_p, c_p, c_p, c_p, c_p, c_p, C.c_int32, C.c_int32, c_p, c_p, c_p]),
     "fa_adam_scratch_floats": (C.c_int64, []),
     "fa_run_tasks": (C.c_int, [c_p, C.c_int32, c_p]),
     "fa_pack_weights": (C.c_int, [c_p, c_p, c_p, c_p]),
+    "fa_rccl_available": (C.c_int, []),
+    "fa_rccl_library": (C.c_char_p, []),
+    "fa_rccl_unique_id": (C.c_int, [c_p]),
+    "fa_rccl_comm_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32, c_p, C.c_int32, C.c_int32]),
+    "fa_rccl_comm_destroy": (C.c_int, [c_p]),
+    "fa_rccl_comm_ranks": (C.c_int, [c_p]),
+    "fa_adv_allreduce": (C.c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "fa_grad_allreduce": (C.c_int, [c_p, C.c_int64, c_p, c_p]),
     "fa_get_state": (C.c_int, [c_p, C.POINTER(StateHost)]),
     "fa_set_state": (C.c_int, [c_p, C.POINTER(StateHost)]),
     "fa_selftest_math": (C.c_int, [c_p, C.c_uint64, C.c_uint64, c_p]),

@@ -39,6 +39,7 @@ static int fail(int code, const std::string &msg) {
     g_err = msg;
     return code;
 }
+int fa_api_fail(int code, const std::string &msg) { return fail(code, msg); } // for the other translation units
 #define FA_HIP(expr)                                                                          \
     do {                                                                                      \
         hipError_t _e = (expr);                                                               \
@@ -644,6 +645,17 @@ int fa_adam_step(float *params, float *grads, float *exp_avg, float *exp_avg_sq,
     if (nseg < 1 || n < 1) return fail(FA_ERR_INVALID, "fa_adam_step: need nseg >= 1 and n >= 1");
     if (reinterpret_cast<uintptr_t>(scratch) & 15) return fail(FA_ERR_INVALID, "fa_adam_step: scratch must be 16-byte aligned");
     FA_HIP(fa_launch_adam(params, grads, exp_avg, exp_avg_sq, steps, seg, nseg, n, lr, beta1, beta2, eps, max_grad_norm, scratch,
+                          nullptr, static_cast<hipStream_t>(stream)));
+    return FA_OK;
+}
+
+int fa_adam_step_dev(float *params, float *grads, float *exp_avg, float *exp_avg_sq, float *steps, const int32_t *seg,
+                     int32_t nseg, int32_t n, const float *hyper, float *scratch, void *stream) {
+    if (!params || !grads || !exp_avg || !exp_avg_sq || !steps || !seg || !scratch || !hyper)
+        return fail(FA_ERR_INVALID, "fa_adam_step_dev: null argument");
+    if (nseg < 1 || n < 1) return fail(FA_ERR_INVALID, "fa_adam_step_dev: need nseg >= 1 and n >= 1");
+    if (reinterpret_cast<uintptr_t>(scratch) & 15) return fail(FA_ERR_INVALID, "fa_adam_step_dev: scratch must be 16-byte aligned");
+    FA_HIP(fa_launch_adam(params, grads, exp_avg, exp_avg_sq, steps, seg, nseg, n, 0.f, 0.f, 0.f, 0.f, 0.f, scratch, hyper,
                           static_cast<hipStream_t>(stream)));
     return FA_OK;
 }

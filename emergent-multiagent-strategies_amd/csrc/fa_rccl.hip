@@ -1,0 +1,161 @@
+// fa_rccl.hip -- the hot path's ONE cross-GPU exchange done inside the library, on the caller's stream.
+//
+// The reference is one process (train_fortattack.py:199); what has to cover every GPU's samples once the env
+// batch is sharded is the per-agent advantage mean / unbiased std of JointPPO.update
+// (rlcore/algo/ppo.py:121-123) and -- for a consistent data-parallel learner -- the flat
+// gradient buffer of every optimizer step (ppo.py:189-193).  emergent-multiagent-strategies_amd/dist.py does
+// both through torch.distributed; a consumer of libfortattack_hip.so without torch uses these entry points:
+//
+//   fa_adv_allreduce   ncclAllGather of this rank's (N, 3) fp64 moments {n, mean, M2} + the exact merge kernel
+//   fa_grad_allreduce  ncclAllReduce(sum) of a float buffer in place
+//
+// RCCL is opened with dlopen at first use (librccl.so.1: inside a PyTorch process that is the copy torch
+// already mapped): no link-time dependency, and a box without RCCL only loses these calls (FA_ERR_STATE).
+// The declarations come from <rccl/rccl.h>; nothing of RCCL is linked.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <cstdlib>
+#include <mutex>
+#include <string>
+
+#include "fortattack.h"
+
+hipError_t fa_launch_adv_merge(const double *gathered, int W, int N, double *mean_out, double *std_out, hipStream_t st);
+int fa_api_fail(int code, const std::string &msg); // fa_api.hip: sets the thread-local message
+
+namespace {
+struct Rccl {
+    void *handle = nullptr;
+    std::string error, path;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+Rccl &rccl() {
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char *env = std::getenv("FA_RCCL_LIB");
+        const char *names[] = {env, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char *n : names) {
+            if (!n || !*n) continue;
+            r.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+            if (r.handle) {
+                r.path = n;
+                break;
+            }
+            r.error = dlerror();
+        }
+        if (!r.handle) return;
+        auto sym = [&](const char *name) {
+            void *p = dlsym(r.handle, name);
+            if (!p) r.error = std::string("missing symbol ") + name;
+            return p;
+        };
+        r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
+        r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));
+        r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
+        r.CommCount = reinterpret_cast<decltype(r.CommCount)>(sym("ncclCommCount"));
+        r.AllGather = reinterpret_cast<decltype(r.AllGather)>(sym("ncclAllGather"));
+        r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(sym("ncclAllReduce"));
+        r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+        if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.CommCount || !r.AllGather || !r.AllReduce ||
+            !r.GetErrorString) {
+            dlclose(r.handle);
+            r.handle = nullptr;
+        }
+    });
+    return r;
+}
+
+int need(const char *who) {
+    Rccl &r = rccl();
+    if (r.handle) return FA_OK;
+    return fa_api_fail(FA_ERR_STATE, std::string(who) + ": RCCL is not available (" + r.error + ")");
+}
+
+#define FA_NCCL(who, expr)                                                                                   \
+    do {                                                                                                     \
+        ncclResult_t _r = (expr);                                                                            \
+        if (_r != ncclSuccess)                                                                               \
+            return fa_api_fail(FA_ERR_HIP, std::string(who) + ": " #expr ": " + rccl().GetErrorString(_r));  \
+    } while (0)
+} // namespace
+
+extern "C" {
+
+int fa_rccl_available(void) { return rccl().handle ? 1 : 0; }
+
+const char *fa_rccl_library(void) { return rccl().handle ? rccl().path.c_str() : ""; }
+
+int fa_rccl_unique_id(void *id_out) {
+    if (!id_out) return fa_api_fail(FA_ERR_INVALID, "fa_rccl_unique_id: null argument");
+    if (int rc = need("fa_rccl_unique_id")) return rc;
+    static_assert(FA_RCCL_UNIQUE_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "fortattack.h and rccl.h disagree on the id size");
+    FA_NCCL("fa_rccl_unique_id", rccl().GetUniqueId(static_cast<ncclUniqueId *>(id_out)));
+    return FA_OK;
+}
+
+int fa_rccl_comm_create(void **comm_out, int32_t nranks, const void *id, int32_t rank, int32_t device_id) {
+    if (!comm_out || !id) return fa_api_fail(FA_ERR_INVALID, "fa_rccl_comm_create: null argument");
+    if (nranks < 1 || rank < 0 || rank >= nranks) return fa_api_fail(FA_ERR_INVALID, "fa_rccl_comm_create: need 0 <= rank < nranks");
+    if (int rc = need("fa_rccl_comm_create")) return rc;
+    int prev = 0;
+    if (hipGetDevice(&prev) != hipSuccess || hipSetDevice(device_id) != hipSuccess)
+        return fa_api_fail(FA_ERR_HIP, "fa_rccl_comm_create: cannot select the device");
+    ncclUniqueId uid = *static_cast<const ncclUniqueId *>(id);
+    ncclComm_t comm = nullptr;
+    ncclResult_t r = rccl().CommInitRank(&comm, nranks, uid, rank);
+    (void)hipSetDevice(prev);
+    if (r != ncclSuccess) return fa_api_fail(FA_ERR_HIP, std::string("fa_rccl_comm_create: ncclCommInitRank: ") + rccl().GetErrorString(r));
+    *comm_out = comm;
+    return FA_OK;
+}
+
+int fa_rccl_comm_destroy(void *comm) {
+    if (!comm) return FA_OK;
+    if (int rc = need("fa_rccl_comm_destroy")) return rc;
+    FA_NCCL("fa_rccl_comm_destroy", rccl().CommDestroy(static_cast<ncclComm_t>(comm)));
+    return FA_OK;
+}
+
+int fa_rccl_comm_ranks(void *comm) {
+    if (!comm) return fa_api_fail(FA_ERR_INVALID, "fa_rccl_comm_ranks: null communicator");
+    if (int rc = need("fa_rccl_comm_ranks")) return rc;
+    int n = 0;
+    FA_NCCL("fa_rccl_comm_ranks", rccl().CommCount(static_cast<ncclComm_t>(comm), &n));
+    return n;
+}
+
+int fa_adv_allreduce(fa_env *env, const double *moments, double *gathered, void *nccl_comm, double *mean_out,
+                     double *std_out, void *stream) {
+    if (!env || !moments || !gathered || !nccl_comm || !mean_out || !std_out)
+        return fa_api_fail(FA_ERR_INVALID, "fa_adv_allreduce: null argument");
+    if (int rc = need("fa_adv_allreduce")) return rc;
+    const int N = fa_num_agents(env);
+    int world = 0;
+    FA_NCCL("fa_adv_allreduce", rccl().CommCount(static_cast<ncclComm_t>(nccl_comm), &world));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    // rank r's triple lands at gathered[r]: rank order, so the merge gives every rank the same bits
+    FA_NCCL("fa_adv_allreduce", rccl().AllGather(moments, gathered, (size_t)N * 3, ncclFloat64, static_cast<ncclComm_t>(nccl_comm), s));
+    if (fa_launch_adv_merge(gathered, world, N, mean_out, std_out, s) != hipSuccess)
+        return fa_api_fail(FA_ERR_HIP, "fa_adv_allreduce: merge kernel launch failed");
+    return FA_OK;
+}
+
+int fa_grad_allreduce(float *flat, int64_t n, void *nccl_comm, void *stream) {
+    if (!flat || !nccl_comm || n < 1) return fa_api_fail(FA_ERR_INVALID, "fa_grad_allreduce: null argument");
+    if (int rc = need("fa_grad_allreduce")) return rc;
+    FA_NCCL("fa_grad_allreduce", rccl().AllReduce(flat, flat, (size_t)n, ncclFloat32, ncclSum, static_cast<ncclComm_t>(nccl_comm),
+                                                  static_cast<hipStream_t>(stream)));
+    return FA_OK;
+}
+
+} // extern "C"

@@ -63,9 +63,11 @@ hipError_t fa_launch_train(const FaTrainArgs &a, hipStream_t st);
 hipError_t fa_launch_mask_parts(const FaTrainArgs &a, float *part, hipStream_t st);
 // Adam (torch.optim.Adam, no amsgrad / weight decay) on flat buffers after the global-norm clip of
 // nn.utils.clip_grad_norm_: two launches.  seg: nseg + 1 offsets; steps: nseg step counters (float);
-// scratch: FA_ADAM_SCRATCH floats, 16-byte aligned ([0] receives the clip coefficient)
+// scratch: FA_ADAM_SCRATCH floats, 16-byte aligned ([0] receives the clip coefficient); hyper: null, or 5 device
+// floats (lr, beta1, beta2, eps, max_norm) that replace the by-value arguments at run time
 hipError_t fa_launch_adam(float *p, float *g, float *m, float *v, float *steps, const int32_t *seg, int nseg, int n, float lr,
-                          float beta1, float beta2, float eps, float max_norm, float *scratch, hipStream_t st);
+                          float beta1, float beta2, float eps, float max_norm, float *scratch, const float *hyper,
+                          hipStream_t st);
 // out[k] = sum over tiles of slabs[t][k], k < FA_SLAB_LOSS + 8 (fixed order: reproducible); out[FA_SLAB_LOSS + 8..9]
 // is where fa_ppo_grad keeps the scale pair when the caller passes none
 hipError_t fa_launch_train_reduce(const float *slabs, int tiles, float *out, hipStream_t st);

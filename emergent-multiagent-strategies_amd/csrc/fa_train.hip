@@ -730,7 +730,11 @@ __global__ __launch_bounds__(64) void fa_sqnorm_part_kernel(const float *__restr
 __global__ __launch_bounds__(256) void fa_adam_kernel(float *__restrict__ p, float *__restrict__ g, float *__restrict__ m,
                                                       float *__restrict__ v, const float *__restrict__ steps,
                                                       const int32_t *__restrict__ seg, int nseg, float lr, float beta1,
-                                                      float beta2, float eps, float max_norm, float *__restrict__ scratch) {
+                                                      float beta2, float eps, float max_norm, float *__restrict__ scratch,
+                                                      const float *__restrict__ hyper) {
+    if (hyper) { // (lr, beta1, beta2, eps, max_norm) read at run time: a captured graph follows an LR schedule
+        lr = hyper[0]; beta1 = hyper[1]; beta2 = hyper[2]; eps = hyper[3]; max_norm = hyper[4];
+    }
     double t = reinterpret_cast<const double *>(scratch + 4)[threadIdx.x & 63];
     for (int d = 32; d >= 1; d >>= 1) t += __shfl_xor(t, d);
     const float coef = fminf(1.0f, max_norm / ((float)sqrt(t) + 1e-6f));
@@ -773,10 +777,11 @@ hipError_t fa_launch_mask_parts(const FaTrainArgs &a, float *part, hipStream_t s
 }
 
 hipError_t fa_launch_adam(float *p, float *g, float *m, float *v, float *steps, const int32_t *seg, int nseg, int n,
-                          float lr, float beta1, float beta2, float eps, float max_norm, float *scratch, hipStream_t st) {
+                          float lr, float beta1, float beta2, float eps, float max_norm, float *scratch, const float *hyper,
+                          hipStream_t st) {
     hipLaunchKernelGGL(fa_sqnorm_part_kernel, dim3(FA_NORM_PARTS), dim3(64), 0, st, g, n, reinterpret_cast<double *>(scratch + 4),
                        steps, nseg);
     hipLaunchKernelGGL(fa_adam_kernel, dim3((n + 255) / 256), dim3(256), 0, st, p, g, m, v, steps, seg, nseg, lr, beta1, beta2,
-                       eps, max_norm, scratch);
+                       eps, max_norm, scratch, hyper);
     return hipGetLastError();
 }

@@ -10,9 +10,88 @@ and which must now cover every rank's samples.  What the learner and bench.py ca
 -- latency bound, 144 B at 3v3 -- and fa_adv_merge combines the triples exactly
 (Chan-Golub-LeVeque, in rank order: every rank gets the same bits).  ``two_pass_mean_std`` is the
 two-all-reduce formulation (mean first, then squared deviations), kept as the reference form.
+
+Two routes carry the exchange.  The default is torch.distributed (any backend; "nccl" is RCCL).  ``LibraryExchange``
+is the in-library route of include/fortattack.h (fa_adv_allreduce / fa_grad_allreduce: RCCL opened by
+libfortattack_hip.so itself, the collective enqueued on the caller's stream next to the kernels) -- what a consumer
+without torch uses; here torch.distributed only hands the 128-byte communicator id to the other ranks.
+``FORCE_COLLECTIVE`` makes a world of ONE rank take the collective branch as well (the all-gather / all-reduce run on
+one rank and must change nothing): how the GPU tests execute RCCL on a one-GPU box.
 """
+import ctypes as C
+
 import torch
 import torch.distributed as dist
+
+FORCE_COLLECTIVE = False
+
+
+def world_size(group=None):
+    return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+
+
+def exchanging(group=None):
+    """Whether the torch.distributed route runs its collectives: several ranks, or one rank under FORCE_COLLECTIVE."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size(group) > 1 or FORCE_COLLECTIVE
+
+
+class LibraryExchange(object):
+    """One RCCL communicator owned by libfortattack_hip.so (fa_rccl_comm_create) for this process's device.
+    rank / world come from torch.distributed when it is initialised (its default group moves the id), else (0, 1):
+    a single process needs no process group at all to push its exchange through RCCL."""
+
+    def __init__(self, device, group=None):
+        from . import _lib
+        self._L = _lib
+        lib = _lib.load()
+        if not lib.fa_rccl_available():
+            raise _lib.FaError("RCCL could not be opened by libfortattack_hip.so (set FA_RCCL_LIB to its path)")
+        dev = torch.device(device)
+        self.device = dev
+        self.rank = dist.get_rank(group) if dist.is_available() and dist.is_initialized() else 0
+        self.world = world_size(group)
+        uid = (C.c_char * 128)()
+        if self.rank == 0:
+            _lib.check(lib.fa_rccl_unique_id(uid), "fa_rccl_unique_id")
+        if self.world > 1:
+            box = [bytes(uid)]
+            dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            uid = (C.c_char * 128).from_buffer_copy(box[0])
+        comm = C.c_void_p()
+        _lib.check(lib.fa_rccl_comm_create(C.byref(comm), self.world, uid, self.rank, dev.index or 0), "fa_rccl_comm_create")
+        self.comm = comm
+        self._gather = None
+
+    def ranks(self):
+        return int(self._L.load().fa_rccl_comm_ranks(self.comm))
+
+    def adv_mean_std(self, eng, moments):
+        """ppo.py:121-123 over all ranks from this rank's (N,3) moments: fa_adv_allreduce on the current stream."""
+        if self._gather is None:
+            self._gather = torch.zeros((self.world, eng.N, 3), dtype=torch.float64, device=eng.device)
+            self._mean = torch.zeros(eng.N, dtype=torch.float64, device=eng.device)
+            self._std = torch.zeros(eng.N, dtype=torch.float64, device=eng.device)
+        L = self._L
+        L.check(L.load().fa_adv_allreduce(eng._h, moments.data_ptr(), self._gather.data_ptr(), self.comm, self._mean.data_ptr(),
+                                          self._std.data_ptr(), C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)),
+                "fa_adv_allreduce")
+        return self._mean, self._std
+
+    def all_reduce_(self, flat):
+        """Sum `flat` (float32, contiguous) over the ranks in place, on the current stream."""
+        assert flat.dtype == torch.float32 and flat.is_contiguous()
+        L = self._L
+        L.check(L.load().fa_grad_allreduce(flat.data_ptr(), flat.numel(), self.comm,
+                                           C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)), "fa_grad_allreduce")
+        return flat
+
+    def close(self):
+        if self.comm:
+            torch.cuda.synchronize(self.device)
+            self._L.load().fa_rccl_comm_destroy(self.comm)
+            self.comm = None
 
 
 def _all_reduce_sum_(t, group=None):
@@ -37,7 +116,7 @@ def adv_mean_std(eng, group=None):
     """Global per-agent advantage mean / unbiased std for the storage bound to `eng`.
     One rank: fa_adv_mean_std (four launches, no collective).  Several ranks: local two-pass
     moments, ONE all-gather of (N,3) doubles per rank, exact merge kernel (fa_adv_merge)."""
-    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
+    if not exchanging(group):
         return eng.adv_mean_std()
     world = dist.get_world_size(group)
     buf = getattr(eng, "_adv_gather", None)
@@ -49,12 +128,15 @@ def adv_mean_std(eng, group=None):
     return eng.adv_merge(buf)
 
 
-def gae_adv_mean_std(eng, gamma=0.99, tau=0.95, group=None):
+def gae_adv_mean_std(eng, gamma=0.99, tau=0.95, group=None, exchange=None):
     """compute_returns (GAE) + the global per-agent advantage mean / unbiased std in one pass over
     the rollout buffers (fa_gae_moments: three launches); with several ranks additionally ONE all-gather
-    of the local (N,3) moments and the exact merge kernel."""
+    of the local (N,3) moments and the exact merge kernel -- through torch.distributed, or inside the library
+    when `exchange` is a LibraryExchange."""
     mom, mean, std = eng.gae_moments(gamma, tau)
-    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
+    if exchange is not None:
+        return exchange.adv_mean_std(eng, mom)
+    if not exchanging(group):
         return mean, std
     world = dist.get_world_size(group)
     buf = getattr(eng, "_adv_gather", None)

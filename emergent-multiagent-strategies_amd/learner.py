@@ -22,6 +22,7 @@ import torch
 import torch.distributed as dist
 import torch.nn as nn
 
+from . import dist as fa_dist
 from .dist import gae_adv_mean_std
 from . import mpnn_pack
 from .mpnn import MPNN, TwinMPNN
@@ -80,15 +81,21 @@ class GraphedPPOStep(object):
     restored) before the first real step."""
 
     def __init__(self, pol, opt, own_sl, opp_sl, rows, mb, clip_param, value_loss_coef, entropy_coef, max_grad_norm,
-                 clipped_value_loss, group, fused=False, share_cu=False):
-        self.pol, self.opt, self.group, self.world = pol, opt, group, _world(group)
+                 clipped_value_loss, group, fused=False, share_cu=False, exchange=None):
+        # the gradient exchange: `exchange` (dist.LibraryExchange: RCCL inside the library) or torch.distributed on
+        # `group`; a world of one rank exchanges nothing unless dist.FORCE_COLLECTIVE / an explicit exchange says so
+        self.pol, self.opt, self.group = pol, opt, group
+        self.world = exchange.world if exchange is not None else _world(group)
+        self.exchanging = exchange is not None or fa_dist.exchanging(group)
+        self._reduce = exchange.all_reduce_ if exchange is not None else (lambda t: dist.all_reduce(t, group=group))
         self.params = [p for p in pol.parameters()]
         self.fused = bool(fused)
+        self.max_grad_norm = max_grad_norm
         # torch path: the minibatch is gathered into static buffers; fused: the kernel reads rows idx of the rollout
         self.static = None if self.fused else [torch.empty((mb,) + tuple(r.shape[1:]), dtype=r.dtype, device=r.device) for r in rows]
         self.rows = tuple(rows)
         self.mb = mb
-        world = self.world
+        world, exchanging = self.world, self.exchanging
         if self.fused:   # csrc/fa_train.hip: forward + losses + backward of the minibatch in one launch
             from .env import ppo_grad
             dev = rows[0].device
@@ -112,14 +119,14 @@ class GraphedPPOStep(object):
             w, wt = fp.fold_pack()
             _, self._scratch = ppo_grad(*self.rows, w, wt, None, team, G, N - G, clip_param, value_loss_coef, entropy_coef,
                                         clipped_value_loss, scratch=self._scratch, out=self._out, idx=self.idx,
-                                        normalize=(world == 1), share_cu=share_cu)
+                                        normalize=not exchanging, share_cu=share_cu)
             fp.attach_grads()               # every parameter's .grad is its slice of fp.gflat
             fp.unfold(self._out)
             sums = self._out[LOSS:LOSS + 3] * inv_count
             mmp = self._out[LOSS + 9]       # the alive-mask mean of the minibatch (1 where that is 0)
             if not clipped_value_loss:      # the scalar-MSE value loss is not masked (ppo.py:178-182)
                 sums = sums * (self._unmask + (1.0 - self._unmask) * mmp)
-            if world == 1:
+            if not exchanging:
                 return sums / mmp, None
             fp.gflat[PF:PF + 3].copy_(sums)  # the flat gradient buffer carries the loss sums and the mask mean
             fp.gflat[PF + 3].copy_(self._out[LOSS + 3] * inv_count)
@@ -130,11 +137,11 @@ class GraphedPPOStep(object):
                 return fused_fwd_bwd()
             obs_b, act_b, vp_b, ret_b, olp_b, adv_b = self.static
             out = ppo_losses(pol, obs_b[:, own_sl], obs_b[:, opp_sl], act_b[:, own_sl], vp_b[:, own_sl], ret_b[:, own_sl],
-                             olp_b[:, own_sl], adv_b[:, own_sl], clip_param, clipped_value_loss, normalize=(world == 1))
+                             olp_b[:, own_sl], adv_b[:, own_sl], clip_param, clipped_value_loss, normalize=not exchanging)
             opt.zero_grad(set_to_none=True)
             (out[0] * value_loss_coef + out[1] - out[2] * entropy_coef).backward()
             losses = torch.stack([out[0].detach(), out[1].detach(), out[2].detach()])
-            if world == 1:
+            if not exchanging:
                 return losses, None
             grads = [p.grad for p in self.params if p.grad is not None]
             return losses, torch.cat([g.reshape(-1) for g in grads] + [losses, out[3].detach().reshape(1)])
@@ -165,7 +172,7 @@ class GraphedPPOStep(object):
         def eager():
             losses, flat = fwd_bwd()
             if flat is not None:
-                dist.all_reduce(flat, group=group)
+                self._reduce(flat)
             return finish(losses, flat)
 
         # ---- warm-up on a side stream, then undo it -------------------------------------------------------
@@ -193,7 +200,7 @@ class GraphedPPOStep(object):
         # ---- capture -----------------------------------------------------------------------------------
         self.g1 = torch.cuda.CUDAGraph()
         self.g2 = None
-        if world == 1:
+        if not exchanging:
             with torch.cuda.graph(self.g1):
                 self.losses = eager()
         else:
@@ -207,18 +214,20 @@ class GraphedPPOStep(object):
         if self.fused:
             assert all(a.data_ptr() == b.data_ptr() for a, b in zip(rows, self.rows)), "the captured step reads the rollout in place"
             self.idx.copy_(idx)
+            self.fp.refresh_hyper(self.opt, self.max_grad_norm)   # lr / betas / eps live in device memory, not in the graph
         else:
             for st, src in zip(self.static, rows):
                 torch.index_select(src, 0, idx, out=st)
         self.g1.replay()
         if self.g2 is not None:
-            dist.all_reduce(self.flat, group=self.group)
+            self._reduce(self.flat)          # between the two graphs, on the same stream
             self.g2.replay()
         return self.losses
 
 
 def joint_ppo_update(pol, opt, own_sl, opp_sl, rows, clip_param, ppo_epoch, num_mini_batch, value_loss_coef,
-                     entropy_coef, max_grad_norm, clipped_value_loss=True, group=None, sampler=None, graphs=None):
+                     entropy_coef, max_grad_norm, clipped_value_loss=True, group=None, sampler=None, graphs=None,
+                     exchange=None):
     """JointPPO.update (ppo.py:116-204) for one team's shared policy over flattened rollout rows.
 
     rows = (obs, actions, value_preds, returns, old_log_probs, advantages), each (B, N, .) with B = T * E
@@ -231,6 +240,8 @@ def joint_ppo_update(pol, opt, own_sl, opp_sl, rows, clip_param, ppo_epoch, num_
     of the un-normalised losses plus this rank's alive-mask mean; dividing by the all-rank mask mean
     afterwards gives exactly the gradient of the reference's loss on the union minibatch (the three
     losses are linear in 1 / mask.mean()), so all ranks step identically.
+    `exchange`: a dist.LibraryExchange -> the all-reduce is the library's own RCCL call (fa_grad_allreduce) instead of
+    torch.distributed's.
     `graphs`: a dict owned by the caller -> full-size minibatch steps replay from hipGraphs (GraphedPPOStep;
     CUDA tensors and a capturable optimizer); a ragged last minibatch runs eagerly.
     Returns a (3,) tensor: (value_loss, action_loss, entropy) summed over the minibatches and divided by
@@ -241,7 +252,8 @@ def joint_ppo_update(pol, opt, own_sl, opp_sl, rows, clip_param, ppo_epoch, num_
         "PPO requires the number of processes * number of steps = {} to be greater than "
         "or equal to the number of PPO mini batches ({}).".format(batch, num_mini_batch))
     mb = int(batch / num_mini_batch)                             # ppo.py:210
-    world = _world(group)
+    world = exchange.world if exchange is not None else _world(group)
+    exchanging = exchange is not None or fa_dist.exchanging(group)
     params = [p for p in pol.parameters()]
     acc = torch.zeros(3, device=obs_f.device)
     for epoch in range(ppo_epoch):
@@ -256,21 +268,25 @@ def joint_ppo_update(pol, opt, own_sl, opp_sl, rows, clip_param, ppo_epoch, num_
                 if key not in graphs:
                     graphs[key] = GraphedPPOStep(pol, opt, own_sl, opp_sl, rows, mb, clip_param, value_loss_coef,
                                                  entropy_coef, max_grad_norm, clipped_value_loss, group,
-                                                 fused=graphs.get("fused", False) and mpnn_pack.supported(pol))
+                                                 fused=graphs.get("fused", False) and mpnn_pack.supported(pol),
+                                                 exchange=exchange)
                 acc += graphs[key].run(rows, idx)
                 continue
             obs_b = obs_f[idx]
             out = ppo_losses(pol, obs_b[:, own_sl], obs_b[:, opp_sl], act_f[idx][:, own_sl], vp_f[idx][:, own_sl],
                              ret_f[idx][:, own_sl], olp_f[idx][:, own_sl], adv_f[idx][:, own_sl], clip_param,
-                             clipped_value_loss, normalize=(world == 1))
+                             clipped_value_loss, normalize=not exchanging)
             value_loss, action_loss, dist_entropy = out[:3]
             opt.zero_grad(set_to_none=True)
             (value_loss * value_loss_coef + action_loss - dist_entropy * entropy_coef).backward()
             losses = torch.stack([value_loss.detach(), action_loss.detach(), dist_entropy.detach()])
-            if world > 1:
+            if exchanging:
                 grads = [p.grad for p in params if p.grad is not None]
                 flat = torch.cat([g.reshape(-1) for g in grads] + [losses, out[3].detach().reshape(1)])
-                dist.all_reduce(flat, group=group)
+                if exchange is not None:
+                    exchange.all_reduce_(flat)
+                else:
+                    dist.all_reduce(flat, group=group)
                 flat.div_(world)                                 # equal shard sizes: mean over ranks == union mean
                 mm = flat[-1]
                 flat.div_(torch.where(mm != 0, mm, torch.ones_like(mm)))
@@ -289,7 +305,7 @@ class BatchedLearner(object):
     def __init__(self, eng, num_steps=128, hidden_dim=128, lr=1e-4, clip_param=0.2, ppo_epoch=4,
                  num_mini_batch=32, value_loss_coef=0.5, entropy_coef=0.01, max_grad_norm=0.5,
                  gamma=0.99, tau=0.95, clipped_value_loss=True, use_graph=False, group=None, policy_backend="auto",
-                 sample_seed=None, update_backend="auto"):
+                 sample_seed=None, update_backend="auto", exchange="torch"):
         # defaults: arguments.py:22-45
         # policy_backend: "hip" = the fused fa_policy kernel runs the rollout's forwards (hidden_dim 128),
         # "torch" = the PyTorch modules do, "auto" = hip whenever it supports the configuration
@@ -300,6 +316,19 @@ class BatchedLearner(object):
         self.value_loss_coef, self.entropy_coef = value_loss_coef, entropy_coef
         self.max_grad_norm, self.clipped_value_loss = max_grad_norm, clipped_value_loss
         self.group = group
+        # exchange: "torch" = torch.distributed collectives on `group` (backend "nccl" is RCCL); "rccl" = the library's own
+        # RCCL communicators (dist.LibraryExchange -> fa_adv_allreduce / fa_grad_allreduce), also with ONE rank.
+        # Each team's update chain gets its own communicator / process group: the two chains run concurrently on two
+        # streams, and collectives of one communicator are ordered
+        if exchange not in ("torch", "rccl"):
+            raise ValueError("exchange must be 'torch' or 'rccl'")
+        self._exch, self._team_exch, self._team_groups = None, [None, None], [group, group]
+        if exchange == "rccl":
+            self._exch = fa_dist.LibraryExchange(self.device, group)
+            self._team_exch = [fa_dist.LibraryExchange(self.device, group) for _ in range(2)]
+        elif fa_dist.exchanging(group):
+            ranks = dist.get_process_group_ranks(group) if group is not None else None
+            self._team_groups = [dist.new_group(ranks=ranks) for _ in range(2)]
         # learner.py:60-68: guards first (policy1), then attackers (policy2); shared per team
         self.policies = [MPNN(num_agents=self.G, num_opp_agents=self.A, hidden_dim=hidden_dim, num_actions=8),
                          MPNN(num_agents=self.A, num_opp_agents=self.G, hidden_dim=hidden_dim, num_actions=8)]
@@ -313,6 +342,10 @@ class BatchedLearner(object):
         # forward + losses + backward is the fa_ppo_grad kernel; "torch": PyTorch autograd with the fa_attend op
         if update_backend not in ("auto", "fused", "torch"):
             raise ValueError("update_backend must be 'auto', 'fused' or 'torch'")
+        if update_backend == "fused" and not (use_graph and self.device.type == "cuda" and
+                                               all(mpnn_pack.supported(p) for p in self.policies)):
+            raise ValueError("update_backend='fused' needs use_graph=True, a CUDA device, hidden_dim = 128 and teams of <= 8 "
+                             "agents (update_backend='auto' falls back to PyTorch autograd instead)")
         self._update_graphs = {"fused": update_backend != "torch"} if use_graph else None
         self._update_backend = update_backend
         self.storage = JointRolloutStorage(num_steps, self.E, self.N, device=self.device)
@@ -351,10 +384,16 @@ class BatchedLearner(object):
         self.policies[1].load_state_dict(policies_list[-1])
 
     def save(self, path):
-        torch.save({"models": self.state_dicts(), "ob_rms": (None, None)}, path)
+        # the reference's two keys (train_fortattack.py:123-128) + the fused policy kernel's sampling position: the
+        # Philox key is (sample_seed; rollout counter, step, env, agent), so a resumed run must not start over at 0
+        torch.save({"models": self.state_dicts(), "ob_rms": (None, None),
+                    "fa_rollout_counter": int(self._rollout_counter.item())}, path)
 
     def load(self, path):
-        self.load_models(torch.load(path, map_location=self.device, weights_only=False)["models"])
+        ck = torch.load(path, map_location=self.device, weights_only=False)
+        self.load_models(ck["models"])
+        if "fa_rollout_counter" in ck:          # (absent in the reference's own checkpoints)
+            self._rollout_counter.fill_(int(ck["fa_rollout_counter"]))
 
     # ---- ensemble of frozen attacker strategies (train_fortattack_v2.py, learner.py:119-140) ----
     def load_attacker_ensemble(self, checkpoints, hidden_dim=128):
@@ -548,7 +587,7 @@ class BatchedLearner(object):
                 self.step(s)
             self._value_last()
         # compute_returns + the advantage mean / std of ppo.py:121-123 (over ALL ranks) in one pass
-        self._adv_mean_std = gae_adv_mean_std(self.eng, self.gamma, self.tau, self.group)
+        self._adv_mean_std = gae_adv_mean_std(self.eng, self.gamma, self.tau, self.group, exchange=self._exch)
         # train_fortattack.py:88: episode_rewards += reward * masks (alive before the step)
         self.episode_rewards = (st.rewards * st.masks[1:]).sum(0)[..., 0]
 
@@ -569,22 +608,23 @@ class BatchedLearner(object):
             out.append(joint_ppo_update(
                 self.policies[ti], self.optimizers[ti], self.team_slices[ti], self.team_slices[1 - ti], rows,
                 self.clip_param, self.ppo_epoch, self.num_mini_batch, self.value_loss_coef, self.entropy_coef,
-                self.max_grad_norm, self.clipped_value_loss, self.group, sampler,
-                graphs=None if sampler is not None else self._update_graphs))
+                self.max_grad_norm, self.clipped_value_loss, self._team_groups[ti], sampler,
+                graphs=None if sampler is not None else self._update_graphs, exchange=self._team_exch[ti]))
         return torch.stack(out)
 
     def _teams_step_ok(self, rows):
         g = self._update_graphs
         batch = rows[0].shape[0]
         mb = int(batch / self.num_mini_batch) if batch >= self.num_mini_batch else 0
-        return (g is not None and g.get("fused", False) and g.get("teams_together", True) and _world(self.group) == 1
+        return (g is not None and g.get("fused", False) and g.get("teams_together", True)
                 and mb > 0 and batch % mb == 0 and all(mpnn_pack.supported(p) for p in self.policies))
 
     def _update_teams_together(self, rows):
         """Both teams' JointPPO.update (learner.py:175-188 runs them one after the other; they share nothing but the
         read-only rollout) as two concurrent chains of optimizer steps.  The minibatch permutations are drawn in the
         sequential order -- all of the guards' epochs, then all of the attackers' -- so the result is the
-        sequential update's, step for step."""
+        sequential update's, step for step.  Several ranks: each chain's all-reduce (between the two graphs of its step)
+        goes through the team's own communicator, so the chains stay independent across the ranks too."""
         g, batch, dev = self._update_graphs, rows[0].shape[0], rows[0].device
         mb = int(batch / self.num_mini_batch)
         perms = [[torch.randperm(batch, device=dev) for _ in range(self.ppo_epoch)] for _ in range(2)]
@@ -594,7 +634,8 @@ class BatchedLearner(object):
             if key not in g:
                 g[key] = GraphedPPOStep(self.policies[ti], self.optimizers[ti], self.team_slices[ti], self.team_slices[1 - ti],
                                         rows, mb, self.clip_param, self.value_loss_coef, self.entropy_coef, self.max_grad_norm,
-                                        self.clipped_value_loss, self.group, fused=True, share_cu=True)
+                                        self.clipped_value_loss, self._team_groups[ti], fused=True, share_cu=True,
+                                        exchange=self._team_exch[ti])
             steps.append(g[key])
             assert all(a.data_ptr() == b.data_ptr() for a, b in zip(rows, g[key].rows)), "the captured step reads the rollout in place"
         acc = torch.zeros(2, 3, device=dev)

@@ -243,7 +243,7 @@ class FlatPolicy(object):
         self.plain, self.mscr, self.dmscr = z(WEIGHT_FLOATS), z(128 * 128), z(128 * 128)
         self.w, self.wt = z(WEIGHT_FLOATS), z(TRANS_FLOATS)
         self._fold = [self._tasks(self._fold_stage1()), self._tasks(self._fold_stage2())]
-        self._unfold = None
+        self._unfold = {}       # gradient buffer address -> its two task lists (captured graphs keep the pointers)
         self.attach_grads()
 
     def attach_grads(self):
@@ -342,10 +342,11 @@ class FlatPolicy(object):
     def unfold(self, grads_plain):
         """plain-layout gradients of the kernel-facing matrices (a FA_SLAB buffer) -> gflat (== every parameter's
         .grad): the chain rule of the fold.  Uses M = W_val W_out of the LAST fold_pack()."""
-        if self._unfold is None or self._unfold[2] != grads_plain.data_ptr():
-            self._unfold = self._build_unfold(grads_plain.data_ptr()) + [grads_plain.data_ptr()]
-        self._run(self._unfold[0])
-        self._run(self._unfold[1])
+        tl = self._unfold.get(grads_plain.data_ptr())
+        if tl is None:      # never dropped: every GraphedPPOStep's graph replays fa_task_kernel on ITS list
+            tl = self._unfold[grads_plain.data_ptr()] = self._build_unfold(grads_plain.data_ptr()) + [grads_plain]
+        self._run(tl[0])
+        self._run(tl[1])
 
     # -- optimizer --------------------------------------------------------------------------------------------------
     def bind_adam(self, opt):
@@ -375,15 +376,26 @@ class FlatPolicy(object):
         assert seg == sorted(seg) and seg[0] == 0
         self._seg = torch.tensor(seg + [PF_FLOATS], dtype=torch.int32, device=dev)
         self._coef = torch.zeros(int(self._lib.load().fa_adam_scratch_floats()), device=dev)   # [0]: the clip coefficient
+        self._hyper = torch.zeros(8, device=dev)      # (lr, beta1, beta2, eps, max_grad_norm): refresh_hyper()
+        self._hyper_host = None
         self._opt = opt
 
-    def adam_step(self, opt, max_grad_norm):
-        """clip_grad_norm_(max_grad_norm) + Adam over the flat buffers: fa_adam_step (two launches)."""
+    def refresh_hyper(self, opt, max_grad_norm):
+        """Bring the device copy of (lr, beta1, beta2, eps, max_grad_norm) up to date: fa_adam_step_dev reads them at run
+        time, so a captured optimizer step follows a change of opt.param_groups[0] (copy only when something moved)."""
         self.bind_adam(opt)
         g = opt.param_groups[0]
+        hp = (float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(max_grad_norm))
+        if hp != self._hyper_host:
+            self._hyper[:5].copy_(torch.tensor(hp, dtype=torch.float32))
+            self._hyper_host = hp
+
+    def adam_step(self, opt, max_grad_norm):
+        """clip_grad_norm_(max_grad_norm) + Adam over the flat buffers: fa_adam_step_dev (two launches)."""
+        if not torch.cuda.is_current_stream_capturing():
+            self.refresh_hyper(opt, max_grad_norm)
         L, C = self._lib, self._C
         vp = lambda t: C.c_void_p(t.data_ptr())
-        L.check(L.load().fa_adam_step(vp(self.pflat), vp(self.gflat), vp(self.mflat), vp(self.vflat), vp(self.steps), vp(self._seg),
-                                      len(_PF), PF_FLOATS, float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]),
-                                      float(g["eps"]), float(max_grad_norm), vp(self._coef),
-                                      C.c_void_p(torch.cuda.current_stream().cuda_stream)), "fa_adam_step")
+        L.check(L.load().fa_adam_step_dev(vp(self.pflat), vp(self.gflat), vp(self.mflat), vp(self.vflat), vp(self.steps), vp(self._seg),
+                                          len(_PF), PF_FLOATS, vp(self._hyper), vp(self._coef),
+                                          C.c_void_p(torch.cuda.current_stream().cuda_stream)), "fa_adam_step_dev")

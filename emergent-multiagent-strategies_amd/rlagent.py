@@ -1,6 +1,7 @@
 """The reference's per-agent holder ``Neo`` (rlagent.py:7-51) and its team trainer ``JointPPO``
 (rlcore/algo/ppo.py:98-204) over this package's RolloutStorage and joint_ppo_update: the same
-constructor arguments, attributes and methods, so that code written against the reference's
+constructor arguments and attributes, and every method the reference's Learner calls (the three it never
+calls -- act, before_update, update: dead code there -- exist and say so), so that code written against the reference's
 ``Learner`` internals (``agent.rollouts``, ``agent.actor_critic``, ``trainer.update(rollouts_list,
 opp_rollouts_list)``) runs on the repo's classes.  The batched trainer (learner.BatchedLearner) does
 not go through these -- it works on the joint tensors directly; a ``Neo`` built with
@@ -70,8 +71,28 @@ class Neo(object):
     def update_rollout(self, obs, reward, mask):                  # :33-34
         self.rollouts.insert(obs, self.states, self.action, self.action_log_prob, self.value, reward, mask)
 
+    def act(self, step, deterministic=False):                     # :36-39
+        """Never called by the reference's Learner (learner.py:160 runs the TEAM policy on the concatenated
+        observations) and not callable there either: it passes (obs, hidden, masks) where MPNN.act expects
+        (inp, state, oppInp).  A single agent's holder has no opponents' observations to give the MPNN."""
+        raise NotImplementedError("Neo.act: the MPNN needs the opponents' observations; act through the team policy "
+                                  "(BatchedLearner.step, or actor_critic.act(own, opp)) as learner.py:143-172 does")
+
     def wrap_horizon(self, next_value, start_pt, end_pt):         # :41-42
         self.rollouts.compute_returns(next_value, True, self.args.gamma, self.args.tau, start_pt, end_pt)
 
+    def before_update(self):                                      # :44-45 (storage.py:45 has it commented out)
+        fn = getattr(self.rollouts, "before_update", None)
+        if fn is not None:
+            fn()
+
     def after_update(self):                                       # :47-48
         self.rollouts.after_update()
+
+    def update(self):                                             # :50-51
+        """The reference's single-agent PPO over one agent's rollouts, unused by its Learner (teams are trained
+        by JointPPO, learner.py:175-188).  Set `trainer` to an object with update(rollouts) to use it."""
+        if self.trainer is None:
+            raise NotImplementedError("Neo.update: no single-agent trainer; teams are trained by JointPPO.update "
+                                      "(rlagent.JointPPO / BatchedLearner.update)")
+        return self.trainer.update(self.rollouts)

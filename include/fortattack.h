@@ -355,7 +355,39 @@ int fa_pack_weights(const float *plain, float *weights, float *weights_t, void *
 int fa_adam_step(float *params, float *grads, float *exp_avg, float *exp_avg_sq, float *steps, const int32_t *seg,
                  int32_t nseg, int32_t n, float lr, float beta1, float beta2, float eps, float max_grad_norm, float *scratch,
                  void *stream);
+/* The same step with the hyper-parameters read from device memory at run time: hyper = 5 floats (lr, beta1, beta2,
+ * eps, max_grad_norm).  A launch captured in a hipGraph then follows optimizer.param_groups[0] (a learning-rate
+ * schedule, a resumed run with another --lr; rlcore/algo/ppo.py:35 reads lr once) without a re-capture: rewrite the
+ * five floats, replay. */
+int fa_adam_step_dev(float *params, float *grads, float *exp_avg, float *exp_avg_sq, float *steps, const int32_t *seg,
+                     int32_t nseg, int32_t n, const float *hyper, float *scratch, void *stream);
 int64_t fa_adam_scratch_floats(void);
+
+/* ---- the cross-GPU exchange inside the library (RCCL, opened with dlopen at first use) -------------
+ * The reference is ONE process (train_fortattack.py:199).  With the env batch sharded over GPUs, two quantities
+ * must cover every rank's samples: the per-agent advantage mean / unbiased std of JointPPO.update
+ * (rlcore/algo/ppo.py:121-123) and -- for a consistent data-parallel learner -- the gradients of every optimizer
+ * step (ppo.py:189-193).  The Python package does both through torch.distributed (dist.py); these entry points are
+ * the same exchange for a consumer without torch, stream-ordered on the caller's stream, no host round trip.
+ * RCCL is not linked: librccl.so.1 (FA_RCCL_LIB overrides the name) is opened on first use; without it these calls
+ * return FA_ERR_STATE and everything else works.  `nccl_comm` is an ncclComm_t -- the caller's own, or one made by
+ * fa_rccl_comm_create (the 128-byte id from fa_rccl_unique_id on rank 0 reaches the other ranks by the caller's
+ * means: MPI, a file, torch.distributed.broadcast). */
+#define FA_RCCL_UNIQUE_ID_BYTES 128
+int fa_rccl_available(void);                 /* 1 when RCCL could be opened */
+const char *fa_rccl_library(void);           /* the name it was opened under ("" when unavailable) */
+int fa_rccl_unique_id(void *id_out);         /* ncclGetUniqueId: FA_RCCL_UNIQUE_ID_BYTES bytes (host) */
+int fa_rccl_comm_create(void **comm_out, int32_t nranks, const void *id, int32_t rank, int32_t device_id);
+int fa_rccl_comm_destroy(void *comm);
+int fa_rccl_comm_ranks(void *comm);          /* ncclCommCount (>= 1), negative on error */
+/* ppo.py:121-123 over ALL ranks: ncclAllGather of this rank's moments (N,3) = {n, mean, M2} (fa_gae_moments /
+ * fa_adv_moments) into gathered (world, N, 3) -- caller-owned device scratch -- then the exact merge of
+ * fa_adv_merge in rank order: every rank ends with the same bits in mean_out / std_out (N doubles each). */
+int fa_adv_allreduce(fa_env *env, const double *moments, double *gathered, void *nccl_comm, double *mean_out,
+                     double *std_out, void *stream);
+/* ncclAllReduce(sum, float32) of `n` floats in place: the flat gradient buffer of one optimizer step (the
+ * un-normalised gradients + loss sums + this rank's alive-mask mean, learner.py GraphedPPOStep). */
+int fa_grad_allreduce(float *flat, int64_t n, void *nccl_comm, void *stream);
 
 /* ---- state access (synchronous; tests / checkpoint) ------------------------------ */
 int fa_get_state(fa_env *env, const fa_state_host *out);

@@ -69,7 +69,14 @@ def test_collector_golden(fa, golden_dir):
             assert np.array_equal(views[i].masks.cpu().numpy(), g["after_masks"][j, i])
 
 
-@pytest.mark.parametrize("E,G,A,T", [(300, 3, 3, 64), (64, 5, 5, 128)])
+@pytest.mark.parametrize("E,G,A,T", [(300, 3, 3, 64), (64, 5, 5, 128),
+                                     # the three GAE kernels of fa_launch_gae (csrc/fa_collect.hip): <= 131 072 columns
+                                     # fa_gae_coop_kernel (above); between, or misaligned -> fa_gae_kernel; >= 262 144
+                                     # columns in multiples of four -> fa_gae4_kernel.  T = 40: two 16-step chunks + a tail
+                                     (32768, 3, 3, 40),        # 196 608 columns: fa_gae_kernel
+                                     (49152, 3, 3, 40),        # 294 912 columns: fa_gae4_kernel
+                                     (26215, 5, 5, 19),        # 262 150 columns, not a multiple of 4: fa_gae_kernel
+                                     (37, 2, 5, 33)])          # N = 7: the non-vectorised statistics kernels
 def test_gae_and_stats_vs_numpy_oracle(fa, E, G, A, T):
     import collector_oracle as co
     N = G + A
@@ -176,6 +183,9 @@ def test_fused_rollout_equals_per_step_launches(fa, G, A, E, T, chunk, rng, max_
 
 @pytest.mark.parametrize("E,G,A,T,shift", [(300, 3, 3, 64, 0.0), (64, 5, 5, 128, 0.0), (4096, 3, 3, 128, 0.0),
                                              (37, 2, 5, 33, 0.0),           # ragged: 259 columns, N = 7
+                                             (32768, 3, 3, 24, 0.0),        # fa_gae_kernel (196 608 columns)
+                                             (65536, 3, 3, 24, 0.0),        # fa_gae4_kernel (393 216 columns)
+                                             (4097, 3, 3, 9, 0.0),          # odd row count: fa_adv_onepass_kernel (non-vec)
                                              (500, 3, 3, 48, 1000.0)])      # |mean| >> std: no cancellation
 def test_gae_moments_one_pass_equals_gae_plus_two_pass(fa, E, G, A, T, shift):
     """fa_gae_moments (GAE, then one-pass advantage moments) == fa_gae followed

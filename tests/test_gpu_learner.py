@@ -85,13 +85,125 @@ def test_closed_loop_rollout_and_update(fa, use_graph, hidden, backend, tmp_path
     path = str(tmp_path / "ep0.pt")
     L.save(path)
     ck = torch.load(path, weights_only=False)
-    assert set(ck) == {"models", "ob_rms"} and len(ck["models"]) == N and ck["ob_rms"] == (None, None)
+    # the reference's two keys + the sampling position of the fused policy kernel (ignored by the reference's loader)
+    assert set(ck) == {"models", "ob_rms", "fa_rollout_counter"} and len(ck["models"]) == N and ck["ob_rms"] == (None, None)
+    assert ck["fa_rollout_counter"] == 2
     L2 = fa.BatchedLearner(fa.BatchedFortAttack(8, G, A, max_t), num_steps=4, hidden_dim=hidden)
     L2.load(path)
+    assert int(L2._rollout_counter.item()) == 2
     for a, b in zip(L.policies[1].parameters(), L2.policies[1].parameters()):
         assert torch.equal(a, b)
     only_guards = L.update(train_guards_only=True)      # train_fortattack_v2 path (learner.py:177)
     assert only_guards.shape == (1, 3)
+
+
+def test_bench_closed_loop_launch_at_full_size_vs_oracle(fa):
+    """The exact launch bench.py's `closed_loop` record times (bench.py closed_loop(): BatchedLearner(use_graph=True)
+    at 3v3 x 4096 envs x 128 steps, max_time_steps 100, base_seed 0 -- ONE hipGraph of 128 x (fa_policy_kernel<3> +
+    fa_step_kernel<3,3,false,true,3>) + V(obs[T])), two rollouts: env rows / masks / done against the oracle driven by
+    the sampled actions (bit for bit), the policy-side rows against the PyTorch definition, GAE returns against the
+    numpy oracle (bit for bit, including the stale entries carried from the first rollout into the second)."""
+    import collector_oracle as co
+    from fa_oracle import OracleEnv
+    torch.manual_seed(0)
+    E, G, A, T, max_t = 4096, 3, 3, 128, 100
+    N = G + A
+    eng = fa.BatchedFortAttack(E, G, A, max_t, base_seed=0)
+    orc = OracleEnv(E, G, A, max_t, base_seed=0)
+    L = fa.BatchedLearner(eng, num_steps=T, use_graph=True)
+    assert L.policy_backend == "hip" and L._update_graphs["fused"]
+    torch.manual_seed(1)
+    L.reset()
+    assert L._graphs is not None
+    stale = np.zeros((T + 1, E, N, 1), np.float32)
+    for upd in range(2):
+        L.collect()
+        torch.cuda.synchronize()
+        ep_start, rew, vals, msk, rets = _check_rollout_against_oracle(fa, L, orc, first=(upd == 0))
+        want = stale.copy()
+        for i in range(N):
+            co.gae_single_pass(rew[:, :, i], vals[:, :, i], msk[:, :, i], want[:, :, i], ep_start, 0.99, 0.95)
+        assert np.array_equal(rets, want)
+        stale = rets
+        assert int(L.storage.done.sum()) >= E              # every env ended at least once (max_t = 100 < T)
+        mean, std = L._adv_mean_std
+        for i in range(N):
+            a = (rets[:-1, :, i] - vals[:-1, :, i]).astype(np.float32).astype(np.float64)
+            assert abs(float(mean[i]) - a.mean()) <= 1e-12 * max(1.0, abs(a.mean()))
+            assert abs(float(std[i]) - a.std(ddof=1)) <= 1e-11 * a.std(ddof=1)
+        L.after_update()
+
+
+def test_one_learner_mixing_update_variants_keeps_every_captured_step_valid(fa):
+    """A learner that runs update() (two-chain steps), update(train_guards_only=True) (a second captured step for the
+    guards' policy with its own gradient buffer) and update() again: every captured graph keeps replaying its own
+    unfold task list (mpnn_pack.FlatPolicy.unfold keeps one list per gradient buffer) -- the repeated update equals
+    the first one bit for bit from the same state."""
+    torch.manual_seed(2)
+    eng = fa.BatchedFortAttack(256, 3, 3, 12, base_seed=8)
+    L = fa.BatchedLearner(eng, num_steps=16, num_mini_batch=4, ppo_epoch=2, use_graph=True, update_backend="fused")
+    L.reset()
+    L.collect()
+    fps = L._flat
+
+    def snap():
+        return [(fp.pflat.clone(), getattr(fp, "mflat", None) is not None and fp.mflat.clone(),
+                 getattr(fp, "vflat", None) is not None and fp.vflat.clone(),
+                 getattr(fp, "steps", None) is not None and fp.steps.clone()) for fp in fps]
+
+    def restore(sn):
+        for fp, (p, m, v, st) in zip(fps, sn):
+            fp.pflat.copy_(p)
+            if m is not False:
+                fp.mflat.copy_(m); fp.vflat.copy_(v); fp.steps.copy_(st)
+
+    torch.manual_seed(7)
+    L.update()                                              # captures; binds the optimizers to the flat buffers
+    s0 = snap()
+    torch.manual_seed(7)
+    l1 = L.update().clone()
+    p1 = [fp.pflat.clone() for fp in fps]
+    restore(s0)
+    L.update(train_guards_only=True)                        # a second GraphedPPOStep of the guards' policy
+    assert len(fps[0]._unfold) == 2 and len(fps[1]._unfold) == 1
+    for _ in range(3):                                      # churn the allocator: a freed task list would be reused
+        torch.empty(1 << 16, device="cuda").random_()
+    restore(s0)
+    torch.manual_seed(7)
+    l2 = L.update().clone()
+    torch.cuda.synchronize()
+    assert torch.equal(l1, l2)
+    assert all(torch.equal(a, fp.pflat) for a, fp in zip(p1, fps))
+
+
+def test_captured_optimizer_step_follows_the_learning_rate(fa):
+    """lr / betas / eps reach fa_adam_step through device memory (fa_adam_step_dev), not as values frozen into the
+    hipGraph: halving param_groups[0]['lr'] after the capture halves the next first-step displacement."""
+    torch.manual_seed(3)
+    eng = fa.BatchedFortAttack(128, 3, 3, 12, base_seed=1)
+    L = fa.BatchedLearner(eng, num_steps=8, num_mini_batch=1, ppo_epoch=1, use_graph=True, update_backend="fused", lr=1e-3)
+    L.reset()
+    L.collect()
+    L.update()                                              # capture
+    fp = L._flat[0]
+    moved = []
+    for lr in (1e-3, 5e-4):
+        L.optimizers[0].param_groups[0]["lr"] = lr
+        fp.mflat.zero_(); fp.vflat.zero_(); fp.steps.zero_()
+        before = fp.pflat.clone()
+        torch.manual_seed(4)
+        L.update()
+        moved.append((fp.pflat - before).abs().max().item())
+        fp.pflat.copy_(before)
+    assert abs(moved[0] - 1e-3) < 2e-5 and abs(moved[1] - 5e-4) < 1e-5, moved   # Adam's first step is lr * sign(g)
+
+
+def test_fused_update_backend_is_refused_where_it_cannot_run(fa):
+    eng = fa.BatchedFortAttack(64, 3, 3, 10)
+    with pytest.raises(ValueError, match="update_backend='fused'"):
+        fa.BatchedLearner(eng, num_steps=8, use_graph=False, update_backend="fused")
+    with pytest.raises(ValueError, match="update_backend='fused'"):
+        fa.BatchedLearner(eng, num_steps=8, use_graph=True, hidden_dim=32, update_backend="fused")
 
 
 @pytest.mark.parametrize("use_graph", [False, True])

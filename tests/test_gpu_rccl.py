@@ -1,0 +1,142 @@
+"""GPU: RCCL really executes (`ncclAllReduce` on the step stream).  A one-GPU box cannot hold two
+RCCL ranks, so both routes run with ONE rank pushed through the collective branch, where the collectives must change
+nothing:
+
+  * torch.distributed backend "nccl" (== RCCL), world_size 1, dist.FORCE_COLLECTIVE: librccl is loaded, a communicator
+    is created, the f64 all_gather_into_tensor of the advantage moments and the flat gradient all_reduce between the
+    two graph replays of every optimizer step run;
+  * the library's own route (include/fortattack.h fa_adv_allreduce / fa_grad_allreduce, dist.LibraryExchange): RCCL
+    opened by libfortattack_hip.so with dlopen, no process group at all.
+
+Checked against the no-collective path: advantage mean / std bit for bit; the update to the rounding of the one
+division that moves (the un-normalised gradients are divided by the mask mean after the exchange instead of inside
+the kernel).
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _collector(fa, exchange=None):
+    """Open-loop rollout + GAE + advantage statistics (bench.py's hot path) -> mean, std as numpy."""
+    from emergent_multiagent_strategies_amd.dist import gae_adv_mean_std
+    E, G, A, T = 512, 3, 3, 32
+    N = G + A
+    eng = fa.BatchedFortAttack(E, G, A, 15, base_seed=5)
+    st = fa.JointRolloutStorage(T, E, N, device="cuda")
+    eng.bind_storage(st)
+    g = torch.Generator(device="cuda").manual_seed(9)
+    st.actions.copy_(torch.randint(0, 8, st.actions.shape, device="cuda", generator=g))
+    st.value_preds.copy_(torch.randn(st.value_preds.shape, device="cuda", generator=g))
+    eng.collect_reset()
+    eng.collect_rollout(0, T)
+    mean, std = gae_adv_mean_std(eng, 0.99, 0.95, exchange=exchange)
+    torch.cuda.synchronize()
+    return mean.cpu().numpy().copy(), std.cpu().numpy().copy()
+
+
+def _learner(fa, exchange="torch"):
+    """Two collect + update rounds of the closed-loop learner (hidden_dim 128, hipGraphs, fused update)."""
+    torch.manual_seed(0)
+    eng = fa.BatchedFortAttack(128, 3, 3, 10, base_seed=3)
+    L = fa.BatchedLearner(eng, num_steps=16, num_mini_batch=4, ppo_epoch=2, use_graph=True, update_backend="fused",
+                          exchange=exchange)
+    torch.manual_seed(100)
+    L.reset()
+    L.collect()
+    acts = L.storage.actions.cpu().numpy().copy()
+    losses = L.update().cpu().numpy()                   # compared: one update (8 Adam steps per team) from the same rollout
+    params = [fp.pflat.cpu().numpy().copy() for fp in L._flat]
+    L.after_update()
+    L.collect()                                         # a second round on the captured graphs
+    assert bool(torch.isfinite(L.update()).all())
+    torch.cuda.synchronize()
+    steps = [v for k, v in L._update_graphs.items() if isinstance(k, tuple)]
+    return L, params, losses, acts, all(s.g2 is not None for s in steps)
+
+
+def _loaded_rccl():
+    return sorted({l.split()[-1] for l in open("/proc/self/maps") if "librccl" in l})
+
+
+def _worker(route, port, q):
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        sys.path.insert(0, ROOT)
+        torch.cuda.set_device(0)
+        import emergent_multiagent_strategies_amd as fa
+        from emergent_multiagent_strategies_amd import dist as fdist
+        out = {}
+        out["plain_ms"] = _collector(fa)                            # no process group: no collective
+        _, out["plain_p"], out["plain_l"], out["plain_a"], two = _learner(fa)
+        assert not two
+        if route == "torch-nccl":
+            import torch.distributed as dist
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+            fdist.FORCE_COLLECTIVE = True
+            assert fdist.exchanging()
+            out["coll_ms"] = _collector(fa)
+            _, out["coll_p"], out["coll_l"], out["coll_a"], two = _learner(fa)
+            out["ranks"], out["backend"] = dist.get_world_size(), dist.get_backend()
+            # a plain f64 all-gather and f32 all-reduce on this communicator, for the record
+            x = torch.arange(18, dtype=torch.float64, device="cuda")
+            y = torch.empty_like(x)
+            dist.all_gather_into_tensor(y, x)
+            z = torch.ones(1000, device="cuda")
+            dist.all_reduce(z)
+            torch.cuda.synchronize()
+            assert torch.equal(x, y) and float(z.sum()) == 1000.0
+            dist.destroy_process_group()
+        else:
+            ex = fdist.LibraryExchange("cuda:0")
+            out["ranks"], out["backend"] = ex.ranks(), fa._lib.load().fa_rccl_library().decode()
+            out["coll_ms"] = _collector(fa, exchange=ex)
+            z = torch.full((1000,), 2.0, device="cuda")
+            ex.all_reduce_(z)
+            torch.cuda.synchronize()
+            assert float(z.sum()) == 2000.0
+            ex.close()
+            L, out["coll_p"], out["coll_l"], out["coll_a"], two = _learner(fa, exchange="rccl")
+            assert L._exch.ranks() == 1
+        out["two_graphs"] = two
+        out["rccl_maps"] = _loaded_rccl()
+        q.put(("ok", out))
+    except Exception as exc:   # the parent asserts on the message
+        import traceback
+        q.put(("error", traceback.format_exc()))
+
+
+@pytest.mark.parametrize("route", ["torch-nccl", "library"])
+def test_one_rank_through_rccl_changes_nothing(route):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_worker, args=(route, _free_port(), q))
+    p.start()
+    status, out = q.get(timeout=900)
+    p.join(timeout=120)
+    assert status == "ok", out
+    assert out["rccl_maps"], "librccl was not mapped into the process"
+    assert out["ranks"] == 1 and (out["backend"] == "nccl" if route == "torch-nccl" else "rccl" in out["backend"])
+    assert out["two_graphs"]                                        # every optimizer step: graph 1 -> all-reduce -> graph 2
+    # the advantage statistics through the all-gather + merge: the same bits
+    assert np.array_equal(out["plain_ms"][0], out["coll_ms"][0]) and np.array_equal(out["plain_ms"][1], out["coll_ms"][1])
+    # the same rollout (sampling does not depend on the exchange) ...
+    assert np.array_equal(out["plain_a"], out["coll_a"])
+    # ... and the same update up to the moved division: 8 Adam steps of 1e-4 per team
+    assert np.abs(out["plain_l"] - out["coll_l"]).max() < 2e-4 * max(1.0, np.abs(out["plain_l"]).max())
+    worst = max(np.abs(a - b).max() for a, b in zip(out["plain_p"], out["coll_p"]))
+    assert worst < 4e-4, worst

@@ -72,12 +72,18 @@ def main():
                           ppo_epoch=args.ppo_epoch, num_mini_batch=args.num_mini_batch,
                           value_loss_coef=args.value_loss_coef, entropy_coef=args.entropy_coef,
                           max_grad_norm=args.max_grad_norm, gamma=args.gamma, tau=args.tau,
-                          clipped_value_loss=not args.no_clipped_value_loss, use_graph=not args.no_graph)
-    torch.manual_seed(args.seed + 1 + rank)            # different action sampling per rank
+                          clipped_value_loss=not args.no_clipped_value_loss, use_graph=not args.no_graph,
+                          sample_seed=args.seed + 1)
+    # Action sampling (fused policy kernel): Philox keyed by (sample_seed; rollout counter, step, GLOBAL env index,
+    # agent) -- the same seed on every rank, the env index makes the shards differ.  torch's generator only draws
+    # the minibatch permutations (and the samples of the PyTorch policy fallback): different per rank.
+    torch.manual_seed(args.seed + 1 + rank)
     if args.continue_training:
         if not args.load_dir:
             raise SystemExit("--continue-training needs --load-dir (the checkpoint file to resume from)")
-        L.load(args.load_dir)
+        L.load(args.load_dir)                          # (restores the sampling position when the checkpoint has it)
+        if int(L._rollout_counter.item()) == 0:        # a reference checkpoint: continue past the rollouts already made
+            L._rollout_counter.fill_(args.ckpt + 1)
     if args.guard_load_dir:
         L.policies[0].load_state_dict(torch.load(args.guard_load_dir, map_location="cpu", weights_only=False)["models"][0])
     if args.train_guards_only:
