@@ -10,12 +10,15 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libfa_oracle.so")
+# FA_ORACLE_LIB: another build of the same source (`make asan`: libfa_oracle_asan.so under LD_PRELOAD=libasan.so)
+_LIB_PATH = os.environ.get("FA_ORACLE_LIB") or os.path.join(_HERE, "libfa_oracle.so")
 _lib = None
 
 
 def build(force=False):
     """Compile the oracle with gcc (seconds)."""
+    if os.environ.get("FA_ORACLE_LIB"):
+        return _LIB_PATH
     if force or not os.path.isfile(_LIB_PATH) or (
             os.path.getmtime(_LIB_PATH) < os.path.getmtime(os.path.join(_HERE, "fa_oracle.c"))):
         subprocess.check_call(["make", "-C", _HERE, "-s", "-B"])

@@ -271,6 +271,74 @@ def gen_mpnn_fixture():
     print("mpnn_h32       params(full)=%d" % int(rec["full_param_count"]))
 
 
+def mpnn_h128_setup(pol, torch):
+    """What both sides do to a freshly constructed full-size policy before the h = 128 golden forward (here on the
+    reference module, in tests/ on the repo's): non-zero biases and larger logits than the 0.01-gain init gives, drawn
+    from torch's global stream in parameter order."""
+    for p in pol.parameters():
+        if p.dim() == 1:
+            p.data.uniform_(-0.3, 0.3)
+    pol.dist.linear.weight.data.mul_(3.0)
+
+
+def mpnn_fingerprint(pol, np):
+    """(P, 4) float64 per parameter tensor in state_dict order: sum, sum of absolute values, first and last element
+    (numpy float64 sums).  Compared with a tolerance: orthogonal_ init goes through a LAPACK QR whose last bits
+    depend on the thread count / CPU dispatch, so the seed gives the same weights to ~1e-7, not to the bit."""
+    out = []
+    for v in pol.state_dict().values():
+        a = v.detach().cpu().numpy().reshape(-1).astype(np.float64)
+        out.append([a.sum(), np.abs(a).sum(), a[0], a[-1]])
+    return np.array(out, np.float64)
+
+
+def gen_mpnn_h128_fixture():
+    """The reference MPNN at its full size (hidden_dim 128, mpnn.py:18-89), both teams, 3v3 and 5v5: seed-constructed
+    weights (NOT shipped: 158 153 floats per policy; the repo's module draws the same ones from the same seed -- the
+    fingerprints in the fixture prove it before anything is compared) + observations -> value, log-softmax of the
+    logits.  Closes the chain reference -> mpnn.py -> fa_policy_kernel at h = 128 on the GPU box."""
+    import torch
+    rh.import_reference()
+    torch.set_num_threads(1)
+    from mpnn import MPNN
+
+    class _Sp(object):
+        shape = (8,)
+
+    rec = {}
+    for tag, G, A, seed, B in (("3v3", 3, 3, 21, 96), ("5v5", 5, 5, 22, 60)):
+        N = G + A
+        torch.manual_seed(seed)
+        nets = []
+        for n, m in ((G, A), (A, G)):
+            net = MPNN(action_space=_Sp(), num_agents=n, num_opp_agents=m, num_entities=0, input_size=6, pos_index=2,
+                       mask_dist=None, entity_mp=False, policy_layers=1)
+            mpnn_h128_setup(net, torch)
+            nets.append(net)
+        g = torch.Generator().manual_seed(seed + 100)
+        obs = torch.randn((B, N, 6), generator=g)
+        obs[:, :, 0] = (torch.rand((B, N), generator=g) > 0.3).float()
+        obs[:, :, 3] = obs[:, :, 3] * 3 + 4.7
+        value, logp = torch.zeros(B, N), torch.zeros(B, N, 8)
+        with torch.no_grad():
+            for net, own, opp in ((nets[0], slice(0, G), slice(G, N)), (nets[1], slice(G, N), slice(0, G))):
+                n = own.stop - own.start
+                inp = obs[:, own].transpose(0, 1).reshape(-1, 6)      # agent-major, as learner.py:150-152 cats
+                oin = obs[:, opp].transpose(0, 1).reshape(-1, 6)
+                x = net._fwd(inp, oin, None)
+                v = net._value(x)
+                lg = net.dist(net._policy(x)).logits                  # normalised logits = log-softmax
+                value[:, own] = v.view(n, B).transpose(0, 1)
+                logp[:, own] = lg.view(n, B, 8).transpose(0, 1)
+        rec[tag + ".meta"] = np.array([G, A, seed, B], np.int64)
+        rec[tag + ".obs"] = obs.numpy()
+        rec[tag + ".value"], rec[tag + ".logp_all"] = value.numpy(), logp.numpy()
+        rec[tag + ".fingerprint_g"] = mpnn_fingerprint(nets[0], np)
+        rec[tag + ".fingerprint_a"] = mpnn_fingerprint(nets[1], np)
+    np.savez_compressed(os.path.join(OUT, "mpnn_h128.npz"), **rec)
+    print("mpnn_h128      ", {k: v.shape for k, v in rec.items() if k.endswith("obs")})
+
+
 def gen_choice_fixture():
     """The ensemble path's RNG interleaving: train_fortattack_v2.py follows EVERY
     env.reset() -- the first one (:29-35) and each episode-end one (:104-111) -- with
@@ -309,7 +377,7 @@ def gen_choice_fixture():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["mt", "env", "collector", "mpnn", "choice"]
+    which = sys.argv[1:] or ["mt", "env", "collector", "mpnn", "mpnn128", "choice"]
     if "choice" in which:
         gen_choice_fixture()
     if "mt" in which:
@@ -320,5 +388,7 @@ if __name__ == "__main__":
         gen_collector_fixture()
     if "mpnn" in which:
         gen_mpnn_fixture()
+    if "mpnn128" in which:
+        gen_mpnn_h128_fixture()
     sizes = {f: os.path.getsize(os.path.join(OUT, f)) for f in sorted(os.listdir(OUT)) if f.endswith(".npz")}
     print(sizes, "total", sum(sizes.values()))

@@ -70,6 +70,34 @@ def test_fused_forward_matches_torch_module(fa, G, A, E):
     assert torch.equal(v2, v) and none_a is None and none_l is None
 
 
+@pytest.mark.parametrize("tag", ["3v3", "5v5"])
+def test_fused_forward_matches_the_reference_golden_at_full_size(fa, golden_dir, tag):
+    """fa_policy_kernel against the REFERENCE's mpnn.py at hidden_dim 128 (tests/golden/mpnn_h128.npz: values and
+    log-softmax logits of the reference module; its seed-constructed weights are re-made here and proven equal by
+    their fingerprints): no hop through this repo's PyTorch module."""
+    import os
+    from emergent_multiagent_strategies_amd import mpnn_pack
+    from test_mpnn_cpu import h128_policies
+    g = np.load(os.path.join(golden_dir, "mpnn_h128.npz"))
+    pols, G, A = h128_policies(fa.MPNN, g, tag, device="cuda")
+    packed = [mpnn_pack.pack_policy(p) for p in pols]
+    obs = torch.from_numpy(g[tag + ".obs"]).cuda().contiguous()
+    E = obs.shape[0]
+    eng = fa.BatchedFortAttack(E, G, A, 20)
+    v, act, lp = eng.policy_act(obs, packed[0], packed[1], deterministic=True)
+    want_v = torch.from_numpy(g[tag + ".value"]).cuda()
+    want_lp = torch.from_numpy(g[tag + ".logp_all"]).cuda()
+    assert (v - want_v).abs().max() < TOL
+    assert (lp - want_lp.gather(-1, act.unsqueeze(-1))[..., 0]).abs().max() < TOL
+    top2 = want_lp.topk(2, dim=-1).values
+    clear = (top2[..., 0] - top2[..., 1]) > 1e-3
+    assert torch.equal(act[clear], want_lp.argmax(-1)[clear]) and float(clear.float().mean()) > 0.9
+    # sampled actions' log-probs come from the same table
+    counter = torch.zeros(1, dtype=torch.int64, device="cuda")
+    _, act_s, lp_s = eng.policy_act(obs, packed[0], packed[1], seed=5, counter=counter, step=0)
+    assert (lp_s - want_lp.gather(-1, act_s.unsqueeze(-1))[..., 0]).abs().max() < TOL
+
+
 def test_sampling_is_a_draw_from_softmax_and_reproducible(fa):
     G, A, E = 3, 3, 16384
     N = G + A

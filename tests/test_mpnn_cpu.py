@@ -43,6 +43,48 @@ def test_forward_matches_reference_golden(MPNN, golden_dir, tag):
     assert np.abs(ours.numpy() - ref_logits.numpy()).max() < TOL
 
 
+def h128_policies(MPNN, golden, tag, device="cpu"):
+    """The two full-size policies of tests/golden/mpnn_h128.npz re-made from their seed (oracle/gen_golden.py
+    gen_mpnn_h128_fixture does the same to the reference's module), fingerprints checked against the reference's."""
+    G, A, seed, B = [int(v) for v in golden[tag + ".meta"]]
+    torch.manual_seed(seed)
+    pols = []
+    for (n, m), fp_key in (((G, A), ".fingerprint_g"), ((A, G), ".fingerprint_a")):
+        pol = MPNN(num_agents=n, num_opp_agents=m, num_actions=8)
+        for p in pol.parameters():
+            if p.dim() == 1:
+                p.data.uniform_(-0.3, 0.3)
+        pol.dist.linear.weight.data.mul_(3.0)
+        fp = []
+        for v in pol.state_dict().values():
+            a = v.detach().numpy().reshape(-1).astype(np.float64)
+            fp.append([a.sum(), np.abs(a).sum(), a[0], a[-1]])
+        # (to 1e-6, not to the bit: orthogonal_'s LAPACK QR rounds differently with the thread count / CPU)
+        fp, ref = np.array(fp), golden[tag + fp_key]
+        assert (np.abs(fp[:, :2] - ref[:, :2]).max(1) <= 1e-6 * ref[:, 1] + 1e-6).all() and \
+            np.abs(fp[:, 2:] - ref[:, 2:]).max() < 1e-5, "seed-constructed weights differ from the reference's"
+        pols.append(pol.to(device))
+    return pols, G, A
+
+
+@pytest.mark.parametrize("tag", ["3v3", "5v5"])
+def test_full_size_forward_matches_reference_golden(MPNN, golden_dir, tag):
+    """hidden_dim 128 (the size the kernels implement): same seed -> the reference's weights (fingerprints), same
+    observations -> the reference's values and log-softmax logits."""
+    g = np.load(os.path.join(golden_dir, "mpnn_h128.npz"))
+    pols, G, A = h128_policies(MPNN, g, tag)
+    obs = torch.from_numpy(g[tag + ".obs"])
+    N = G + A
+    with torch.no_grad():
+        lg, vg = pols[0].logits_value(obs[:, :G], obs[:, G:])
+        la, va = pols[1].logits_value(obs[:, G:], obs[:, :G])
+    value = torch.cat((vg, va), 1)[..., 0]
+    logp = torch.log_softmax(torch.cat((lg, la), 1), -1)
+    assert np.abs(value.numpy() - g[tag + ".value"]).max() < TOL
+    assert np.abs(logp.numpy() - g[tag + ".logp_all"]).max() < TOL
+    assert float(np.exp(g[tag + ".logp_all"]).max()) > 0.2       # not the near-uniform policy of the 0.01-gain init
+
+
 def test_full_size_parameter_inventory(MPNN, golden_dir):
     g = _golden(golden_dir)
     net = MPNN(num_agents=3, num_opp_agents=3, num_actions=8)
