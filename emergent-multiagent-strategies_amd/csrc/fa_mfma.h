@@ -7,6 +7,9 @@
 
 #include "fa_policy.h"
 
+#ifndef FA_GEMM_CH
+#define FA_GEMM_CH 8 // 16-byte weight steps requested ahead per lane (a chunk = FA_GEMM_CH x 4 MFMAs per row block)
+#endif
 namespace {
 constexpr int LDA = 132;           // padded LDS row stride in floats (128 + 4)
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -16,7 +19,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 template <int K>
 struct BHead {
     static constexpr int NT = K / 8;           // 16-byte steps per lane half
-    static constexpr int CH = NT < 8 ? NT : 8;  // steps per chunk
+    static constexpr int CH = NT < FA_GEMM_CH ? NT : FA_GEMM_CH;  // steps per chunk
     float4 v[CH];
 };
 template <int K>
@@ -40,6 +43,11 @@ __device__ __forceinline__ void gemm_cb(const float *arow, const float4 *__restr
         if (t0 + CH < NT) {
 #pragma unroll
             for (int c = 0; c < CH; ++c) bn[c] = wp[(t0 + CH + c) * 64 + lane];
+#ifndef FA_NO_SCHED_BARRIER
+            // keep the requests HERE: under register pressure the scheduler sinks each load to its first use and
+            // waits for an L2 round trip (vmcnt(0)) in front of every four MFMAs
+            __builtin_amdgcn_sched_barrier(0);
+#endif
         }
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
@@ -144,6 +152,67 @@ __device__ __forceinline__ void attend_row(const float *grow, const float *key0,
         for (int j = 1; j < FA_POLICY_MAX_TEAM; ++j) aq = (j == q) ? s[j] : aq;
         attn_row[q] = aq * inv;
     }
+}
+
+// The same attention row with the env's keys held in registers (MT >= nk: 4 for teams of up to four, else
+// FA_POLICY_MAX_TEAM) and no divergent control flow -- the excluded pair is masked, not skipped -- and the result
+// returned in registers, so that a caller can compute several rows before it stores any (the loads of the next
+// row then overlap this row's DPP / exp chains).  Same operations in the same order as attend_row: same bits.
+template <int W, int MT>
+__device__ __forceinline__ void attend_row_regs(const float *grow, const float *key0, int nk, int skip, int q, float (&ov)[W / 16],
+                                                float *attn_row = nullptr) {
+    constexpr int C = W / 16;
+    float gv[C], kv[MT][C];
+#pragma unroll
+    for (int c = 0; c < C; c += 4) *reinterpret_cast<float4 *>(gv + c) = *reinterpret_cast<const float4 *>(grow + q * C + c);
+#pragma unroll
+    for (int j = 0; j < MT; ++j) {
+#pragma unroll
+        for (int c = 0; c < C; c += 4)
+            *reinterpret_cast<float4 *>(&kv[j][c]) = j < nk ? *reinterpret_cast<const float4 *>(key0 + j * LDA + q * C + c) : float4{0, 0, 0, 0};
+    }
+    float s[MT], mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < MT; ++j) {
+        float d = 0.0f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) d = fmaf(gv[c], kv[j][c], d);
+        s[j] = group16_sum(d);
+    }
+#pragma unroll
+    for (int j = 0; j < MT; ++j) {
+        s[j] = (j < nk && j != skip) ? s[j] : -INFINITY;
+        mx = fmaxf(mx, s[j]);
+    }
+    float den = 0.0f;
+#pragma unroll
+    for (int j = 0; j < MT; ++j) {
+        s[j] = (j < nk && j != skip) ? __expf(s[j] - mx) : 0.0f;
+        den += s[j];
+    }
+    const float inv = den > 0.0f ? 1.0f / den : 0.0f; // a team of one has nobody to listen to: msg = 0 (mpnn.py:266-274)
+#pragma unroll
+    for (int c = 0; c < C; ++c) ov[c] = 0.0f;
+#pragma unroll
+    for (int j = 0; j < MT; ++j) {
+        if (j < nk) { // (uniform; the excluded pair's weight is an exact 0: fmaf(0, k, o) == o)
+            const float a = s[j] * inv;
+#pragma unroll
+            for (int c = 0; c < C; ++c) ov[c] = fmaf(a, kv[j][c], ov[c]);
+        }
+    }
+    if (attn_row && q < nk) {
+        float aq = s[0];
+#pragma unroll
+        for (int j = 1; j < MT; ++j) aq = (j == q) ? s[j] : aq;
+        attn_row[q] = aq * inv;
+    }
+}
+template <int W>
+__device__ __forceinline__ void store_row_regs(float *orow, int q, const float (&ov)[W / 16]) {
+    constexpr int C = W / 16;
+#pragma unroll
+    for (int c = 0; c < C; c += 4) *reinterpret_cast<float4 *>(orow + q * C + c) = *reinterpret_cast<const float4 *>(ov + c);
 }
 
 } // namespace

@@ -37,10 +37,16 @@
 // generator cannot be reproduced from inside a kernel).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "fa_policy.h"
 #include "fa_mfma.h"
+#define FA_PROBE_POLICY_TU
+#include "fa_probe.h"
 
+#ifndef FA_POLICY_WAVES
+#define FA_POLICY_WAVES 8 // waves of the 96-row tile's workgroup (4: one per SIMD, the round-2 shape)
+#endif
 namespace {
 __device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
 #pragma unroll
@@ -53,18 +59,30 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32
     }
 }
 
-// NRB = 32-row blocks per tile: 3 (96 rows, one workgroup per CU: the weights in registers are reused three
-// times) or 2 (64 rows, 75 KB of LDS: two workgroups per CU, whose phases interleave -- one's MFMA chains
-// run under the other's stores / attention / barriers)
-template <int NRB>
-__global__ __launch_bounds__(256, NRB == 2 ? 2 : 1) void fa_policy_kernel(FaPolicyArgs a) {
+// NRB = 32-row blocks per tile: 3 (96 rows, one workgroup per CU) or 2 (64 rows, 75 KB of LDS: two workgroups
+// per CU; small batches).  NW = waves per workgroup.  The 96-row tile runs EIGHT waves, two per SIMD: waves 0..3
+// own column block `wave` of row blocks 0 and 1, waves 4..7 the same column block of row block 2 -- a SIMD's MFMA
+// work is what one wave did before (three 32 x 32 tiles per layer), but while one of its waves stores accumulators,
+// waits at a barrier or for an LDS read, the other's MFMA chain runs, and the phases no MFMA runs in (encoders,
+// attention, sampling: latency-bound LDS / DPP chains) have twice the waves to hide their latencies with.
+#define FA_POLICY_SPLIT(...)                                                          \
+    if constexpr (NW == 8) {                                                          \
+        if (wave < 4) { constexpr int R0 = 0, NR = 2; __VA_ARGS__ }                   \
+        else { constexpr int R0 = 2, NR = 1; __VA_ARGS__ }                            \
+    } else if constexpr (NW == 12) {                                                  \
+        const int R0 = wave >> 2; constexpr int NR = 1; __VA_ARGS__                   \
+    } else { constexpr int R0 = 0, NR = NRB; __VA_ARGS__ }
+template <int NRB, int NW>
+__global__ __launch_bounds__(NW * 64, NRB == 2 ? 2 : 1) void fa_policy_kernel(FaPolicyArgs a) {
+    static_assert((NRB == 3 && (NW == 8 || NW == 12)) || NW == 4, "eight / twelve waves: the 96-row tile");
     constexpr int PR = 32 * NRB; // rows (env, agent) per tile
+    constexpr int NT = NW * 64;
     __shared__ __attribute__((aligned(16))) float sH[PR * LDA]; // own hidden state h (128 wide)
     __shared__ __attribute__((aligned(16))) float sG[PR * LDA]; // g / hmix; opponent stage scratch
     __shared__ float sX[PR * 2 * FA_OBS_DIM];                    // observations of the tile's envs (all agents)
     __shared__ float sO[PR * 16];                                // logits (8) + value per row
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int team = blockIdx.y;
     const int N = a.G + a.A;
     const int n = team == 0 ? a.G : a.A, m = N - n;   // own / opponent team size
@@ -84,36 +102,43 @@ __global__ __launch_bounds__(256, NRB == 2 ? 2 : 1) void fa_policy_kernel(FaPoli
         if (e0 >= a.E) return;
         if (tid < ET) sE[tid] = e0 + tid < a.E ? e0 + tid : -1;
     }
+    // (the encoder weights of this thread's column: requested ahead of the observation round trip)
+    float we[FA_OBS_DIM], wo[FA_OBS_DIM];
+#pragma unroll
+    for (int k = 0; k < FA_OBS_DIM; ++k) {
+        we[k] = W[FA_POFF_WE + k * 64 + (tid & 63)];
+        wo[k] = W[FA_POFF_WOE + k * 64 + (tid & 63)];
+    }
+    const float be = W[FA_POFF_BE + (tid & 63)], bo = W[FA_POFF_BOE + (tid & 63)];
     __syncthreads();
 
     // ---- observations of the tile's envs (N * 6 contiguous floats per env) -------------------------------
-    for (int k = tid; k < ET * N * FA_OBS_DIM; k += 256) {
+    for (int k = tid; k < ET * N * FA_OBS_DIM; k += NT) {
         const int el = k / (N * FA_OBS_DIM), e = sE[el];
         sX[k] = e >= 0 ? a.obs[(size_t)e * N * FA_OBS_DIM + (k - el * N * FA_OBS_DIM)] : 0.0f;
     }
     __syncthreads();
 
+    FA_PL_TICK(0)
     const int li = lane & 31, hh = lane >> 5;
+    const int cbw = wave & 3;                 // this wave's column block of the 128-wide layers
+    // the 64-wide layers of the opponent stage have 2 x NRB output tiles: column block ocb, row block(s) from orb
+    const bool opp_two = NW == 4 && NRB == 3 && wave < 2;                 // four waves: waves 0, 1 take two row blocks
+    const bool opp_on = NW == 4 || wave < 2 * NRB;
+    const int ocb = wave & 1, orb = NW >= 8 ? (wave >> 1) : (NRB == 3 ? 2 : (wave >> 1));
     const float4 *Wq = reinterpret_cast<const float4 *>(W);
-    const float4 *wp_ao = Wq + FA_POFF_AO / 4 + (wave & 1) * (64 / 8) * 64;
-    const float4 *wp_bo = Wq + FA_POFF_BO / 4 + (wave & 1) * (64 / 8) * 64;
-    const float4 *wp_am = Wq + FA_POFF_AM / 4 + wave * (128 / 8) * 64;
-    const float4 *wp_w7 = Wq + FA_POFF_W7 / 4 + wave * (256 / 8) * 64;
-    const float4 *wp_w8p = Wq + FA_POFF_W8 / 4 + wave * (128 / 8) * 64;
-    const float4 *wp_w8v = Wq + FA_POFF_W8 / 4 + (4 + wave) * (128 / 8) * 64;
+    const float4 *wp_ao = Wq + FA_POFF_AO / 4 + ocb * (64 / 8) * 64;
+    const float4 *wp_bo = Wq + FA_POFF_BO / 4 + ocb * (64 / 8) * 64;
+    const float4 *wp_am = Wq + FA_POFF_AM / 4 + cbw * (128 / 8) * 64;
+    const float4 *wp_w7 = Wq + FA_POFF_W7 / 4 + cbw * (256 / 8) * 64;
+    const float4 *wp_w8p = Wq + FA_POFF_W8 / 4 + cbw * (128 / 8) * 64;
+    const float4 *wp_w8v = Wq + FA_POFF_W8 / 4 + (4 + cbw) * (128 / 8) * 64;
     BHead<64> hd_o;
-    prefetch_b<64>(wp_ao, lane, hd_o);
+    if (opp_on) prefetch_b<64>(wp_ao, lane, hd_o);
     // ---- encoders (mpnn.py:37-38): h1 = relu(x We + be) -> sH[:, 0:64] (own rows), ho -> sG[:, 0:64] (opp rows)
     {
         const int col = tid & 63, grp = tid >> 6;
-        float we[FA_OBS_DIM], wo[FA_OBS_DIM];
-#pragma unroll
-        for (int k = 0; k < FA_OBS_DIM; ++k) {
-            we[k] = W[FA_POFF_WE + k * 64 + col];
-            wo[k] = W[FA_POFF_WOE + k * 64 + col];
-        }
-        const float be = W[FA_POFF_BE + col], bo = W[FA_POFF_BOE + col];
-        for (int r = grp; r < PR; r += 4) {
+        for (int r = grp; r < PR; r += NW) {
             float vo = 0.0f, vp = 0.0f;
             if (r < ET * n) {
                 const int el = r / n, i = r - el * n;
@@ -136,103 +161,139 @@ __global__ __launch_bounds__(256, NRB == 2 ? 2 : 1) void fa_policy_kernel(FaPoli
         }
     }
     __syncthreads();
+    FA_PL_TICK(1)
 
     // ---- opponent attention (mpnn.py:372-443): g_o = h1 A_o -> sG[:, 64:128] --------------------------------
-    // 64 output columns = 2 column blocks: waves 0,1 take row blocks 0,1; waves 2,3 row block 2
-    {
-        const int cb = wave & 1;
-        if (NRB == 3 && wave < 2) {
-            f32x16 acc[2] = {};
-            gemm_cb<64, 2>(sH + li * LDA + hh * 32, wp_ao, acc, lane, hd_o);
-            prefetch_b<64>(wp_bo, lane, hd_o);
-            store_acc<false>(sG + 64 + cb * 32, 0, acc[0], 0.0f, lane);
-            store_acc<false>(sG + 64 + cb * 32, 1, acc[1], 0.0f, lane);
-        } else { // the last row block (NRB == 3), or row block wave >> 1 (NRB == 2: one block per wave pair)
-            const int rb = NRB == 3 ? 2 : (wave >> 1);
-            f32x16 acc[1] = {};
-            gemm_cb<64, 1>(sH + (rb * 32 + li) * LDA + hh * 32, wp_ao, acc, lane, hd_o);
-            prefetch_b<64>(wp_bo, lane, hd_o);
-            store_acc<false>(sG + 64 + cb * 32, rb, acc[0], 0.0f, lane);
-        }
+    if (opp_two) {
+        f32x16 acc[2] = {};
+        gemm_cb<64, 2>(sH + li * LDA + hh * 32, wp_ao, acc, lane, hd_o);
+        prefetch_b<64>(wp_bo, lane, hd_o);
+        store_acc<false>(sG + 64 + ocb * 32, 0, acc[0], 0.0f, lane);
+        store_acc<false>(sG + 64 + ocb * 32, 1, acc[1], 0.0f, lane);
+    } else if (opp_on) {
+        f32x16 acc[1] = {};
+        gemm_cb<64, 1>(sH + (orb * 32 + li) * LDA + hh * 32, wp_ao, acc, lane, hd_o);
+        prefetch_b<64>(wp_bo, lane, hd_o);
+        store_acc<false>(sG + 64 + ocb * 32, orb, acc[0], 0.0f, lane);
     }
     __syncthreads();
+    FA_PL_TICK(2)
     // scores against the env's opponents, softmax, mix of the opponents' encodings -> sG[r][64:128]
-    {
-        const int q = lane & 15;
-        for (int r = wave * 4 + (lane >> 4); r < PR; r += 16) {
-            const int el = r / n; // (rows beyond the tile's envs mix zeros: harmless, never stored)
-            if (r < ET * n) attend_row<64>(sG + r * LDA + 64, sG + (el * m) * LDA, m, -1, sG + r * LDA + 64, q);
+    // (a wave's rows are all computed before any is stored: the loads of one row overlap the DPP / exp chains of another)
+    constexpr int AIT = PR / (NW * 4); // attention rows per 16-lane sub-group
+    const int q16 = lane & 15, arow0 = wave * 4 + (lane >> 4), RU = ET * n;
+    const bool small_teams = (n > m ? n : m) <= 4, mid_teams = (n > m ? n : m) <= 6; // keys held in registers: 4, 6 or 8
+    auto opp_attention = [&](auto MTc) __attribute__((always_inline)) {
+        constexpr int MT = decltype(MTc)::value;
+        float ov[AIT][4];
+#pragma unroll
+        for (int k = 0; k < AIT; ++k) {
+            const int r = arow0 + k * NW * 4, rr = r < RU ? r : RU - 1;
+            attend_row_regs<64, MT>(sG + rr * LDA + 64, sG + ((rr / n) * m) * LDA, m, -1, q16, ov[k]);
         }
-    }
+#pragma unroll
+        for (int k = 0; k < AIT; ++k) {
+            const int r = arow0 + k * NW * 4;
+            if (r < RU) store_row_regs<64>(sG + r * LDA + 64, q16, ov[k]);
+        }
+    };
+    if (small_teams) opp_attention(std::integral_constant<int, 4>{});
+    else if (mid_teams) opp_attention(std::integral_constant<int, 6>{});
+    else opp_attention(std::integral_constant<int, FA_POLICY_MAX_TEAM>{});
     __syncthreads();
+    FA_PL_TICK(3)
     // e_opp = hmix_o B_o -> sH[:, 64:128]   (h = [h1 | e_opp], mpnn.py:143)
     BHead<128> hd_m;
-    {
-        const int cb = wave & 1;
-        if (NRB == 3 && wave < 2) {
-            f32x16 acc[2] = {};
-            gemm_cb<64, 2>(sG + li * LDA + 64 + hh * 32, wp_bo, acc, lane, hd_o);
-            prefetch_b<128>(wp_am, lane, hd_m);
-            store_acc<false>(sH + 64 + cb * 32, 0, acc[0], 0.0f, lane);
-            store_acc<false>(sH + 64 + cb * 32, 1, acc[1], 0.0f, lane);
-        } else {
-            const int rb = NRB == 3 ? 2 : (wave >> 1);
-            f32x16 acc[1] = {};
-            gemm_cb<64, 1>(sG + (rb * 32 + li) * LDA + 64 + hh * 32, wp_bo, acc, lane, hd_o);
-            prefetch_b<128>(wp_am, lane, hd_m);
-            store_acc<false>(sH + 64 + cb * 32, rb, acc[0], 0.0f, lane);
-        }
+    if (opp_two) {
+        f32x16 acc[2] = {};
+        gemm_cb<64, 2>(sG + li * LDA + 64 + hh * 32, wp_bo, acc, lane, hd_o);
+        prefetch_b<128>(wp_am, lane, hd_m);
+        store_acc<false>(sH + 64 + ocb * 32, 0, acc[0], 0.0f, lane);
+        store_acc<false>(sH + 64 + ocb * 32, 1, acc[1], 0.0f, lane);
+    } else if (opp_on) {
+        f32x16 acc[1] = {};
+        gemm_cb<64, 1>(sG + (orb * 32 + li) * LDA + 64 + hh * 32, wp_bo, acc, lane, hd_o);
+        prefetch_b<128>(wp_am, lane, hd_m);
+        store_acc<false>(sH + 64 + ocb * 32, orb, acc[0], 0.0f, lane);
+    } else {
+        prefetch_b<128>(wp_am, lane, hd_m);
     }
     __syncthreads();
 
     // ---- K = 3 rounds of message passing with shared weights (mpnn.py:155-157) ------------------------------
+    auto team_attention = [&](auto MTc) __attribute__((always_inline)) {
+        constexpr int MT = decltype(MTc)::value;
+        float ov[AIT][8];
+#pragma unroll
+        for (int k = 0; k < AIT; ++k) {
+            const int r = arow0 + k * NW * 4, rr = r < RU ? r : RU - 1, el = rr / n;
+            attend_row_regs<128, MT>(sG + rr * LDA, sH + (el * n) * LDA, n, rr - el * n, q16, ov[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < AIT; ++k) {
+            const int r = arow0 + k * NW * 4;
+            if (r < RU) store_row_regs<128>(sG + r * LDA, q16, ov[k]);
+        }
+    };
     BHead<256> hd_u;
     for (int round = 0; round < 3; ++round) {
-        {   // g = h A -> sG (wave = column block)
-            f32x16 acc[NRB] = {};
-            gemm_cb<128, NRB>(sH + li * LDA + hh * 64, wp_am, acc, lane, hd_m);
+        FA_PL_TICK(4 + round * 8)
+        FA_POLICY_SPLIT({   // g = h A -> sG
+            f32x16 acc[NR] = {};
+            gemm_cb<128, NR>(sH + (R0 * 32 + li) * LDA + hh * 64, wp_am, acc, lane, hd_m);
             prefetch_b<256>(wp_w7, lane, hd_u);
-#pragma unroll
-            for (int rb = 0; rb < NRB; ++rb) store_acc<false>(sG + wave * 32, rb, acc[rb], 0.0f, lane);
-        }
+FA_PL_TICK(5 + round * 8)
+_Pragma("unroll")
+            for (int rb = 0; rb < NR; ++rb) store_acc<false>(sG + cbw * 32, R0 + rb, acc[rb], 0.0f, lane);
+        })
+        FA_PL_TICK(6 + round * 8)
         __syncthreads();
-        {   // team attention, self excluded (mpnn.py:297-298): hmix -> sG rows
-            const int q = lane & 15;
-            for (int r = wave * 4 + (lane >> 4); r < PR; r += 16) {
-                const int el = r / n, i = r - el * n;
-                if (r < ET * n) attend_row<128>(sG + r * LDA, sH + (el * n) * LDA, n, i, sG + r * LDA, q);
-            }
-        }
+        FA_PL_TICK(7 + round * 8)
+        // team attention, self excluded (mpnn.py:297-298): hmix -> sG rows
+        if (small_teams) team_attention(std::integral_constant<int, 4>{});
+        else if (mid_teams) team_attention(std::integral_constant<int, 6>{});
+        else team_attention(std::integral_constant<int, FA_POLICY_MAX_TEAM>{});
+        FA_PL_TICK(8 + round * 8)
         __syncthreads();
-        {   // h' = relu([h | hmix] W7 + bu): lane half 0 walks h, half 1 walks hmix
-            f32x16 acc[NRB] = {};
-            gemm_cb<256, NRB>((hh ? sG : sH) + li * LDA, wp_w7, acc, lane, hd_u);
+        FA_PL_TICK(9 + round * 8)
+        FA_POLICY_SPLIT({   // h' = relu([h | hmix] W7 + bu): lane half 0 walks h, half 1 walks hmix
+            f32x16 acc[NR] = {};
+            gemm_cb<256, NR>((hh ? sG : sH) + (R0 * 32 + li) * LDA, wp_w7, acc, lane, hd_u);
             prefetch_b<128>(round < 2 ? wp_am : wp_w8p, lane, hd_m); // next: the following round's g, or the policy head
-            const float bias = W[FA_POFF_BU + wave * 32 + li];
+            const float bias = W[FA_POFF_BU + cbw * 32 + li];
+            FA_PL_TICK(10 + round * 8)
             __syncthreads(); // every wave has read the old h
-#pragma unroll
-            for (int rb = 0; rb < NRB; ++rb) store_acc<true>(sH + wave * 32, rb, acc[rb], bias, lane);
-        }
+            FA_PL_TICK(11 + round * 8)
+_Pragma("unroll")
+            for (int rb = 0; rb < NR; ++rb) store_acc<true>(sH + cbw * 32, R0 + rb, acc[rb], bias, lane);
+        })
         __syncthreads();
     }
 
     // ---- heads: [p | v] = relu(h [Wp0 | Wv0] + b) (mpnn.py:66-72), p -> sG, v -> sH ------------------------
-    {
-        f32x16 accp[NRB] = {}, accv[NRB] = {};
+    FA_PL_TICK(28)
+    // (p goes to sG straight after its GEMM: hmix is dead since the barrier behind the last W7 layer; only v -> sH
+    // has to wait until every wave has read h.  One accumulator set live at a time.)
+    FA_POLICY_SPLIT({
         BHead<128> hd_v;
         prefetch_b<128>(wp_w8v, lane, hd_v);
-        gemm_cb<128, NRB>(sH + li * LDA + hh * 64, wp_w8p, accp, lane, hd_m);
-        gemm_cb<128, NRB>(sH + li * LDA + hh * 64, wp_w8v, accv, lane, hd_v);
-        if (wave < NRB) prefetch_b<256>(Wq + FA_POFF_W9 / 4, lane, hd_u);
-        const float bp = W[FA_POFF_B8 + wave * 32 + li], bv = W[FA_POFF_B8 + 128 + wave * 32 + li];
-        __syncthreads(); // every wave has read h
-#pragma unroll
-        for (int rb = 0; rb < NRB; ++rb) {
-            store_acc<true>(sG + wave * 32, rb, accp[rb], bp, lane);
-            store_acc<true>(sH + wave * 32, rb, accv[rb], bv, lane);
+        {
+            f32x16 accp[NR] = {};
+            gemm_cb<128, NR>(sH + (R0 * 32 + li) * LDA + hh * 64, wp_w8p, accp, lane, hd_m);
+            const float bp = W[FA_POFF_B8 + cbw * 32 + li];
+_Pragma("unroll")
+            for (int rb = 0; rb < NR; ++rb) store_acc<true>(sG + cbw * 32, R0 + rb, accp[rb], bp, lane);
         }
-    }
+        f32x16 accv[NR] = {};
+        gemm_cb<128, NR>(sH + (R0 * 32 + li) * LDA + hh * 64, wp_w8v, accv, lane, hd_v);
+        if (wave < NRB) prefetch_b<256>(Wq + FA_POFF_W9 / 4, lane, hd_u);
+        const float bv = W[FA_POFF_B8 + 128 + cbw * 32 + li];
+        __syncthreads(); // every wave has read h
+_Pragma("unroll")
+        for (int rb = 0; rb < NR; ++rb) store_acc<true>(sH + cbw * 32, R0 + rb, accv[rb], bv, lane);
+    })
     __syncthreads();
+    FA_PL_TICK(29)
     // logits (8) | value (1) = [p | v] W9 + b9, W9 block diagonal in a 32-column block: wave = row block
     if (wave < NRB) {
         f32x16 acc[1] = {};
@@ -247,6 +308,7 @@ __global__ __launch_bounds__(256, NRB == 2 ? 2 : 1) void fa_policy_kernel(FaPoli
         }
     }
     __syncthreads();
+    FA_PL_TICK(30)
 
     // ---- value, log-softmax, sample, log-prob of the sample -> rollout rows ----------------------------------
     const int el_out = tid / n;
@@ -294,7 +356,9 @@ __global__ __launch_bounds__(256, NRB == 2 ? 2 : 1) void fa_policy_kernel(FaPoli
             a.logp[o] = la - lse;
         }
     }
+    FA_PL_TICK(31)
 }
+#undef FA_POLICY_SPLIT
 // Ensemble: sort the envs into tiles of equal strategy.  One workgroup: histogram, tile ranges per
 // strategy, scatter (the order inside a strategy's tiles is arbitrary -- every output is per env and the
 // sampling key holds the env index, so results do not depend on it).
@@ -347,7 +411,7 @@ hipError_t fa_launch_group_envs(const int32_t *env_strategy, int E, int pool_siz
 hipError_t fa_launch_policy(const FaPolicyArgs &a, hipStream_t st) {
     const int ET = fa_policy_tile_envs(a.E, a.G, a.A);
     const int tiles = a.env_list ? a.tiles : (a.E + ET - 1) / ET;
-    if (policy_rows(a.E, a.G, a.A) == 64) hipLaunchKernelGGL(fa_policy_kernel<2>, dim3(tiles, 2), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(fa_policy_kernel<3>, dim3(tiles, 2), dim3(256), 0, st, a);
+    if (policy_rows(a.E, a.G, a.A) == 64) hipLaunchKernelGGL((fa_policy_kernel<2, 4>), dim3(tiles, 2), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((fa_policy_kernel<3, FA_POLICY_WAVES>), dim3(tiles, 2), dim3(FA_POLICY_WAVES * 64), 0, st, a);
     return hipGetLastError();
 }

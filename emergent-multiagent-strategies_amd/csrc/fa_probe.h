@@ -16,4 +16,5 @@
 #define FA_PROBE_WAVE0_LOOP_END(lane)
 #define FA_PROBE_WAVE0_END(lane)
 #define FA_TR_TICK(k) // fa_train.hip phase marks
+#define FA_PL_TICK(k) // fa_policy.hip phase marks
 #endif

@@ -33,6 +33,13 @@
 
 namespace {
 constexpr int TR = FA_TR_ROWS;
+// Eight waves per workgroup, two per SIMD (still one workgroup per CU: the four 64-row buffers fill the LDS).  A wave
+// owns ONE 32 x 32 output tile of a 64 x 128 layer -- column block wave & 3, row block wave >> 2 -- so a SIMD's two
+// waves share a column block's weights and its MFMA work is what one wave did in round 2; but while one of them
+// stores accumulators, waits for an LDS / L2 read or sits at a barrier the other's MFMA chain runs, the row-wise phases
+// (attention forward / backward, relu masks, tile loads) have twice the waves to hide their latencies with, and the
+// weight-gradient accumulators that live across the three rounds are 96 registers per lane instead of 192.
+constexpr int NWV = 8, NTH = NWV * 64;
 constexpr int SOW = 32; // row stride of the head-output buffer sO (9 used: 8 logits + value)
 
 // acc (32 x 32) += X[rows][32 cols at X]^T * DY[rows][32 cols at DY] over the tile's 64 rows: both operands
@@ -162,15 +169,15 @@ __device__ __forceinline__ void attend_env_bwd(const float *dout0, float *g0, co
 }
 
 // GATHER: the minibatch is rows a.idx[.] of the rollout arrays (else rows 0..B)
-// SHARE: amdgpu_num_vgpr(232) = 464 of a SIMD's 512 registers per lane (the compiler takes 256 + 208 accumulation
-// registers).  The kernel would use all 512 -- and then NOTHING else fits on a CU it occupies: when the two teams'
-// updates run as concurrent chains, the other team's small launches (fold / unfold tasks at 48 registers, the
-// slab reduction, clip, Adam) waited for whole tiles to retire (fa_task_kernel 134 us in flight instead of 11).
-// 48 registers per lane left free cost this kernel 2-3 % and bring the update from 0.276 to 0.260 s (a sweep:
-// 240 -> 0.284, 232 -> 0.260, 224 -> 0.263, 216 -> 0.261, 208 -> 0.270, 192 -> 0.279); a lone chain
-// (guards-only training, FaTrainArgs::share_cu = 0) runs the uncapped build.
+// SHARE: amdgpu_num_vgpr(116) = 232 of the 256 registers a wave may have with two waves per SIMD (the cap counts
+// architectural and accumulation registers separately), i.e. 464 of a SIMD's 512 per lane.  Uncapped the kernel takes
+// all 512 -- and then NOTHING else fits on a CU it occupies: when the two teams' updates run as concurrent chains, the
+// other team's small launches (fold / unfold tasks at 48 registers, the slab reduction, clip, Adam) wait for whole
+// tiles to retire (round 2, four waves: fa_task_kernel 134 us in flight instead of 11; cap 232 of 256 per SIMD-half:
+// update 0.276 -> 0.260 s).  Eight waves: uncapped 0.268 s per update, capped 0.253 s; a lone chain (guards-only
+// training, FaTrainArgs::share_cu = 0) runs the uncapped build.
 #ifndef FA_TRAIN_NUM_VGPR
-#define FA_TRAIN_NUM_VGPR 232
+#define FA_TRAIN_NUM_VGPR 116
 #endif
 template <bool GATHER>
 __device__ __forceinline__ void fa_train_body(const FaTrainArgs &a) {
@@ -184,6 +191,7 @@ __device__ __forceinline__ void fa_train_body(const FaTrainArgs &a) {
     // tools/isa_lint.py for why this kernel wants as few exec-masked joins as possible)
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, hh = lane >> 5, q16 = lane & 15;
+    const int cbw = wave & 3, rbw = wave >> 2; // this wave's column / row block of a 64 x 128 layer
     const int N = a.G + a.A;
     const int n = a.team == 0 ? a.G : a.A, m = N - n;
     const int own0 = a.team == 0 ? 0 : a.G, opp0 = a.team == 0 ? a.G : 0;
@@ -198,13 +206,13 @@ __device__ __forceinline__ void fa_train_body(const FaTrainArgs &a) {
     float *hsave = a.hsave + (size_t)blockIdx.x * FA_TR_SAVE_FLOATS;
 
     auto save_tile = [&](const float *src, float *dst) { // 64 x 128 LDS -> global
-        for (int k = tid; k < TR * 32; k += 256) {
+        for (int k = tid; k < TR * 32; k += NTH) {
             const int r = k >> 5, c4 = k & 31;
             reinterpret_cast<float4 *>(dst)[k] = *reinterpret_cast<const float4 *>(src + r * LDA + c4 * 4);
         }
     };
     auto load_tile = [&](float *dst, const float *src) {
-        for (int k = tid; k < TR * 32; k += 256) {
+        for (int k = tid; k < TR * 32; k += NTH) {
             const int r = k >> 5, c4 = k & 31;
             *reinterpret_cast<float4 *>(dst + r * LDA + c4 * 4) = reinterpret_cast<const float4 *>(src)[k];
         }
@@ -216,7 +224,7 @@ __device__ __forceinline__ void fa_train_body(const FaTrainArgs &a) {
 #pragma unroll
         for (int k = 0; k < FA_OBS_DIM; ++k) { we[k] = W[FA_POFF_WE + k * 64 + col]; wo[k] = W[FA_POFF_WOE + k * 64 + col]; }
         const float be = W[FA_POFF_BE + col], bo = W[FA_POFF_BOE + col];
-        for (int r = grp; r < TR; r += 4) {
+        for (int r = grp; r < TR; r += NWV) {
             if (dst_own) {
                 float v = 0.0f;
                 if (r < RU) {
@@ -243,6 +251,7 @@ __device__ __forceinline__ void fa_train_body(const FaTrainArgs &a) {
     };
     // g_o = h1 A_o -> B1[:, 64:128]  (64 output columns: column block wave & 1, row block wave >> 1)
     auto project_opp = [&]() {
+        if (wave >= 4) return;
         BHead<64> hd;
         const float4 *wp = Wq + FA_POFF_AO / 4 + (wave & 1) * 8 * 64;
         prefetch_b<64>(wp, lane, hd);
@@ -251,25 +260,24 @@ __device__ __forceinline__ void fa_train_body(const FaTrainArgs &a) {
         store_acc<false>(B1 + 64 + (wave & 1) * 32, wave >> 1, acc[0], 0.0f, lane);
     };
     // g = h A_m: B0 -> dst (all 128 columns; wave = column block); `hd`: the first weights, requested earlier
-    const float4 *wp_am = Wq + FA_POFF_AM / 4 + wave * 16 * 64;
+    const float4 *wp_am = Wq + FA_POFF_AM / 4 + cbw * 16 * 64;
     auto project_team = [&](float *dst, const BHead<128> &hd) {
         const float4 *wp = wp_am;
-        f32x16 acc[2] = {};
-        gemm_cb<128, 2>(B0 + li * LDA + hh * 64, wp, acc, lane, hd);
-        store_acc<false>(dst + wave * 32, 0, acc[0], 0.0f, lane);
-        store_acc<false>(dst + wave * 32, 1, acc[1], 0.0f, lane);
+        f32x16 acc[1] = {};
+        gemm_cb<128, 1>(B0 + (rbw * 32 + li) * LDA + hh * 64, wp, acc, lane, hd);
+        store_acc<false>(dst + cbw * 32, rbw, acc[0], 0.0f, lane);
     };
 
     FA_TR_TICK(0)
     // ================================ forward ==========================================================
     if (GATHER) {
         const int ow = N * FA_OBS_DIM;
-        for (int k = tid; k < ET * ow; k += 256) {
+        for (int k = tid; k < ET * ow; k += NTH) {
             const int el = k / ow;
             sX[k] = el < ne ? a.obs[(size_t)a.idx[e0 + el] * ow + (k - el * ow)] : 0.0f;
         }
     } else {
-        for (int k = tid; k < ET * N * FA_OBS_DIM; k += 256)
+        for (int k = tid; k < ET * N * FA_OBS_DIM; k += NTH)
             sX[k] = k < ne * N * FA_OBS_DIM ? a.obs[(size_t)e0 * N * FA_OBS_DIM + k] : 0.0f;
     }
     __syncthreads();
@@ -277,10 +285,10 @@ __device__ __forceinline__ void fa_train_body(const FaTrainArgs &a) {
     __syncthreads();
     project_opp();
     __syncthreads();
-    for (int r = wave * 4 + (lane >> 4); r < TR; r += 16) // opponent attention (mpnn.py:372-443)
+    for (int r = wave * 4 + (lane >> 4); r < TR; r += NWV * 4) // opponent attention (mpnn.py:372-443)
         if (r < RU) attend_row<64>(B1 + r * LDA + 64, B2 + ((r / n) * m) * LDA, m, -1, B1 + r * LDA + 64, q16, sAttn[0] + r * 8);
     __syncthreads();
-    {   // e_opp = mix_o B_o -> B0[:, 64:128]
+    if (wave < 4) {   // e_opp = mix_o B_o -> B0[:, 64:128]
         BHead<64> hd;
         const float4 *wp = Wq + FA_POFF_BO / 4 + (wave & 1) * 8 * 64;
         prefetch_b<64>(wp, lane, hd);
@@ -293,28 +301,34 @@ __device__ __forceinline__ void fa_train_body(const FaTrainArgs &a) {
     prefetch_b<128>(wp_am, lane, hd_am);
     __syncthreads();
     save_tile(B0, hsave);
-    const float4 *wpp = Wq + FA_POFF_W8 / 4 + wave * 16 * 64, *wpv = Wq + FA_POFF_W8 / 4 + (4 + wave) * 16 * 64;
+    const float4 *wpp = Wq + FA_POFF_W8 / 4 + cbw * 16 * 64, *wpv = Wq + FA_POFF_W8 / 4 + (4 + cbw) * 16 * 64;
     for (int round = 0; round < 3; ++round) {
+        FA_TR_TICK(33 + round * 7)
         project_team(B1, hd_am);
+        FA_TR_TICK(34 + round * 7)
         BHead<256> hd_u;
-        const float4 *wp_u = Wq + FA_POFF_W7 / 4 + wave * 32 * 64;
+        const float4 *wp_u = Wq + FA_POFF_W7 / 4 + cbw * 32 * 64;
         prefetch_b<256>(wp_u, lane, hd_u);
         __syncthreads();
-        for (int r = wave * 4 + (lane >> 4); r < TR; r += 16) { // team attention, self excluded (mpnn.py:250-332)
+        FA_TR_TICK(35 + round * 7)
+        for (int r = wave * 4 + (lane >> 4); r < TR; r += NWV * 4) { // team attention, self excluded (mpnn.py:250-332)
             const int el = r / n;
             if (r < RU) attend_row<128>(B1 + r * LDA, B0 + (el * n) * LDA, n, r - el * n, B1 + r * LDA, q16, sAttn[1 + round] + r * 8);
         }
+        FA_TR_TICK(36 + round * 7)
         __syncthreads();
+        FA_TR_TICK(37 + round * 7)
         {   // h' = relu([h | hmix] W7 + bu)
-            f32x16 acc[2] = {};
-            gemm_cb<256, 2>((hh ? B1 : B0) + li * LDA, wp_u, acc, lane, hd_u);
+            f32x16 acc[1] = {};
+            gemm_cb<256, 1>((hh ? B1 : B0) + (rbw * 32 + li) * LDA, wp_u, acc, lane, hd_u);
             prefetch_b<128>(round < 2 ? wp_am : wpp, lane, hd_am); // next: the following round's g, or the policy head
-            const float bias = W[FA_POFF_BU + wave * 32 + li];
+            const float bias = W[FA_POFF_BU + cbw * 32 + li];
+            FA_TR_TICK(38 + round * 7)
             __syncthreads();
-            store_acc<true>(B0 + wave * 32, 0, acc[0], bias, lane);
-            store_acc<true>(B0 + wave * 32, 1, acc[1], bias, lane);
+            store_acc<true>(B0 + cbw * 32, rbw, acc[0], bias, lane);
         }
         __syncthreads();
+        FA_TR_TICK(39 + round * 7)
         if (round < 2) save_tile(B0, hsave + (round + 1) * TR * 128);
     }
     FA_TR_TICK(2)
@@ -322,15 +336,12 @@ __device__ __forceinline__ void fa_train_body(const FaTrainArgs &a) {
         BHead<128> hv;
         const BHead<128> &hp = hd_am;
         prefetch_b<128>(wpv, lane, hv);
-        f32x16 accp[2] = {}, accv[2] = {};
-        gemm_cb<128, 2>(B0 + li * LDA + hh * 64, wpp, accp, lane, hp);
-        gemm_cb<128, 2>(B0 + li * LDA + hh * 64, wpv, accv, lane, hv);
-        const float bp = W[FA_POFF_B8 + wave * 32 + li], bv = W[FA_POFF_B8 + 128 + wave * 32 + li];
-#pragma unroll
-        for (int rb = 0; rb < 2; ++rb) {
-            store_acc<true>(B1 + wave * 32, rb, accp[rb], bp, lane);
-            store_acc<true>(B2 + wave * 32, rb, accv[rb], bv, lane);
-        }
+        f32x16 accp[1] = {}, accv[1] = {};
+        gemm_cb<128, 1>(B0 + (rbw * 32 + li) * LDA + hh * 64, wpp, accp, lane, hp);
+        gemm_cb<128, 1>(B0 + (rbw * 32 + li) * LDA + hh * 64, wpv, accv, lane, hv);
+        const float bp = W[FA_POFF_B8 + cbw * 32 + li], bv = W[FA_POFF_B8 + 128 + cbw * 32 + li];
+        store_acc<true>(B1 + cbw * 32, rbw, accp[0], bp, lane);
+        store_acc<true>(B2 + cbw * 32, rbw, accv[0], bv, lane);
     }
     __syncthreads();
     if (wave < 2) { // [logits | value] = [P | V] W9 + b9 -> sO (row block = wave)
@@ -428,9 +439,8 @@ __device__ __forceinline__ void fa_train_body(const FaTrainArgs &a) {
     // ================================ backward =========================================================
     // ---- heads --------------------------------------------------------------------------------------
     {   // dW9 = [P | V]^T dOUT (256 x 32): 8 k-blocks, two per wave;  db9 = column sums of dOUT
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const int kb = wave * 2 + t;
+        {
+            const int kb = wave;
             f32x16 acc = {};
             gemm_tn((kb < 4 ? B1 : B2) + (kb & 3) * 32, LDA, sO, SOW, acc, lane);
             store_tile_global(slab + FA_POFF_W9 + kb * 32 * 32, 32, acc, lane);
@@ -443,15 +453,15 @@ __device__ __forceinline__ void fa_train_body(const FaTrainArgs &a) {
     }
     {   // d[P | V] = dOUT W9^T (K = 32 -> 256 columns: blocks wave, wave + 4), through the relus in place
         BHead<32> h0, h1;
-        const float4 *wp0 = Tq + FA_TOFF_W9T / 4 + wave * 4 * 64, *wp1 = Tq + FA_TOFF_W9T / 4 + (4 + wave) * 4 * 64;
+        const float4 *wp0 = Tq + FA_TOFF_W9T / 4 + cbw * 4 * 64, *wp1 = Tq + FA_TOFF_W9T / 4 + (4 + cbw) * 4 * 64;
         prefetch_b<32>(wp0, lane, h0);
         prefetch_b<32>(wp1, lane, h1);
-        f32x16 ap[2] = {}, av[2] = {};
-#pragma unroll
-        for (int rb = 0; rb < 2; ++rb) { // A = sO (row stride SOW): one 16-byte read per four MFMAs
+        f32x16 ap[1] = {}, av[1] = {};
+        {   // A = sO (row stride SOW): one 16-byte read per four MFMAs
+            constexpr int rb = 0;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                const float4 x = *reinterpret_cast<const float4 *>(sO + (rb * 32 + li) * SOW + hh * 16 + c * 4);
+                const float4 x = *reinterpret_cast<const float4 *>(sO + (rbw * 32 + li) * SOW + hh * 16 + c * 4);
                 ap[rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(x.x, h0.v[c].x, ap[rb], 0, 0, 0);
                 ap[rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(x.y, h0.v[c].y, ap[rb], 0, 0, 0);
                 ap[rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(x.z, h0.v[c].z, ap[rb], 0, 0, 0);
@@ -463,17 +473,13 @@ __device__ __forceinline__ void fa_train_body(const FaTrainArgs &a) {
             }
         }
         __syncthreads(); // dW9 has read P and V
-#pragma unroll
-        for (int rb = 0; rb < 2; ++rb) {
-            store_acc_relu_mask(B1 + wave * 32, rb, ap[rb], lane);
-            store_acc_relu_mask(B2 + wave * 32, rb, av[rb], lane);
-        }
+        store_acc_relu_mask(B1 + cbw * 32, rbw, ap[0], lane);
+        store_acc_relu_mask(B2 + cbw * 32, rbw, av[0], lane);
     }
     __syncthreads();
     {   // dW8 = h3^T [dP | dV] (128 x 256): 32 tiles, eight per wave (column block cb, k-blocks 0..3);  db8
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const int cb = wave * 2 + t;
+        {
+            const int cb = wave;
 #pragma unroll
             for (int kb = 0; kb < 4; ++kb) {
                 f32x16 acc = {};
@@ -481,7 +487,7 @@ __device__ __forceinline__ void fa_train_body(const FaTrainArgs &a) {
                 store_tile_global(slab + FA_POFF_W8 + kb * 32 * 256 + cb * 32, 256, acc, lane);
             }
         }
-        {
+        if (wave < 4) {
             const float *src = (wave < 2 ? B1 : B2) + (tid & 127);
             float sum = 0.0f;
             for (int r = 0; r < TR; ++r) sum += src[r * LDA];
@@ -490,30 +496,30 @@ __device__ __forceinline__ void fa_train_body(const FaTrainArgs &a) {
     }
     {   // dh3 = [dP | dV] W8^T (K = 256: half 0 walks dP, half 1 dV) -> B3
         BHead<256> hd;
-        const float4 *wp = Tq + FA_TOFF_W8T / 4 + wave * 32 * 64;
+        const float4 *wp = Tq + FA_TOFF_W8T / 4 + cbw * 32 * 64;
         prefetch_b<256>(wp, lane, hd);
-        f32x16 acc[2] = {};
-        gemm_cb<256, 2>((hh ? B2 : B1) + li * LDA, wp, acc, lane, hd);
-        store_acc<false>(B3 + wave * 32, 0, acc[0], 0.0f, lane);
-        store_acc<false>(B3 + wave * 32, 1, acc[1], 0.0f, lane);
+        f32x16 acc[1] = {};
+        gemm_cb<256, 1>((hh ? B2 : B1) + (rbw * 32 + li) * LDA, wp, acc, lane, hd);
+        store_acc<false>(B3 + cbw * 32, rbw, acc[0], 0.0f, lane);
     }
     __syncthreads();
 
     FA_TR_TICK(5)
     // ---- the three rounds, last first: B0 = the round's output h, B3 = dL/d(output) ---------------------
-    // dW7 (256 x 128: column block = wave, 8 k-blocks) and dA_m (128 x 128: 4 k-blocks) accumulate in registers
-    // across the three rounds (a read-modify-write of the slab per round instead cost 60-110 k cycles per round:
-    // its loads serialise in front of every tile's MFMA chain)
-    f32x16 acc_w7[8], acc_am[4];
+    // dW7 (256 x 128: this wave's column block, k-blocks 4 * rbw .. + 3 -- the h_in half for the waves of row block 0,
+    // the hmix half for the others) and dA_m (128 x 128: k-blocks 2 * rbw, + 1) accumulate in registers across the
+    // three rounds (a read-modify-write of the slab per round instead cost 60-110 k cycles per round: its loads
+    // serialise in front of every tile's MFMA chain)
+    f32x16 acc_w7[4], acc_am[2];
 #pragma unroll
-    for (int t = 0; t < 8; ++t) acc_w7[t] = f32x16{};
+    for (int t = 0; t < 4; ++t) acc_w7[t] = f32x16{};
 #pragma unroll
-    for (int t = 0; t < 4; ++t) acc_am[t] = f32x16{};
+    for (int t = 0; t < 2; ++t) acc_am[t] = f32x16{};
     float dbu = 0.0f; // threads 0..127: their column of the update bias gradient
     for (int round = 2; round >= 0; --round) {
         FA_TR_TICK(6 + (2 - round) * 8)
         // dZ = dL/dh_out through the relu (in place in B3); the bias gradient
-        for (int k = tid; k < TR * 128; k += 256) {
+        for (int k = tid; k < TR * 128; k += NTH) {
             const int r = k >> 7, c = k & 127;
             if (!(B0[r * LDA + c] > 0.0f)) B3[r * LDA + c] = 0.0f;
         }
@@ -530,7 +536,7 @@ __device__ __forceinline__ void fa_train_body(const FaTrainArgs &a) {
         load_tile(B0, hsave + round * TR * 128);
         __syncthreads();
         project_team(B2, hd_g);
-        for (int r = wave * 4 + (lane >> 4); r < TR; r += 16) {
+        for (int r = wave * 4 + (lane >> 4); r < TR; r += NWV * 4) {
             if (r < RU) mix_row<128>(sAttn[1 + round] + r * 8, B0 + ((r / n) * n) * LDA, n, B1 + r * LDA, q16);
             else {
                 *reinterpret_cast<float4 *>(B1 + r * LDA + q16 * 8) = float4{0, 0, 0, 0};
@@ -541,22 +547,19 @@ __device__ __forceinline__ void fa_train_body(const FaTrainArgs &a) {
         FA_TR_TICK(8 + (2 - round) * 8)
         // dW7 += [h_in | hmix]^T dZ  (the transposed weights of the next GEMM are requested first)
         BHead<128> ha, hm;
-        const float4 *wpa = Tq + FA_TOFF_W7T / 4 + wave * 16 * 64, *wpm = Tq + FA_TOFF_W7T / 4 + (4 + wave) * 16 * 64;
+        const float4 *wpa = Tq + FA_TOFF_W7T / 4 + cbw * 16 * 64, *wpm = Tq + FA_TOFF_W7T / 4 + (4 + cbw) * 16 * 64;
         prefetch_b<128>(wpa, lane, ha);
         prefetch_b<128>(wpm, lane, hm);
 #pragma unroll
-        for (int kb = 0; kb < 8; ++kb) gemm_tn((kb < 4 ? B0 : B1) + (kb & 3) * 32, LDA, B3 + wave * 32, LDA, acc_w7[kb], lane);
+        for (int t = 0; t < 4; ++t) gemm_tn((rbw ? B1 : B0) + t * 32, LDA, B3 + cbw * 32, LDA, acc_w7[t], lane);
         FA_TR_TICK(9 + (2 - round) * 8)
         {   // [dh_a | dhmix] = dZ W7^T (K = 128 -> 256 columns)
-            f32x16 aa[2] = {}, am[2] = {};
-            gemm_cb<128, 2>(B3 + li * LDA + hh * 64, wpa, aa, lane, ha);
-            gemm_cb<128, 2>(B3 + li * LDA + hh * 64, wpm, am, lane, hm);
+            f32x16 aa[1] = {}, am[1] = {};
+            gemm_cb<128, 1>(B3 + (rbw * 32 + li) * LDA + hh * 64, wpa, aa, lane, ha);
+            gemm_cb<128, 1>(B3 + (rbw * 32 + li) * LDA + hh * 64, wpm, am, lane, hm);
             __syncthreads(); // every wave has read dZ (and hmix, for dW7)
-#pragma unroll
-            for (int rb = 0; rb < 2; ++rb) {
-                store_acc<false>(B3 + wave * 32, rb, aa[rb], 0.0f, lane);
-                store_acc<false>(B1 + wave * 32, rb, am[rb], 0.0f, lane);
-            }
+            store_acc<false>(B3 + cbw * 32, rbw, aa[0], 0.0f, lane);
+            store_acc<false>(B1 + cbw * 32, rbw, am[0], 0.0f, lane);
         }
         __syncthreads();
         FA_TR_TICK(10 + (2 - round) * 8)
@@ -564,7 +567,7 @@ __device__ __forceinline__ void fa_train_body(const FaTrainArgs &a) {
         // beyond the tile's envs hold a recomputed g of padding rows: their dg is zero
         if (wave == 0 && lane < 32)
             for (int r = RU; r < TR; ++r) *reinterpret_cast<float4 *>(B2 + r * LDA + tid * 4) = float4{0, 0, 0, 0};
-        for (int el = wave * 4 + (lane >> 4); el < ET; el += 16) {
+        for (int el = wave * 4 + (lane >> 4); el < ET; el += NWV * 4) {
             // (teams of up to 4: half the key / key-gradient registers)
             if (n <= 4) attend_env_bwd<128, true, 4>(B1 + (el * n) * LDA, B2 + (el * n) * LDA, B0 + (el * n) * LDA, B3 + (el * n) * LDA,
                                                      sAttn[1 + round] + (el * n) * 8, n, n, q16);
@@ -575,22 +578,21 @@ __device__ __forceinline__ void fa_train_body(const FaTrainArgs &a) {
         FA_TR_TICK(11 + (2 - round) * 8)
         // dA_m += h_in^T dg ;  dh += dg A_m^T
         BHead<128> hd;
-        const float4 *wp = Tq + FA_TOFF_AMT / 4 + wave * 16 * 64;
+        const float4 *wp = Tq + FA_TOFF_AMT / 4 + cbw * 16 * 64;
         prefetch_b<128>(wp, lane, hd);
 #pragma unroll
-        for (int kb = 0; kb < 4; ++kb) gemm_tn(B0 + kb * 32, LDA, B2 + wave * 32, LDA, acc_am[kb], lane);
+        for (int t = 0; t < 2; ++t) gemm_tn(B0 + (2 * rbw + t) * 32, LDA, B2 + cbw * 32, LDA, acc_am[t], lane);
         {
-            f32x16 acc[2] = {};
-            gemm_cb<128, 2>(B2 + li * LDA + hh * 64, wp, acc, lane, hd);
-            store_acc_add(B3 + wave * 32, 0, acc[0], lane);
-            store_acc_add(B3 + wave * 32, 1, acc[1], lane);
+            f32x16 acc[1] = {};
+            gemm_cb<128, 1>(B2 + (rbw * 32 + li) * LDA + hh * 64, wp, acc, lane, hd);
+            store_acc_add(B3 + cbw * 32, rbw, acc[0], lane);
         }
         __syncthreads();
     }
 #pragma unroll
-    for (int kb = 0; kb < 8; ++kb) store_tile_global(slab + FA_POFF_W7 + kb * 32 * 128 + wave * 32, 128, acc_w7[kb], lane);
+    for (int t = 0; t < 4; ++t) store_tile_global(slab + FA_POFF_W7 + (4 * rbw + t) * 32 * 128 + cbw * 32, 128, acc_w7[t], lane);
 #pragma unroll
-    for (int kb = 0; kb < 4; ++kb) store_tile_global(slab + FA_POFF_AM + kb * 32 * 128 + wave * 32, 128, acc_am[kb], lane);
+    for (int t = 0; t < 2; ++t) store_tile_global(slab + FA_POFF_AM + (2 * rbw + t) * 32 * 128 + cbw * 32, 128, acc_am[t], lane);
     if (wave < 2) slab[FA_POFF_BU + tid] = dbu;
 
     FA_TR_TICK(30)
@@ -598,17 +600,17 @@ __device__ __forceinline__ void fa_train_body(const FaTrainArgs &a) {
     encoders(nullptr, B2); // ho -> B2[:, 0:64] (opponent rows), recomputed
     __syncthreads();
     project_opp();         // g_o -> B1[:, 64:128], recomputed
-    for (int r = wave * 4 + (lane >> 4); r < TR; r += 16) { // mix_o -> B1[:, 0:64], from the saved weights
+    for (int r = wave * 4 + (lane >> 4); r < TR; r += NWV * 4) { // mix_o -> B1[:, 0:64], from the saved weights
         if (r < RU) mix_row<64>(sAttn[0] + r * 8, B2 + ((r / n) * m) * LDA, m, B1 + r * LDA, q16);
         else *reinterpret_cast<float4 *>(B1 + r * LDA + q16 * 4) = float4{0, 0, 0, 0};
     }
     __syncthreads();
-    {   // dB_o = mix_o^T de_opp (64 x 64: one tile per wave)
+    if (wave < 4) {   // dB_o = mix_o^T de_opp (64 x 64: one tile per wave 0..3)
         f32x16 acc = {};
         gemm_tn(B1 + (wave >> 1) * 32, LDA, B3 + 64 + (wave & 1) * 32, LDA, acc, lane);
         store_tile_global(slab + FA_POFF_BO + (wave >> 1) * 32 * 64 + (wave & 1) * 32, 64, acc, lane);
     }
-    {   // dmix_o = de_opp B_o^T -> B2[:, 64:128]
+    if (wave < 4) {   // dmix_o = de_opp B_o^T -> B2[:, 64:128]
         BHead<64> hd;
         const float4 *wp = Tq + FA_TOFF_BOT / 4 + (wave & 1) * 8 * 64;
         prefetch_b<64>(wp, lane, hd);
@@ -618,11 +620,11 @@ __device__ __forceinline__ void fa_train_body(const FaTrainArgs &a) {
     }
     __syncthreads();
     // opponent attention backward per env: dmix_o (B2[:, 64:]), g_o (B1[:, 64:]) -> dg_o in place; dho -> B1[:, 0:64]
-    for (int el = wave * 4 + (lane >> 4); el < ET; el += 16)
+    for (int el = wave * 4 + (lane >> 4); el < ET; el += NWV * 4)
         attend_env_bwd<64, false, FA_POLICY_MAX_TEAM>(B2 + (el * n) * LDA + 64, B1 + (el * n) * LDA + 64, B2 + (el * m) * LDA, B1 + (el * m) * LDA,
                                   sAttn[0] + (el * n) * 8, n, m, q16);
     __syncthreads();
-    {   // dA_o = h1^T dg_o ;  dh1 += dg_o A_o^T
+    if (wave < 4) {   // dA_o = h1^T dg_o ;  dh1 += dg_o A_o^T
         f32x16 acc = {};
         gemm_tn(B0 + (wave >> 1) * 32, LDA, B1 + 64 + (wave & 1) * 32, LDA, acc, lane);
         store_tile_global(slab + FA_POFF_AO + (wave >> 1) * 32 * 64 + (wave & 1) * 32, 64, acc, lane);
@@ -637,12 +639,12 @@ __device__ __forceinline__ void fa_train_body(const FaTrainArgs &a) {
     FA_TR_TICK(31)
     // ---- encoders: through the relus, then [dW ; db] = [x | 1]^T dpre as one 32 x 32 MFMA tile per 32 columns ----
     // (own side: waves 0, 1; opponent side: waves 2, 3).  [x | 1 | 0...] rows go to sO / sO2.
-    for (int k = tid; k < 2 * TR * 64; k += 256) {
+    for (int k = tid; k < 2 * TR * 64; k += NTH) {
         const int side = k / (TR * 64), kk = k - side * TR * 64, r = kk >> 6, c = kk & 63;
         if (side == 0) { if (!(B0[r * LDA + c] > 0.0f)) B3[r * LDA + c] = 0.0f; }
         else if (!(B2[r * LDA + c] > 0.0f)) B1[r * LDA + c] = 0.0f;
     }
-    for (int k = tid; k < 2 * TR * SOW; k += 256) {
+    for (int k = tid; k < 2 * TR * SOW; k += NTH) {
         const int side = k / (TR * SOW), kk = k - side * TR * SOW, r = kk / SOW, c = kk - r * SOW;
         const int per = side == 0 ? n : m, first = side == 0 ? own0 : opp0, used = side == 0 ? RU : RO;
         float v = 0.0f;
@@ -653,7 +655,7 @@ __device__ __forceinline__ void fa_train_body(const FaTrainArgs &a) {
         (side == 0 ? sO : sO2)[kk] = v;
     }
     __syncthreads();
-    {
+    if (wave < 4) {
         const int side = wave >> 1, cb = wave & 1;
         f32x16 acc = {};
         gemm_tn(side == 0 ? sO : sO2, SOW, (side == 0 ? B3 : B1) + cb * 32, LDA, acc, lane);
@@ -669,9 +671,9 @@ __device__ __forceinline__ void fa_train_body(const FaTrainArgs &a) {
 }
 
 template <bool GATHER>
-__global__ __launch_bounds__(256, 1) void fa_train_kernel(FaTrainArgs a) { fa_train_body<GATHER>(a); }
+__global__ __launch_bounds__(NTH, 1) void fa_train_kernel(FaTrainArgs a) { fa_train_body<GATHER>(a); }
 // (the attribute takes a literal, not a template argument: hence a second kernel and not a third parameter)
-__global__ __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(FA_TRAIN_NUM_VGPR))) void fa_train_share_kernel(FaTrainArgs a) {
+__global__ __launch_bounds__(NTH, 1) __attribute__((amdgpu_num_vgpr(FA_TRAIN_NUM_VGPR))) void fa_train_share_kernel(FaTrainArgs a) {
     fa_train_body<true>(a);
 }
 
@@ -759,7 +761,7 @@ int fa_train_tile_envs(int G, int A) { return TR / (G > A ? G : A); }
 
 hipError_t fa_launch_train(const FaTrainArgs &a, hipStream_t st) {
     const int ET = fa_train_tile_envs(a.G, a.A);
-    const dim3 grid((a.B + ET - 1) / ET), block(256);
+    const dim3 grid((a.B + ET - 1) / ET), block(NTH);
     if (a.idx && a.share_cu) hipLaunchKernelGGL(fa_train_share_kernel, grid, block, 0, st, a);
     else if (a.idx) hipLaunchKernelGGL(fa_train_kernel<true>, grid, block, 0, st, a);
     else hipLaunchKernelGGL(fa_train_kernel<false>, grid, block, 0, st, a);

@@ -2,7 +2,12 @@
 // built by tools/make_timing_build.py, read by tools/timing_probe.py).  Sections accumulate
 // shader-clock ticks per wave role into g_dbg; g_hw records where the hardware placed each wave.
 #pragma once
-#ifndef FA_PROBE_TRAIN_TU // ---- the step kernels' translation unit (fa_step.hip)
+#if defined(FA_PROBE_POLICY_TU) // ---- fa_policy.hip: wave 0 (and wave 4) of one workgroup record the shader clock at phase marks
+__device__ unsigned long long g_pl[128];
+#define FA_PL_TICK(k) if ((threadIdx.x & 255) == 0 && blockIdx.x == 100 && blockIdx.y == 0) g_pl[(k) + (threadIdx.x >> 8) * 64] = clock64();
+extern "C" int fa_dbg_policy(unsigned long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pl), sizeof(unsigned long long) * 128); }
+#define FA_TR_TICK(k)
+#elif !defined(FA_PROBE_TRAIN_TU) // ---- the step kernels' translation unit (fa_step.hip)
 #ifndef FA_TICK_WAVE1
 #define FA_TICK_WAVE1 0 // 1: report pair wave 1 instead of the last pair wave
 #endif
@@ -27,7 +32,9 @@ extern "C" int fa_dbg_read(unsigned long long *out, int reset) {
 extern "C" int fa_dbg_hw(unsigned *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_hw), sizeof(unsigned) * 4096); }
 
 #define FA_TR_TICK(k)
+#define FA_PL_TICK(k)
 #else // ---- fa_train.hip
+#define FA_PL_TICK(k)
 // fa_train.hip: workgroup 0 / thread 0 records the shader clock at phase marks
 __device__ unsigned long long g_tr[64];
 #define FA_TR_TICK(k) if (threadIdx.x == 0 && blockIdx.x == 7) g_tr[k] = clock64();

@@ -18,6 +18,8 @@ __device__ unsigned long long g_trace[2][FA_TRACE_STEPS][24];
 #define FA_PROBE_WAVE0_END(lane)
 extern "C" int fa_dbg_trace(unsigned long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_trace), sizeof(g_trace)); }
 #define FA_TR_TICK(k)
+#define FA_PL_TICK(k)
 #else
 #define FA_TR_TICK(k)
+#define FA_PL_TICK(k)
 #endif

@@ -38,7 +38,13 @@ for r in range(3):
     names.update({base: "  round %d: (prev tail)" % (2 - r), base + 1: "  round %d: relu mask + bias grad" % (2 - r),
                   base + 2: "  round %d: load h, recompute g, hmix" % (2 - r), base + 3: "  round %d: dW7" % (2 - r),
                   base + 4: "  round %d: dZ W7^T" % (2 - r), base + 5: "  round %d: attention backward" % (2 - r)})
-keys = [k for k in sorted(names) if buf[k]]
+for r in range(3):
+    base = 33 + r * 7
+    names.update({base: "  fwd round %d: (prev tail: save_tile)" % r, base + 1: "  fwd round %d: g = h A (gemm128 + store)" % r,
+                  base + 2: "  fwd round %d: barrier" % r, base + 3: "  fwd round %d: attention" % r, base + 4: "  fwd round %d: barrier" % r,
+                  base + 5: "  fwd round %d: gemm256" % r, base + 6: "  fwd round %d: barrier + store + barrier" % r})
+order = [0, 1] + list(range(33, 54)) + [2, 3, 4, 5] + list(range(6, 33))
+keys = [k for k in order if k in names and buf[k]]
 prev = None
 for k in keys:
     if prev is not None:
