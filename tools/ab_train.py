@@ -56,6 +56,10 @@ def one(name, tests):
             best = min(best, a.elapsed_time(b) * 100)
         out["ppo_grad_%dv%d_us" % (G, A)] = round(best, 1)
         out["grad_checksum_%dv%d" % (G, A)] = float(o.double().abs().sum())
+        if os.environ.get("FA_AB_DUMP"):
+            import numpy as np
+            os.makedirs(os.path.join(ROOT, "gpurun_out", "dump"), exist_ok=True)
+            np.save(os.path.join(ROOT, "gpurun_out", "dump", "%s_%s_%dv%d.npy" % (name, os.environ["FA_AB_DUMP"], G, A)), o.cpu().numpy())
     torch.manual_seed(0)
     eng = fa.BatchedFortAttack(4096, 3, 3, 100, track_counters=False)
     L = fa.BatchedLearner(eng, num_steps=128, use_graph=True)
