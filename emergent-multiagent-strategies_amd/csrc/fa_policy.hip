@@ -81,6 +81,7 @@ __global__ __launch_bounds__(NW * 64, NRB == 2 ? 2 : 1) void fa_policy_kernel(Fa
     __shared__ __attribute__((aligned(16))) float sG[PR * LDA]; // g / hmix; opponent stage scratch
     __shared__ float sX[PR * 2 * FA_OBS_DIM];                    // observations of the tile's envs (all agents)
     __shared__ float sO[PR * 16];                                // logits (8) + value per row
+    __shared__ float sNz[NW == 8 ? PR * FA_NUM_ACTIONS : 1];     // eight waves: log(-log u) per (row, action), see below
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int team = blockIdx.y;
@@ -88,6 +89,11 @@ __global__ __launch_bounds__(NW * 64, NRB == 2 ? 2 : 1) void fa_policy_kernel(Fa
     const int n = team == 0 ? a.G : a.A, m = N - n;   // own / opponent team size
     const int own0 = team == 0 ? 0 : a.G, opp0 = team == 0 ? a.G : 0;
     const int ET = PR / (n > m ? n : m);               // envs per tile
+    // r / n, r / m, k / (6 N) for row indices below 2048 as a multiply and a shift (exact for divisors up to 16 -- team
+    // sizes -- and checked for 6 N <= 96 on the host side of this file); a run-time integer division is ~35 instructions
+    const unsigned inv_n = 65536u / (unsigned)n + 1u, inv_m = 65536u / (unsigned)m + 1u;
+    auto div_n = [&](int r) { return (int)(((unsigned)r * inv_n) >> 16); };
+    auto div_m = [&](int r) { return (int)(((unsigned)r * inv_m) >> 16); };
     // which envs: a contiguous range, or -- ensemble of attacker strategies -- the tile's slots of the
     // strategy-sorted env list (every env of a tile then shares one set of attacker weights)
     __shared__ int sE[PR];
@@ -141,7 +147,7 @@ __global__ __launch_bounds__(NW * 64, NRB == 2 ? 2 : 1) void fa_policy_kernel(Fa
         for (int r = grp; r < PR; r += NW) {
             float vo = 0.0f, vp = 0.0f;
             if (r < ET * n) {
-                const int el = r / n, i = r - el * n;
+                const int el = div_n(r), i = r - el * n;
                 const float *x = sX + (el * N + own0 + i) * FA_OBS_DIM;
                 vo = be;
 #pragma unroll
@@ -149,7 +155,7 @@ __global__ __launch_bounds__(NW * 64, NRB == 2 ? 2 : 1) void fa_policy_kernel(Fa
                 vo = fmaxf(vo, 0.0f);
             }
             if (r < ET * m) {
-                const int el = r / m, j = r - el * m;
+                const int el = div_m(r), j = r - el * m;
                 const float *x = sX + (el * N + opp0 + j) * FA_OBS_DIM;
                 vp = bo;
 #pragma unroll
@@ -189,7 +195,7 @@ __global__ __launch_bounds__(NW * 64, NRB == 2 ? 2 : 1) void fa_policy_kernel(Fa
 #pragma unroll
         for (int k = 0; k < AIT; ++k) {
             const int r = arow0 + k * NW * 4, rr = r < RU ? r : RU - 1;
-            attend_row_regs<64, MT>(sG + rr * LDA + 64, sG + ((rr / n) * m) * LDA, m, -1, q16, ov[k]);
+            attend_row_regs<64, MT>(sG + rr * LDA + 64, sG + (div_n(rr) * m) * LDA, m, -1, q16, ov[k]);
         }
 #pragma unroll
         for (int k = 0; k < AIT; ++k) {
@@ -226,7 +232,7 @@ __global__ __launch_bounds__(NW * 64, NRB == 2 ? 2 : 1) void fa_policy_kernel(Fa
         float ov[AIT][8];
 #pragma unroll
         for (int k = 0; k < AIT; ++k) {
-            const int r = arow0 + k * NW * 4, rr = r < RU ? r : RU - 1, el = rr / n;
+            const int r = arow0 + k * NW * 4, rr = r < RU ? r : RU - 1, el = div_n(rr);
             attend_row_regs<128, MT>(sG + rr * LDA, sH + (el * n) * LDA, n, rr - el * n, q16, ov[k]);
         }
 #pragma unroll
@@ -294,7 +300,34 @@ _Pragma("unroll")
     })
     __syncthreads();
     FA_PL_TICK(29)
-    // logits (8) | value (1) = [p | v] W9 + b9, W9 block diagonal in a 32-column block: wave = row block
+    // log(-log u) of a row's eight Gumbel-max draws: Philox4x32-10 keyed by (seed; counter, step, global env, agent)
+    auto gumbel_row = [&](int row, float (&g)[FA_NUM_ACTIONS]) __attribute__((always_inline)) {
+        const int el = div_n(row), i = row - el * n;
+        const uint64_t ge = (uint64_t)(a.env_offset + sE[el]);
+        const uint32_t ctr = a.counter ? (uint32_t)a.counter[0] : 0u;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            uint32_t c[4] = {(uint32_t)ge, (uint32_t)(ge >> 32) ^ ((uint32_t)(own0 + i) << 16) ^ ((uint32_t)half << 31),
+                             (uint32_t)a.step, ctr};
+            philox4x32_10(c, (uint32_t)a.seed, (uint32_t)(a.seed >> 32));
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float u = ((float)(c[k] >> 8) + 0.5f) * (1.0f / 16777216.0f); // (0, 1)
+                g[half * 4 + k] = logf(-logf(u));
+            }
+        }
+    };
+    // logits (8) | value (1) = [p | v] W9 + b9, W9 block diagonal in a 32-column block: wave = row block.  Eight waves:
+    // the draws do not depend on the logits -- two of the waves without a row block make them meanwhile
+    if (NW == 8 && wave >= 4 && wave < 6 && !a.deterministic && !a.value_only) {
+        const int row = tid - 256;
+        if (row < RU && sE[div_n(row)] >= 0) {
+            float g[FA_NUM_ACTIONS];
+            gumbel_row(row, g);
+#pragma unroll
+            for (int k = 0; k < FA_NUM_ACTIONS; ++k) sNz[row * FA_NUM_ACTIONS + k] = g[k];
+        }
+    }
     if (wave < NRB) {
         f32x16 acc[1] = {};
         gemm_cb<256, 1>((hh ? sH : sG) + (wave * 32 + li) * LDA, Wq + FA_POFF_W9 / 4, acc, lane, hd_u);
@@ -311,7 +344,7 @@ _Pragma("unroll")
     FA_PL_TICK(30)
 
     // ---- value, log-softmax, sample, log-prob of the sample -> rollout rows ----------------------------------
-    const int el_out = tid / n;
+    const int el_out = tid < PR ? div_n(tid) : 0;
     if (tid < ET * n && sE[el_out] >= 0) {
         const int el = el_out, i = tid - el * n;
         const int e = sE[el];
@@ -333,20 +366,18 @@ _Pragma("unroll")
                 for (int k = 1; k < FA_NUM_ACTIONS; ++k)
                     if (lg[k] > best) { best = lg[k]; act = k; }
             } else {
-                const uint64_t ge = (uint64_t)(a.env_offset + e);
-                const uint32_t ctr = a.counter ? (uint32_t)a.counter[0] : 0u;
+                float g[FA_NUM_ACTIONS];
+                if constexpr (NW == 8) {
+#pragma unroll
+                    for (int k = 0; k < FA_NUM_ACTIONS; ++k) g[k] = sNz[tid * FA_NUM_ACTIONS + k];
+                } else {
+                    gumbel_row(tid, g);
+                }
                 float best = -INFINITY;
 #pragma unroll
-                for (int half = 0; half < 2; ++half) {
-                    uint32_t c[4] = {(uint32_t)ge, (uint32_t)(ge >> 32) ^ ((uint32_t)(own0 + i) << 16) ^ ((uint32_t)half << 31),
-                                     (uint32_t)a.step, ctr};
-                    philox4x32_10(c, (uint32_t)a.seed, (uint32_t)(a.seed >> 32));
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const float u = ((float)(c[k] >> 8) + 0.5f) * (1.0f / 16777216.0f); // (0, 1)
-                        const float z = lg[half * 4 + k] - logf(-logf(u));                   // Gumbel-max
-                        if (z > best) { best = z; act = half * 4 + k; }
-                    }
+                for (int k = 0; k < FA_NUM_ACTIONS; ++k) {
+                    const float z = lg[k] - g[k]; // Gumbel-max
+                    if (z > best) { best = z; act = k; }
                 }
             }
             float la = lg[0];
