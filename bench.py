@@ -345,7 +345,7 @@ def main():
     traffic, traffic_src = None, None
     kernel_name = eng.step_variant(T // launches_per_rollout)   # which step kernel these launches ran
     if (E, G, A, T) == (4096, 3, 3, 128):
-        for rnd in ("r02", "r01"):
+        for rnd in ("r03", "r02", "r01"):
             prof = os.path.join(ROOT, "profiles", "%s_%s_summary.json" % (rnd, "fused" if graph is None else "perstep"))
             if not os.path.isfile(prof):
                 continue
@@ -506,7 +506,8 @@ def closed_loop(fa, args, rank, local_rank, world, dev, barrier):
         "update": "JointPPO: 4 epochs x 32 minibatches x 2 teams, Adam, grad-clip; every optimizer step (fused forward + "
                   "losses + backward kernel, fold / unfold, clip + Adam on flat buffers) replayed from a hipGraph, %s" % (
             "the two teams as concurrent chains on two streams" if world == 1 else
-            "flat gradient all-reduce per optimizer step, teams one after the other"),
+            "one flat gradient all-reduce per optimizer step between the two graphs of a step; the two teams as concurrent "
+            "chains on two streams, each on its own communicator"),
         "dtype": "f32 policy / f64 env", "unit": "env-steps/s"}
 
 
@@ -536,7 +537,7 @@ def closed_loop_rooflines(fa, L, E, G, A, T):
     if L.policy_backend == "hip":
         sec = timed(lambda: L._hip_act(0), 200)
         flops = E * (G * policy_flops_per_row(G, A) + A * policy_flops_per_row(A, G))
-        out["policy"] = {"bound": "mfma", "kernel": "fa_policy_kernel<%d>" % max(G, A), "achieved": flops / sec / 1e12,
+        out["policy"] = {"bound": "mfma", "kernel": "fa_policy_kernel<3, 8> (96-row tiles, eight waves)", "achieved": flops / sec / 1e12,
                          "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": flops / sec / 1e12 / MFMA_F32_PEAK_TFLOPS,
                          "traffic": None, "flops_per_launch": flops, "avg_launch_us": sec * 1e6,
                          "timed_by": "hipEvents on the launch stream, 200 eager launches of fa_collect_act",

@@ -21,15 +21,15 @@
 // -- 48k MACs per row instead of 98k -- and needs two LDS buffers instead of four.  The opponent
 // attention (mpnn.py:372-443) folds the same way: A_o = norm * Wkey Wquery^T, B_o = Wval Wout.
 //
-// Tiling.  Workgroup = 4 waves = one tile of ET = 96 / max(n, m) envs of ONE team (blockIdx.y).  Rows =
-// (env, own agent).  A 32x32x2 MFMA takes A[i = lane & 31][k = lane >> 5]: the K axis is permuted so that
+// Tiling.  Workgroup = one tile of ET = 96 / max(n, m) envs of ONE team (blockIdx.y), eight waves (two per SIMD; four
+// for the 64-row tile of small batches).  Rows = (env, own agent).  A 32x32x2 MFMA takes A[i = lane & 31][k = lane >> 5]: the K axis is permuted so that
 // lane half hh covers k in [hh*K/2, (hh+1)*K/2) -- then a lane's A values of four consecutive MFMAs are
 // one contiguous 16-byte LDS read, and for the K = 256 update layer half 0 reads h and half 1 reads hmix
 // from their own buffers with no concatenation.  The packed B operand uses the same permutation:
 // float4 index (cb * K/8 + t4) * 64 + lane holds W[k = hh*K/2 + 4*t4 + q][col = 32*cb + (lane & 31)],
-// q = 0..3.  Each wave owns one 32-column block of the layer's output for all three 32-row blocks (its
-// B registers are reused three times); LDS rows are padded to 132 floats (bank-conflict-free 16-byte
-// column reads).
+// q = 0..3.  A wave owns one 32-column block of the layer's output -- waves 0..3 for row blocks 0 and 1, waves 4..7
+// for row block 2 (see FA_POLICY_SPLIT) -- and its B registers are reused for each of its row blocks; LDS rows are
+// padded to 132 floats (bank-conflict-free 16-byte column reads).
 //
 // Sampling: Gumbel-max over the 8 logits with Philox4x32-10 uniforms keyed by (seed; rollout counter,
 // rollout step, global env index, agent) -- a draw from softmax(logits), i.e. the distribution of

@@ -32,7 +32,7 @@ lib = C.CDLL(LIB)
 buf = (C.c_ulonglong * 64)()
 lib.fa_dbg_train(buf)
 names = {0: "start", 1: "fwd: encoders + opponent stage", 2: "fwd: 3 rounds", 3: "fwd: heads", 4: "losses", 5: "bwd: heads",
-         30: "bwd: rounds done", 31: "bwd: opponent stage", 32: "bwd: encoders"}
+         30: "bwd: rounds done", 31: "bwd: opponent stage", 32: "bwd: encoders", 48: "bwd: shared weight gradients (end phase)"}
 for r in range(3):
     base = 6 + r * 8
     names.update({base: "  round %d: (prev tail)" % (2 - r), base + 1: "  round %d: relu mask + bias grad" % (2 - r),
@@ -43,7 +43,7 @@ for r in range(3):
     names.update({base: "  fwd round %d: (prev tail: save_tile)" % r, base + 1: "  fwd round %d: g = h A (gemm128 + store)" % r,
                   base + 2: "  fwd round %d: barrier" % r, base + 3: "  fwd round %d: attention" % r, base + 4: "  fwd round %d: barrier" % r,
                   base + 5: "  fwd round %d: gemm256" % r, base + 6: "  fwd round %d: barrier + store + barrier" % r})
-order = [0, 1] + list(range(33, 54)) + [2, 3, 4, 5] + list(range(6, 33))
+order = [0, 1] + list(range(33, 48)) + [2, 3, 4, 5] + list(range(6, 33)) + [48]
 keys = [k for k in order if k in names and buf[k]]
 prev = None
 for k in keys:
