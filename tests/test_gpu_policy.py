@@ -139,6 +139,25 @@ def test_env_shards_draw_what_one_big_batch_draws(fa):
         assert torch.equal(full[k], torch.cat((lo[k], hi[k])))
 
 
+@pytest.mark.parametrize("G,A", [(3, 3), (5, 5), (2, 4)])
+def test_eight_wave_tile_kernel_draws_what_the_four_wave_kernel_draws(fa, G, A):
+    """4096 envs in one handle run fa_policy_kernel<3, 8> (96-row tiles, eight waves, Gumbel noise drawn by idle waves);
+    the same envs as shards of 512 run fa_policy_kernel<2, 4> (64-row tiles, four waves, noise drawn inline).  A row's
+    arithmetic is the same in both -- K order of the MFMA chains, attention, sampling key -- so values, sampled actions
+    and log-probs agree bit for bit."""
+    E, S = 4096, 512
+    N = G + A
+    pols, packed = _policies(fa, G, A, 6)
+    obs = _obs(E, N, 9)
+    counter = torch.full((1,), 3, dtype=torch.int64, device="cuda")
+    full = fa.BatchedFortAttack(E, G, A, 20).policy_act(obs, packed[0], packed[1], seed=11, counter=counter, step=5)
+    parts = [fa.BatchedFortAttack(S, G, A, 20, env_offset=o).policy_act(obs[o:o + S].contiguous(), packed[0], packed[1], seed=11,
+                                                                         counter=counter, step=5) for o in range(0, E, S)]
+    for k in range(3):
+        assert torch.equal(full[k], torch.cat([p[k] for p in parts]))
+    assert len(torch.unique(full[1])) == 8                                    # every action is drawn somewhere
+
+
 def test_collect_act_writes_the_policy_rows(fa):
     G, A, E, T = 3, 3, 200, 6
     N = G + A
