@@ -14,3 +14,4 @@ from .rlagent import JointPPO, Neo  # noqa: F401
 
 __all__ = ["BatchedFortAttack", "FortAttackGlobalEnv", "make_fortattack_env", "JointRolloutStorage",
            "RolloutStorage", "FaError", "Box", "Discrete", "MASpace", "MPNN", "BatchedLearner", "Neo", "JointPPO"]
+from . import render  # noqa: F401

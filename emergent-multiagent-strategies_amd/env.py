@@ -485,6 +485,7 @@ class FortAttackGlobalEnv(object):
         if a.shape[0] != self.n:
             raise AssertionError("expected %d actions, got %d" % (self.n, a.shape[0]))
         self._cache = None
+        self._stepped = True
         self._act.copy_(torch.from_numpy(a.astype(np.int64)).view(1, -1))
         self._eng.step(self._act, auto_reset=False, want=(),
                        out=dict(obs_f64=self._obs64, reward_f64=self._rew64, done=self._done))
@@ -497,8 +498,16 @@ class FortAttackGlobalEnv(object):
         done = bool(self._done.item())
         return obs, reward_n, done, {"n": [{} for _ in range(self.n)]}
 
-    def render(self, *args, **kwargs):  # GUI: out of scope
-        return []
+    def render(self, attn_list=None, mode="human", close=False, size=350, viz_dead=False):
+        """fortattack.py:368-600.  The pyglet window is out of scope: mode "human"
+        stays a no-op returning [] as the reference's trainers expect; mode "rgb_array" returns [frame], the same
+        scene rasterised headlessly from the device state (render.py), lasers for the agents whose last action was 7."""
+        if mode != "rgb_array":
+            return []
+        from .render import render_state
+        st = self._eng.get_state()
+        shoot = (self._act.cpu().numpy().reshape(1, -1) == 7) if getattr(self, "_stepped", False) else None
+        return [render_state(st, 0, self._eng.G, shoot=shoot, size=size, viz_dead=viz_dead)]
 
     def terminate(self):
         pass
