@@ -38,10 +38,12 @@ def _check_rollout_against_oracle(fa, learner, orc, first):
             pol = learner.policies[ti]
             v, lp, _ = pol.evaluate_actions(st.obs[:-1].flatten(0, 1)[:, own], st.obs[:-1].flatten(0, 1)[:, opp],
                                             st.actions.flatten(0, 1)[:, own])
-            assert (v.view(T, E, -1, 1) - st.value_preds[:-1, :, own]).abs().max() < 1e-4
+            # float32, folded algebra vs the module: ~1e-6 RELATIVE (values grow to +-100 as the critic learns)
+            vtol = 1e-4 * max(1.0, float(v.abs().max()))
+            assert (v.view(T, E, -1, 1) - st.value_preds[:-1, :, own]).abs().max() < vtol
             assert (lp.view(T, E, -1, 1) - st.action_log_probs[:, :, own]).abs().max() < 1e-4
             vT = pol.get_value(st.obs[T][:, own], st.obs[T][:, opp])
-            assert (vT - st.value_preds[T, :, own]).abs().max() < 1e-4
+            assert (vT - st.value_preds[T, :, own]).abs().max() < vtol
     # GAE over the stored rows == numpy oracle, bit for bit
     vals, rets = st.value_preds.cpu().numpy(), st.returns.cpu().numpy()
     return ep_start, rew, vals, msk, rets

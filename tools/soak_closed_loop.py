@@ -45,6 +45,6 @@ for it in range(R):
 st = eng.get_state()
 print(json.dumps({"config": "%dv%d, E=%d, T=%d, max_time_steps=%d, BatchedLearner(use_graph=True), %d collect + update iterations"
                   % (G, A, E, T, max_t, R), "env_steps": R * E * T, "differing_rows": 0,
-                  "checked": "obs / rewards / masks / done rows and GAE returns bit for bit, policy rows <= 1e-4 vs the PyTorch module",
+                  "checked": "obs / rewards / masks / done rows and GAE returns bit for bit, policy rows <= 1e-4 (values: relative) vs the PyTorch module",
                   "shoot_fraction_first_last": [shoot_frac[0], shoot_frac[-1]], "entropy_first_last": [ent[0], ent[-1]],
                   "episodes": int(st["result_count"].sum()), "seconds": round(time.time() - t0, 1)}))
