@@ -445,10 +445,13 @@ __device__ __forceinline__ void fa_train_body(const FaTrainArgs &a) {
             gemm_tn((kb < 4 ? B1 : B2) + (kb & 3) * 32, LDA, sO, SOW, acc, lane);
             store_tile_global(slab + FA_POFF_W9 + kb * 32 * 32, 32, acc, lane);
         }
-        if (wave == 0 && lane < 32) {
+        {   // db9 = column sums of dOUT: sixteen 4-row partial sums per column (sO2 is free until the encoders), folded
+            // behind the next barrier -- a bias sum as one lane per column is a 64-deep serial chain on two waves
+            const int col = tid & 31, part = tid >> 5;
             float sum = 0.0f;
-            for (int r = 0; r < TR; ++r) sum += sO[r * SOW + tid];
-            slab[FA_POFF_B9 + tid] = sum;
+#pragma unroll
+            for (int r = 0; r < TR / 16; ++r) sum += sO[(part * (TR / 16) + r) * SOW + col];
+            sO2[part * 32 + col] = sum;
         }
     }
     {   // d[P | V] = dOUT W9^T (K = 32 -> 256 columns: blocks wave, wave + 4), through the relus in place
@@ -473,6 +476,12 @@ __device__ __forceinline__ void fa_train_body(const FaTrainArgs &a) {
             }
         }
         __syncthreads(); // dW9 has read P and V
+        if (tid < 32) {
+            float sum = 0.0f;
+#pragma unroll
+            for (int part = 0; part < 16; ++part) sum += sO2[part * 32 + tid];
+            slab[FA_POFF_B9 + tid] = sum;
+        }
         store_acc_relu_mask(B1 + cbw * 32, rbw, ap[0], lane);
         store_acc_relu_mask(B2 + cbw * 32, rbw, av[0], lane);
     }
@@ -487,11 +496,12 @@ __device__ __forceinline__ void fa_train_body(const FaTrainArgs &a) {
                 store_tile_global(slab + FA_POFF_W8 + kb * 32 * 256 + cb * 32, 256, acc, lane);
             }
         }
-        if (wave < 4) {
-            const float *src = (wave < 2 ? B1 : B2) + (tid & 127);
+        {   // db8: two 32-row partial sums per column of [dP | dV] (sO -- dOUT -- is dead by now), folded behind the barrier below
+            const int col = tid & 255, half = tid >> 8;
+            const float *src = (col < 128 ? B1 : B2) + (col & 127) + half * (TR / 2) * LDA;
             float sum = 0.0f;
-            for (int r = 0; r < TR; ++r) sum += src[r * LDA];
-            slab[FA_POFF_B8 + tid] = sum;
+            for (int r = 0; r < TR / 2; ++r) sum += src[r * LDA];
+            sO[half * 256 + col] = sum;
         }
     }
     {   // dh3 = [dP | dV] W8^T (K = 256: half 0 walks dP, half 1 dV) -> B3
@@ -503,6 +513,7 @@ __device__ __forceinline__ void fa_train_body(const FaTrainArgs &a) {
         store_acc<false>(B3 + cbw * 32, rbw, acc[0], 0.0f, lane);
     }
     __syncthreads();
+    if (tid < 256) slab[FA_POFF_B8 + tid] = sO[tid] + sO[256 + tid];
 
     FA_TR_TICK(5)
     // ---- the three rounds, last first: B0 = the round's output h, B3 = dL/d(output) ---------------------
@@ -524,10 +535,11 @@ __device__ __forceinline__ void fa_train_body(const FaTrainArgs &a) {
             if (!(B0[r * LDA + c] > 0.0f)) B3[r * LDA + c] = 0.0f;
         }
         __syncthreads();
-        if (wave < 2) {
+        {   // the update bias gradient: four 16-row partial sums per column of dZ, folded behind the next barrier
+            const int col = tid & 127, q = tid >> 7;
             float sum = 0.0f;
-            for (int r = 0; r < TR; ++r) sum += B3[r * LDA + tid];
-            dbu += sum;
+            for (int r = 0; r < TR / 4; ++r) sum += B3[(q * (TR / 4) + r) * LDA + col];
+            sO2[q * 128 + col] = sum;
         }
         FA_TR_TICK(7 + (2 - round) * 8)
         // h_in -> B0, g = h_in A_m -> B2 (recomputed), hmix -> B1 (recomputed from the saved weights)
@@ -535,6 +547,7 @@ __device__ __forceinline__ void fa_train_body(const FaTrainArgs &a) {
         prefetch_b<128>(wp_am, lane, hd_g);
         load_tile(B0, hsave + round * TR * 128);
         __syncthreads();
+        if (tid < 128) dbu += ((sO2[tid] + sO2[128 + tid]) + sO2[256 + tid]) + sO2[384 + tid];
         project_team(B2, hd_g);
         for (int r = wave * 4 + (lane >> 4); r < TR; r += NWV * 4) {
             if (r < RU) mix_row<128>(sAttn[1 + round] + r * 8, B0 + ((r / n) * n) * LDA, n, B1 + r * LDA, q16);
