@@ -101,7 +101,7 @@ def test_closed_loop_rollout_and_update(fa, use_graph, hidden, backend, tmp_path
 
 def test_bench_closed_loop_launch_at_full_size_vs_oracle(fa):
     """The exact launch bench.py's `closed_loop` record times (bench.py closed_loop(): BatchedLearner(use_graph=True)
-    at 3v3 x 4096 envs x 128 steps, max_time_steps 100, base_seed 0 -- ONE hipGraph of 128 x (fa_policy_kernel<3> +
+    at 3v3 x 4096 envs x 128 steps, max_time_steps 100, base_seed 0 -- ONE hipGraph of 128 x (fa_policy_kernel<3, 8> +
     fa_step_kernel<3,3,false,true,3>) + V(obs[T])), two rollouts: env rows / masks / done against the oracle driven by
     the sampled actions (bit for bit), the policy-side rows against the PyTorch definition, GAE returns against the
     numpy oracle (bit for bit, including the stale entries carried from the first rollout into the second)."""
