@@ -56,16 +56,57 @@ def train_flops_per_row(n, m):
     return 3.0 * fwd + 2.0 * 3 * 128 * 128
 
 
-def measured_stream():
-    """What plain streaming kernels sustain on the box (tools/ubench_hbm.hip, committed record):
-    context for `peak` (the 8 TB/s vendor figure the roofline is priced against)."""
+def measured_stream(dev):
+    """What plain streaming kernels sustain on THIS box in THIS run (context for `peak`, the 8 TB/s vendor figure the
+    roofline is priced against): torch's elementwise kernels over 1 GiB float32 tensors -- copy (r + w), triad
+    (2 r + w), read (a sum) -- best of 5, bytes moved / time.  The round-1 record of the hand-written streaming kernels
+    (tools/ubench_hbm.hip) rides along, labelled as what it is."""
+    import torch
+    out = {"source": "live: torch elementwise kernels over 1 GiB f32 tensors, best of 5, this run"}
+    try:
+        n = 1 << 28
+        a = torch.empty(n, device=dev).normal_()
+        b = torch.empty_like(a).normal_()
+        c = torch.empty_like(a)
+
+        def best(fn, nbytes):
+            fn()
+            torch.cuda.synchronize()
+            t = []
+            for _ in range(5):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                fn()
+                e1.record()
+                torch.cuda.synchronize()
+                t.append(e0.elapsed_time(e1) * 1e-3)
+            return nbytes / min(t) / 1e9
+
+        out["copy"] = best(lambda: c.copy_(a), 8.0 * n)
+        out["triad"] = best(lambda: torch.add(a, b, alpha=3.0, out=c), 12.0 * n)
+        out["read"] = best(lambda: a.sum(), 4.0 * n)
+        del a, b, c
+        torch.cuda.empty_cache()
+    except Exception as exc:
+        out["error"] = repr(exc)
     try:
         d = json.load(open(os.path.join(ROOT, "profiles", "r01_hbm_stream.json")))
-        return {"copy": max(v for k, v in d.items() if k.startswith("copy")),
-                "triad": max(v for k, v in d.items() if k.startswith("triad")),
-                "read": max(v for k, v in d.items() if k.startswith("read"))}
+        out["committed_round1_record"] = {"source": "profiles/r01_hbm_stream.json (tools/ubench_hbm.hip, round 1; NOT measured in this run)",
+                                          "copy": max(v for k, v in d.items() if k.startswith("copy")),
+                                          "triad": max(v for k, v in d.items() if k.startswith("triad")),
+                                          "read": max(v for k, v in d.items() if k.startswith("read"))}
     except Exception:
-        return None
+        pass
+    return out
+
+
+def policy_kernel_label(E, G, A):
+    """The fa_policy_kernel instantiation fa_collect_act launches for this shape (csrc/fa_policy.hip: policy_rows)."""
+    n_max = max(G, A)
+    wgs96 = 2 * ((E + 96 // n_max - 1) // (96 // n_max))
+    if wgs96 < 192:
+        return "fa_policy_kernel<2, 4> (64-row tiles = %d envs of %dv%d, four waves, two workgroups per CU)" % (64 // n_max, G, A)
+    return "fa_policy_kernel<3, 8> (96-row tiles = %d envs of %dv%d, eight waves)" % (96 // n_max, G, A)
 
 
 def algorithmic_bytes_per_env_step(n_agents):
@@ -176,6 +217,18 @@ def cpu_baseline(E, G, A, T, budget_s=20.0):
                                      "it cannot run on the GPU box"}
 
 
+def _ranges(ids):
+    """[0,1,2,5,6] -> '0-2,5-6'"""
+    out, k = [], 0
+    while k < len(ids):
+        j = k
+        while j + 1 < len(ids) and ids[j + 1] == ids[j] + 1:
+            j += 1
+        out.append(str(ids[k]) if j == k else "%d-%d" % (ids[k], ids[j]))
+        k = j + 1
+    return ",".join(out)
+
+
 def self_launch(args):
     """`python bench.py --gpus N` without a launcher: start N ranks under torch.distributed.run (one
     process per GPU, rendezvous on 127.0.0.1) with the same arguments and pass their output through."""
@@ -191,11 +244,13 @@ def self_launch(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=None,
+                    help="rollouts to time: EXACTLY this many when given (default: 20, raised by --min-seconds)")
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--min-seconds", type=float, default=0.5,
+    ap.add_argument("--min-seconds", type=float, default=None,
                     help="keep timing whole rollouts until the timed region is at least this long (the 128-step "
-                         "rollout takes ~0.2 ms: 20 of them are a 4 ms sample); 0 = exactly --steps")
+                         "rollout takes ~0.2 ms: 20 of them are a 4 ms sample).  Default: 0.5 when --steps is not "
+                         "given, 0 (= exactly --steps) when it is")
     ap.add_argument("--envs", type=int, default=4096, help="envs per GPU")
     ap.add_argument("--rollout", type=int, default=128, help="env-steps per rollout (T)")
     ap.add_argument("--guards", type=int, default=3)
@@ -211,6 +266,9 @@ def main():
     ap.add_argument("--closed-loop-rollouts", type=int, default=20)
     ap.add_argument("--closed-loop-updates", type=int, default=3)
     ap.add_argument("--no-esweep", action="store_true", help="skip the E-sweep record (fused launch at 32 768 ... 1 048 576 envs)")
+    ap.add_argument("--no-5v5", action="store_true",
+                    help="skip the 5v5 records of a default 3v3 run (fused launch, closed loop, closed loop with the "
+                         "five-strategy attacker ensemble = BASELINE config 5's per-GPU shape)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL on ROCm)")
     ap.add_argument("--share-devices", action="store_true",
                     help="map ranks onto the visible GPUs round-robin (smoke-testing the multi-rank "
@@ -252,6 +310,17 @@ def main():
 
     import emergent_multiagent_strategies_amd as fa
     from emergent_multiagent_strategies_amd.dist import gae_adv_mean_std
+
+    # which device and which CPUs every rank ended up on (a rank whose CPUs sit on the other socket, or two ranks on one
+    # device, show up here and not as an unexplained slow rank)
+    binding = [{"rank": rank, "local_rank": local_rank, "device": torch.cuda.get_device_name(local_rank),
+                "device_index": local_rank, "pid": os.getpid(),
+                "cpu_affinity": "%d cpus: %s" % (len(os.sched_getaffinity(0)), _ranges(sorted(os.sched_getaffinity(0))))}]
+    if world > 1:
+        box = [None] * world
+        dist.all_gather_object(box, binding[0])
+        binding = box
+        print("rank %d -> cuda:%d, %s" % (rank, local_rank, binding[rank]["cpu_affinity"]), file=sys.stderr, flush=True)
 
     E, G, A, T = args.envs, args.guards, args.attackers, args.rollout
     N = G + A
@@ -299,14 +368,16 @@ def main():
     for _ in range(max(args.warmup, 1)):
         hot_path()
     torch.cuda.synchronize()
-    steps = args.steps
-    if args.min_seconds > 0:
+    steps_requested = 20 if args.steps is None else args.steps
+    min_seconds = (0.5 if args.steps is None else 0.0) if args.min_seconds is None else args.min_seconds
+    steps = steps_requested
+    if min_seconds > 0:
         t0 = time.perf_counter()
         for _ in range(5):
             hot_path()
         torch.cuda.synchronize()
         est = (time.perf_counter() - t0) / 5
-        steps = max(steps, int(args.min_seconds / max(est, 1e-6)) + 1)
+        steps = max(steps, int(min_seconds / max(est, 1e-6)) + 1)
         if world > 1:
             ts = torch.tensor([steps], device=dev, dtype=torch.int64)
             dist.all_reduce(ts, op=dist.ReduceOp.MAX)
@@ -362,11 +433,19 @@ def main():
     closed = None
     if not args.no_closed_loop:
         closed = closed_loop(fa, args, rank, local_rank, world, dev, barrier)
+    # a default 3v3 run on one GPU also carries the 5v5 shapes one GPU can run (BASELINE config 5's per-GPU shape)
+    extra = {}
+    if world == 1 and (G, A) == (3, 3) and not args.no_5v5:
+        extra["fused_5v5"] = fused_record(fa, 5, 5, E, T, dev)
+        if not args.no_closed_loop:
+            extra["closed_loop_5v5"] = closed_loop(fa, args, rank, local_rank, world, dev, barrier, G=5, A=5, rollouts=10, updates=2)
+            extra["closed_loop_5v5_ens5"] = closed_loop(fa, args, rank, local_rank, world, dev, barrier, G=5, A=5, ensemble=5,
+                                                        rollouts=10, updates=2)
 
     if rank == 0:
         res = {
             "metric": "env-steps/sec FortAttack %dv%d, %d parallel envs per GPU" % (G, A, E),
-            "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": steps, "steps_requested": args.steps,
+            "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": steps, "steps_requested": steps_requested,
             "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / steps, "timed_seconds": elapsed,
             "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
@@ -393,7 +472,7 @@ def main():
                 # utilisation -- this is
                 "traffic_frac": (traffic / launch_s / 1e9 / HBM_PEAK_GBPS) if traffic else None,
                 "limiter": "per-wave issue chain (latency), not bandwidth, at this batch size: see DESIGN.md 3.1 / 7",
-                "measured_stream_GBps": measured_stream(),
+                "measured_stream_GBps": measured_stream(dev),
                 "algorithmic_bytes_per_launch": bytes_per_launch,
                 "algorithmic_bytes_per_env_step": algorithmic_bytes_per_env_step(N),
                 "env_steps_per_launch": E * (T // launches_per_rollout),
@@ -405,10 +484,13 @@ def main():
         res["collective"] = {"ranks": dist.get_world_size() if world > 1 else 1,
                              "backend": dist.get_backend() if world > 1 else None,
                              "rccl_ranks": (dist.get_world_size() if (world > 1 and dist.get_backend() == "nccl") else 0),
+                             "rank_binding": binding,
                              "per_rollout": "one all_gather_into_tensor of N x 3 f64 (advantage moments) + exact merge",
                              "per_optimizer_step": "one all_reduce of the flat f32 gradient buffer (149 908 floats) per team"}
         if closed is not None:
             res["closed_loop"] = closed
+        if extra:
+            res.update(extra)
         if world == 1 and not args.no_esweep and (G, A) == (3, 3):
             res["esweep"] = esweep(fa, G, A, dev)
         if world == 1 and not args.no_cpu_baseline:
@@ -451,26 +533,50 @@ def esweep(fa, G, A, dev):
     return out
 
 
-def closed_loop(fa, args, rank, local_rank, world, dev, barrier):
-    """BASELINE config 3 (config 4 when world > 1): the MPNN actor-critic (h = 128, PyTorch-ROCm) in the
-    loop.  A rollout = T x (two-team forward + sampling + fa_collect_step), V(obs[T]), GAE and the
-    advantage moments (all-gathered over ranks); then one JointPPO update (4 epochs x 32 minibatches
-    per team; flat gradient all-reduce per optimizer step when world > 1)."""
+def attacker_pool(fa, G, A, K):
+    """K frozen attacker strategies for the ensemble records (BASELINE config 5): the reference's published 5v5 policies
+    (marlsave/tmp_1/ep{220,650,1240,1600,2520}.pt, exported as data by oracle/gen_golden.py into
+    tests/golden/attackers_tmp1.npz) when the shape is theirs, else K randomly initialised ones."""
+    import numpy as np
+    import torch
+    path = os.path.join(ROOT, "tests", "golden", "attackers_tmp1.npz")
+    if (G, A, K) == (5, 5, 5) and os.path.isfile(path):
+        z = np.load(path)
+        eps = [int(e) for e in z["episodes"]]
+        pool = [{k[len("ep%d." % e):]: torch.from_numpy(z[k]) for k in z.files if k.startswith("ep%d." % e)} for e in eps]
+        return pool, "the reference's published attackers marlsave/tmp_1/ep{%s}.pt (tests/golden/attackers_tmp1.npz)" % ",".join(map(str, eps))
+    return ([fa.MPNN(num_agents=A, num_opp_agents=G, num_actions=8).state_dict() for _ in range(K)],
+            "%d randomly initialised attacker strategies" % K)
+
+
+def closed_loop(fa, args, rank, local_rank, world, dev, barrier, G=None, A=None, ensemble=0, rollouts=None, updates=None):
+    """BASELINE config 3 (config 4 when world > 1; config 5's per-GPU shape with G = A = 5 and `ensemble` = 5): the MPNN
+    actor-critic (h = 128) in the loop.  A rollout = T x (two-team forward + sampling + fa_collect_step), V(obs[T]), GAE
+    and the advantage moments (all-gathered over ranks); then one JointPPO update (4 epochs x 32 minibatches per
+    trained team; flat gradient all-reduce per optimizer step when world > 1).  With an attacker ensemble every env
+    plays one of the frozen strategies, re-drawn at each reset, and only the guards are trained (learner.py:119-140,177)."""
     import torch
     import torch.distributed as dist
-    E, G, A, T = args.envs, args.guards, args.attackers, args.rollout
+    E, T = args.envs, args.rollout
+    G = args.guards if G is None else G
+    A = args.attackers if A is None else A
     torch.manual_seed(0)                                      # identical initial policies on every rank
     eng = fa.BatchedFortAttack(E, G, A, 100, base_seed=0, env_offset=rank * E, device=local_rank,
                                track_counters=not args.no_counters)
     L = fa.BatchedLearner(eng, num_steps=T, use_graph=True)
+    pool_note = None
+    if ensemble:
+        pool, pool_note = attacker_pool(fa, G, A, ensemble)
+        L.load_attacker_ensemble(pool)
+    guards_only = bool(ensemble)
     torch.manual_seed(1 + rank)                               # different action sampling per rank
     L.reset()
     L.collect()
-    L.update()                                                # untimed: captures the update's hipGraphs
+    L.update(train_guards_only=guards_only)                   # untimed: captures the update's hipGraphs
     L.after_update()
     torch.cuda.synchronize()
     barrier()
-    R = max(1, args.closed_loop_rollouts)
+    R = max(1, args.closed_loop_rollouts if rollouts is None else rollouts)
     t0 = time.perf_counter()
     for _ in range(R):
         L.collect()
@@ -481,34 +587,101 @@ def closed_loop(fa, args, rank, local_rank, world, dev, barrier):
     L.collect()
     torch.cuda.synchronize()
     barrier()
-    U = max(1, args.closed_loop_updates)
+    U = max(1, args.closed_loop_updates if updates is None else updates)
     t0 = time.perf_counter()
-    for _ in range(U):                                        # (each a full JointPPO update of both teams from this rollout)
-        L.update()
+    for _ in range(U):                                        # (each a full JointPPO update from this rollout)
+        L.update(train_guards_only=guards_only)
     torch.cuda.synchronize()
     barrier()
     t_upd = (time.perf_counter() - t0) / U
     roof = closed_loop_rooflines(fa, L, E, G, A, T) if rank == 0 else None
+    identical = None
     if world > 1:
         tt = torch.tensor([t_roll, t_upd], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         t_roll, t_upd = float(tt[0]), float(tt[1])
+        # data-parallel invariant: after the updates every rank holds the same parameters, bit for bit
+        import hashlib
+        h = hashlib.sha256()
+        for pol in L.policies:
+            for p in pol.parameters():
+                h.update(p.detach().cpu().numpy().tobytes())
+        box = [None] * world
+        dist.all_gather_object(box, h.hexdigest())
+        identical = len(set(box)) == 1
     per_rollout = t_roll / R
-    return {
+    teams = 1 if guards_only else 2
+    rec = {
         "workload": "FortAttack %dv%d, %d envs/GPU, %d-step rollout, MPNN h=128 actor-critic in the loop "
                     "(BASELINE config %s): two-team forward + sampling + fa_collect_step per env-step replayed from "
-                    "a hipGraph, V(obs[T]), GAE, advantage moments%s" % (
-                        G, A, E, T, "3" if world == 1 else "4", "" if world == 1 else " all-gathered over the ranks"),
+                    "a hipGraph, V(obs[T]), GAE, advantage moments%s%s" % (
+                        G, A, E, T, ("5's per-GPU shape" if ensemble else ("3" if world == 1 else "4")),
+                        "" if world == 1 else " all-gathered over the ranks",
+                        "; attackers = %s, one per env, re-drawn at every reset; guards only trained" % pool_note if ensemble else ""),
         "rollout_env_steps_per_s": world * E * T / per_rollout, "rollout_ms": per_rollout * 1e3,
         "ms_per_env_step_launch": per_rollout * 1e3 / T, "rollouts_timed": R, "updates_timed": U,
         "update_s": t_upd, "train_env_steps_per_s": world * E * T / (per_rollout + t_upd),
         "roofline": roof["policy"] if roof else None, "update_roofline": roof["train"] if roof else None,
-        "update": "JointPPO: 4 epochs x 32 minibatches x 2 teams, Adam, grad-clip; every optimizer step (fused forward + "
-                  "losses + backward kernel, fold / unfold, clip + Adam on flat buffers) replayed from a hipGraph, %s" % (
+        "update": "JointPPO: 4 epochs x 32 minibatches x %d team%s, Adam, grad-clip; every optimizer step (fused forward + "
+                  "losses + backward kernels, fold / unfold, clip + Adam on flat buffers) replayed from a hipGraph, %s" % (
+            teams, "" if teams == 1 else "s",
+            "one chain" if teams == 1 else
             "the two teams as concurrent chains on two streams" if world == 1 else
             "one flat gradient all-reduce per optimizer step between the two graphs of a step; the two teams as concurrent "
-            "chains on two streams, each on its own communicator"),
+            "chains on two streams whose all-reduces are event-ordered (one order on every rank)"),
         "dtype": "f32 policy / f64 env", "unit": "env-steps/s"}
+    if identical is not None:
+        rec["ranks_hold_identical_parameters"] = identical
+    L.close()
+    del L, eng
+    torch.cuda.empty_cache()
+    return rec
+
+
+def fused_record(fa, G, A, E, T, dev, iters=200):
+    """The headline workload (fused rollout launch + GAE + one-pass moments + normalisation) at another team size, one GPU."""
+    import torch
+    from emergent_multiagent_strategies_amd.dist import gae_adv_mean_std
+    N = G + A
+    eng = fa.BatchedFortAttack(E, G, A, 100, base_seed=0, device=dev.index, track_counters=True)
+    st = fa.JointRolloutStorage(T, E, N, device=dev)
+    eng.bind_storage(st)
+    gen = torch.Generator(device=dev).manual_seed(99)
+    st.actions.copy_(torch.randint(0, 8, st.actions.shape, device=dev, generator=gen))
+    st.value_preds.copy_(torch.randn(st.value_preds.shape, device=dev, generator=gen))
+    adv = torch.empty((T, E, N, 1), device=dev)
+    eng.collect_reset()
+
+    def hot():
+        eng.collect_rollout(0, T)
+        mean, std = gae_adv_mean_std(eng, 0.99, 0.95)
+        eng.adv_normalize(mean, std, out=adv)
+
+    for _ in range(5):
+        hot()
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+    t0 = time.perf_counter()
+    for k in range(iters):
+        ev[k][0].record()
+        eng.collect_rollout(0, T)
+        ev[k][1].record()
+        mean, std = gae_adv_mean_std(eng, 0.99, 0.95)
+        eng.adv_normalize(mean, std, out=adv)
+    torch.cuda.synchronize()
+    sec = (time.perf_counter() - t0) / iters
+    launch_s = sum(a.elapsed_time(b) for a, b in ev) / iters * 1e-3
+    gbps = algorithmic_bytes_per_env_step(N) * E * T / launch_s / 1e9
+    rec = {"workload": "FortAttack %dv%d, %d envs, %d-step rollout, open-loop uniform-random actions: fused launch + GAE + "
+                       "one-pass moments + normalisation" % (G, A, E, T),
+           "value": E * T / sec, "unit": "env-steps/s", "ms_per_step": sec * 1e3, "steps": iters,
+           "roofline": {"bound": "hbm", "kernel": eng.step_variant(T) + "<%d,%d>" % (G, A), "achieved": gbps, "peak": HBM_PEAK_GBPS,
+                        "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS, "avg_launch_us": launch_s * 1e6,
+                        "algorithmic_bytes_per_env_step": algorithmic_bytes_per_env_step(N),
+                        "timed_by": "hipEvents on the launch stream, %d launches" % iters}}
+    del eng, st, adv
+    torch.cuda.empty_cache()
+    return rec
 
 
 def closed_loop_rooflines(fa, L, E, G, A, T):
@@ -537,7 +710,7 @@ def closed_loop_rooflines(fa, L, E, G, A, T):
     if L.policy_backend == "hip":
         sec = timed(lambda: L._hip_act(0), 200)
         flops = E * (G * policy_flops_per_row(G, A) + A * policy_flops_per_row(A, G))
-        out["policy"] = {"bound": "mfma", "kernel": "fa_policy_kernel<3, 8> (96-row tiles, eight waves)", "achieved": flops / sec / 1e12,
+        out["policy"] = {"bound": "mfma", "kernel": policy_kernel_label(E, G, A), "achieved": flops / sec / 1e12,
                          "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": flops / sec / 1e12 / MFMA_F32_PEAK_TFLOPS,
                          "traffic": None, "flops_per_launch": flops, "avg_launch_us": sec * 1e6,
                          "timed_by": "hipEvents on the launch stream, 200 eager launches of fa_collect_act",

@@ -9,12 +9,23 @@
 //   fa_adv_allreduce   ncclAllGather of this rank's (N, 3) fp64 moments {n, mean, M2} + the exact merge kernel
 //   fa_grad_allreduce  ncclAllReduce(sum) of a float buffer in place
 //
-// RCCL is opened with dlopen at first use (librccl.so.1: inside a PyTorch process that is the copy torch
-// already mapped): no link-time dependency, and a box without RCCL only loses these calls (FA_ERR_STATE).
-// The declarations come from <rccl/rccl.h>; nothing of RCCL is linked.
+// RCCL is opened with dlopen at first use: first the copy the process has ALREADY mapped (RTLD_NOLOAD -- inside a
+// PyTorch process that is torch/lib/librccl.so, and a second RCCL runtime on the same device must not appear), then
+// by name; RTLD_LOCAL, so its nccl* symbols are not exported to the rest of the process.  No link-time dependency, and
+// a box without RCCL only loses these calls (FA_ERR_STATE).  The declarations come from <rccl/rccl.h> where that
+// header exists; without it the few types and enumerators used here are declared locally (the stable NCCL 2 ABI).
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
+#if __has_include(<rccl/rccl.h>)
 #include <rccl/rccl.h>
+#else
+#define NCCL_UNIQUE_ID_BYTES 128
+typedef struct { char internal[NCCL_UNIQUE_ID_BYTES]; } ncclUniqueId;
+typedef struct ncclComm *ncclComm_t;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclFloat32 = 7, ncclFloat64 = 8 } ncclDataType_t;
+typedef enum { ncclSum = 0 } ncclRedOp_t;
+#endif
 
 #include <cstdlib>
 #include <mutex>
@@ -43,16 +54,18 @@ Rccl &rccl() {
     static std::once_flag once;
     std::call_once(once, [] {
         const char *env = std::getenv("FA_RCCL_LIB");
-        const char *names[] = {env, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-        for (const char *n : names) {
-            if (!n || !*n) continue;
-            r.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
-            if (r.handle) {
-                r.path = n;
-                break;
+        const char *names[] = {env, "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"};
+        // pass 0: only a copy that is already mapped (RTLD_NOLOAD); pass 1: load by name
+        for (int pass = 0; pass < 2 && !r.handle; ++pass)
+            for (const char *n : names) {
+                if (!n || !*n) continue;
+                r.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL | (pass == 0 ? RTLD_NOLOAD : 0));
+                if (r.handle) {
+                    r.path = n;
+                    break;
+                }
+                if (const char *e = dlerror()) r.error = e;
             }
-            r.error = dlerror();
-        }
         if (!r.handle) return;
         auto sym = [&](const char *name) {
             void *p = dlsym(r.handle, name);

@@ -60,7 +60,8 @@ class LibraryExchange(object):
             dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
             uid = (C.c_char * 128).from_buffer_copy(box[0])
         comm = C.c_void_p()
-        _lib.check(lib.fa_rccl_comm_create(C.byref(comm), self.world, uid, self.rank, dev.index or 0), "fa_rccl_comm_create")
+        dev_index = dev.index if dev.index is not None else torch.cuda.current_device()   # an index-less "cuda" = the current device
+        _lib.check(lib.fa_rccl_comm_create(C.byref(comm), self.world, uid, self.rank, dev_index), "fa_rccl_comm_create")
         self.comm = comm
         self._gather = None
 

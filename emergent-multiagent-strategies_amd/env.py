@@ -463,6 +463,7 @@ class FortAttackGlobalEnv(object):
 
     def reset(self):
         self._cache = None
+        self._stepped = False   # render(): no lasers of the previous episode's last action on the first frame
         e = self._eng
         if self._np_global:
             pos = self._draw_reset_positions()

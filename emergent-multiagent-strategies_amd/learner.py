@@ -210,7 +210,9 @@ class GraphedPPOStep(object):
             with torch.cuda.graph(self.g2, pool=self.g1.pool()):
                 self.losses = finish(l0, self.flat)
 
-    def run(self, rows, idx):
+    def run(self, rows, idx, reduce_after=None, reduce_done=None):
+        """reduce_after / reduce_done: events that order this step's collective against another chain's on the same
+        device (waited for before, recorded after the all-reduce; only used with several ranks)."""
         if self.fused:
             assert all(a.data_ptr() == b.data_ptr() for a, b in zip(rows, self.rows)), "the captured step reads the rollout in place"
             self.idx.copy_(idx)
@@ -220,7 +222,11 @@ class GraphedPPOStep(object):
                 torch.index_select(src, 0, idx, out=st)
         self.g1.replay()
         if self.g2 is not None:
+            if reduce_after is not None:
+                torch.cuda.current_stream().wait_event(reduce_after)
             self._reduce(self.flat)          # between the two graphs, on the same stream
+            if reduce_done is not None:
+                reduce_done.record()
             self.g2.replay()
         return self.losses
 
@@ -327,6 +333,8 @@ class BatchedLearner(object):
             self._exch = fa_dist.LibraryExchange(self.device, group)
             self._team_exch = [fa_dist.LibraryExchange(self.device, group) for _ in range(2)]
         elif fa_dist.exchanging(group):
+            # dist.new_group is collective over the WHOLE default world: every rank of the job must construct its
+            # learner (in the same order), also the ranks outside `group`
             ranks = dist.get_process_group_ranks(group) if group is not None else None
             self._team_groups = [dist.new_group(ranks=ranks) for _ in range(2)]
         # learner.py:60-68: guards first (policy1), then attackers (policy2); shared per team
@@ -374,6 +382,28 @@ class BatchedLearner(object):
         self.sample_seed = int(torch.initial_seed() if sample_seed is None else sample_seed) & ((1 << 63) - 1)
         self._rollout_counter = torch.zeros(1, dtype=torch.int64, device=self.device)
 
+    def close(self):
+        """Release what the constructor took from the communication layer: the library's RCCL communicators
+        (ncclCommDestroy) and the per-team process groups.  Idempotent; also run when the learner is collected."""
+        for ex in [self._exch] + list(self._team_exch):
+            if ex is not None:
+                ex.close()
+        self._exch, self._team_exch = None, [None, None]
+        if dist.is_available() and dist.is_initialized():
+            for tg in self._team_groups:
+                if tg is not None and tg is not self.group:
+                    try:
+                        dist.destroy_process_group(tg)
+                    except Exception:
+                        pass
+        self._team_groups = [self.group, self.group]
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
     # ---- model I/O (train_fortattack.py:123-128, learner.py:245-249) ----------------------
     def state_dicts(self):
         """[N state_dicts]: entries 0..G-1 the guard policy, G..N-1 the attacker policy."""
@@ -387,13 +417,21 @@ class BatchedLearner(object):
         # the reference's two keys (train_fortattack.py:123-128) + the fused policy kernel's sampling position: the
         # Philox key is (sample_seed; rollout counter, step, env, agent), so a resumed run must not start over at 0
         torch.save({"models": self.state_dicts(), "ob_rms": (None, None),
-                    "fa_rollout_counter": int(self._rollout_counter.item())}, path)
+                    "fa_rollout_counter": int(self._rollout_counter.item()), "fa_sample_seed": int(self.sample_seed)}, path)
 
     def load(self, path):
         ck = torch.load(path, map_location=self.device, weights_only=False)
         self.load_models(ck["models"])
         if "fa_rollout_counter" in ck:          # (absent in the reference's own checkpoints)
             self._rollout_counter.fill_(int(ck["fa_rollout_counter"]))
+        if "fa_sample_seed" in ck:              # the sampling stream continues where the saved run stopped
+            if int(ck["fa_sample_seed"]) != self.sample_seed:
+                import warnings
+                warnings.warn("checkpoint was written with sample_seed %d, this learner was built with %d: continuing the "
+                              "checkpoint's sampling stream" % (int(ck["fa_sample_seed"]), self.sample_seed))
+            if self._graphs is not None and int(ck["fa_sample_seed"]) != self.sample_seed:
+                raise RuntimeError("the rollout graph is already captured with another sample_seed: load() before reset()")
+            self.sample_seed = int(ck["fa_sample_seed"])
 
     # ---- ensemble of frozen attacker strategies (train_fortattack_v2.py, learner.py:119-140) ----
     def load_attacker_ensemble(self, checkpoints, hidden_dim=128):
@@ -641,18 +679,26 @@ class BatchedLearner(object):
         acc = torch.zeros(2, 3, device=dev)
         # Two free-running chains, one stream per team: a team's step is its own graph, nothing joins the teams
         # until the update is over.  While one chain is in the serial part of a step (reduction, unfold, clip,
-        # Adam, fold: ~0.2 ms in which it cannot use the GPU) or in the last round of its 781 tiles, the other's
+        # Adam, fold: ~0.2 ms in which it cannot use the GPU) or in the last round of its tiles, the other's
         # tiles fill the CUs.
+        # Several ranks: the chains' all-reduces are the only thing they must not do concurrently -- collectives of two
+        # communicators in flight on one device can deadlock when the ranks' stream schedulers order them differently --
+        # so events chain them in ONE order on every rank (guards' step k, attackers' step k, guards' step k + 1, ...);
+        # the graphs on either side of a collective stay concurrent.
         if "team_streams" not in g:
             g["team_streams"] = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
         main = torch.cuda.current_stream()
         for st in g["team_streams"]:
             st.wait_stream(main)
+        ordered = steps[0].g2 is not None
+        last_done = None
         for epoch in range(self.ppo_epoch):
             for k in range(0, batch, mb):
                 for ti, st in enumerate(g["team_streams"]):      # (enqueued alternately: both chains start at once)
                     with torch.cuda.stream(st):
-                        acc[ti] += steps[ti].run(rows, perms[ti][epoch][k:k + mb])
+                        done = torch.cuda.Event() if ordered else None
+                        acc[ti] += steps[ti].run(rows, perms[ti][epoch][k:k + mb], reduce_after=last_done, reduce_done=done)
+                        last_done = done
         for st in g["team_streams"]:
             main.wait_stream(st)
         return acc / (self.ppo_epoch * self.num_mini_batch)

@@ -339,6 +339,150 @@ def gen_mpnn_h128_fixture():
     print("mpnn_h128      ", {k: v.shape for k, v in rec.items() if k.endswith("obs")})
 
 
+def tensor_fingerprint(a, np):
+    """[sum, sum of absolute values, first, last, l2 norm] of a tensor in float64."""
+    a = a.detach().cpu().numpy().reshape(-1).astype(np.float64)
+    return [a.sum(), np.abs(a).sum(), a[0], a[-1], np.sqrt((a * a).sum())]
+
+
+def gen_ppo_update_fixture():
+    """The reference's JointPPO.update (rlcore/algo/ppo.py:116-204) on seed-constructed FULL-SIZE policies (h = 128;
+    weights not shipped -- the fingerprint scheme of mpnn_h128.npz proves the repo's module draws the same ones), ONE
+    full-batch minibatch (ppo_epoch 1, num_mini_batch 1: the sampler's permutation only reorders a sum), 3v3 and 5v5,
+    both teams, clipped and un-clipped value loss.  Recorded: the rollout rows in the joint (B, N, .) layout, the
+    normalised advantages (ppo.py:121-123), the three losses update() returns, and -- read off the reference's
+    parameters after the call -- the clipped gradients (p.grad after clip_grad_norm_) and the Adam displacement
+    (weights after - before): fingerprints of every tensor, every element of the small ones, a strided sample of the
+    large ones.  Closes the chain reference -> fa_ppo_grad / fa_adam_step on the GPU box without a hop through this
+    repo's autograd restatement."""
+    import torch
+    rh.import_reference()
+    torch.set_num_threads(1)
+    from mpnn import MPNN
+    from rlcore.algo.ppo import JointPPO
+    from rlcore.storage import RolloutStorage
+
+    class _Sp(object):
+        shape = (8,)
+
+    clip, vcoef, ecoef, lr = 0.2, 0.5, 0.01, 1e-4                  # arguments.py:22-45 defaults
+    rec = {}
+    # (max_grad_norm 0.5 is the default; the gradient norms here are 0.2 .. 0.5, so two cases lower it to make
+    #  clip_grad_norm_ actually scale)
+    cases = [("3v3_g_clip", 3, 3, 0, True, 31, 4, 64, 0.5), ("3v3_a_noclip", 3, 3, 1, False, 32, 4, 64, 0.1),
+             ("5v5_g_clip", 5, 5, 0, True, 33, 3, 50, 0.5), ("5v5_a_clip", 5, 5, 1, True, 34, 3, 50, 0.15)]
+    for tag, G, A, team, clipped, seed, T, P, gnorm in cases:
+        N = G + A
+        n, m = (G, A) if team == 0 else (A, G)
+        own = slice(0, G) if team == 0 else slice(G, N)
+        opp = slice(G, N) if team == 0 else slice(0, G)
+        torch.manual_seed(seed)
+        net = MPNN(action_space=_Sp(), num_agents=n, num_opp_agents=m, num_entities=0, input_size=6, pos_index=2,
+                   mask_dist=None, entity_mp=False, policy_layers=1)
+        mpnn_h128_setup(net, torch)
+        rec[tag + ".fingerprint"] = mpnn_fingerprint(net, np)
+        g = torch.Generator().manual_seed(seed + 100)
+        B = T * P
+        obs = torch.randn((T + 1, P, N, 6), generator=g)
+        obs[..., 0] = (torch.rand((T + 1, P, N), generator=g) > 0.3).float()      # alive flags = the loss masks (ppo.py:224)
+        obs[..., 3] = obs[..., 3] * 3 + 4.7
+        actions = torch.randint(0, 8, (T, P, N, 1), generator=g)
+        value_preds = torch.randn((T + 1, P, N, 1), generator=g)
+        returns = value_preds + 0.6 * torch.randn((T + 1, P, N, 1), generator=g)   # some inside, some outside the value clip
+        # old log-probs: the policy's own log-probs of these actions + noise, so that the ratios straddle [1-clip, 1+clip]
+        with torch.no_grad():
+            flat = lambda t, sl: t[:T, :, sl].reshape(B, -1, t.shape[-1]).transpose(0, 1).reshape(-1, t.shape[-1])
+            _, lp, _, _ = net.evaluate_actions(flat(obs, own), None, flat(obs, opp), None, flat(actions, own))
+        old_logp = torch.randn((T, P, N, 1), generator=g)
+        old_logp[:, :, own] = lp.view(n, T, P, 1).permute(1, 2, 0, 3) + 0.25 * torch.randn((T, P, n, 1), generator=g)
+
+        def storage(i):
+            s = RolloutStorage(T, P, (6,), None, 1)
+            s.obs.copy_(obs[:, :, i])
+            s.actions.copy_(actions[:, :, i])
+            s.action_log_probs.copy_(old_logp[:, :, i])
+            s.value_preds.copy_(value_preds[:, :, i])
+            s.returns.copy_(returns[:, :, i])
+            return s
+
+        own_st = [storage(i) for i in range(own.start, own.stop)]
+        opp_st = [storage(i) for i in range(opp.start, opp.stop)]
+        adv = torch.zeros((T, P, N, 1))
+        for i in range(N):                                           # ppo.py:121-123, per agent
+            a = returns[:-1, :, i] - value_preds[:-1, :, i]
+            adv[:, :, i] = (a - a.mean()) / (a.std() + 1e-5)
+        before = [p.detach().clone() for p in net.parameters()]
+        ppo = JointPPO(net, clip, 1, 1, vcoef, ecoef, lr=lr, max_grad_norm=gnorm, use_clipped_value_loss=clipped)
+        with rh.quiet():
+            vl, al, ent = ppo.update(own_st, opp_st)
+        rec[tag + ".meta"] = np.array([G, A, team, int(clipped), seed, T, P], np.int64)
+        rec[tag + ".hyper"] = np.array([clip, vcoef, ecoef, lr, gnorm], np.float64)
+        rec[tag + ".obs"] = obs[:T].reshape(B, N, 6).numpy()
+        rec[tag + ".actions"] = actions.reshape(B, N, 1).numpy().astype(np.int8)
+        rec[tag + ".value_preds"] = value_preds[:T].reshape(B, N, 1).numpy()
+        rec[tag + ".returns"] = returns[:T].reshape(B, N, 1).numpy()
+        rec[tag + ".old_logp"] = old_logp.reshape(B, N, 1).numpy()
+        rec[tag + ".adv"] = adv.reshape(B, N, 1).numpy()
+        rec[tag + ".losses"] = np.array([vl, al, ent], np.float64)
+        names = [k for k, _ in net.named_parameters()]
+        rec[tag + ".param_names"] = np.array(names)
+        gfp, dfp = [], []
+        for k, p, b in zip(names, net.parameters(), before):
+            # (a parameter the forward never touches -- oppUpdate, mpnn.py:44 -- has no gradient and does not move)
+            grad = p.grad.detach() if p.grad is not None else torch.zeros_like(p)
+            delta = p.detach() - b
+            gfp.append(tensor_fingerprint(grad, np))
+            dfp.append(tensor_fingerprint(delta, np))
+            stride = 1 if grad.numel() <= 1024 else 61               # small tensors whole, large ones sampled
+            rec["%s.grad.%s" % (tag, k)] = grad.reshape(-1)[::stride].numpy()
+            rec["%s.delta.%s" % (tag, k)] = delta.reshape(-1)[::stride].numpy()
+        rec[tag + ".grad_fingerprint"] = np.array(gfp, np.float64)
+        rec[tag + ".delta_fingerprint"] = np.array(dfp, np.float64)
+        ratio_out = float(((torch.exp(lp.view(n, T, P, 1).permute(1, 2, 0, 3) - old_logp[:, :, own]) - 1).abs() > clip).float().mean())
+        print("ppo_update %-13s losses=%s |g|=%.4f ratios outside the clip range: %.0f%%" % (
+            tag, np.round(rec[tag + ".losses"], 5).tolist(), float(np.sqrt((np.array(gfp)[:, 4] ** 2).sum())), 100 * ratio_out))
+    np.savez_compressed(os.path.join(OUT, "ppo_update_h128.npz"), **rec)
+
+
+def gen_attackers_fixture():
+    """BASELINE config 5 with the PUBLISHED policies: the attacker state_dicts (entry -1 of 'models', learner.py:137-139) of
+    the reference's shipped checkpoints marlsave/tmp_1/ep{220,650,1240,1600,2520}.pt (arguments.py --attacker-ckpts) --
+    weights are data -- together with the reference mpnn.py's outputs for them on a fixed 5v5 observation batch."""
+    import torch
+    rh.import_reference()
+    torch.set_num_threads(1)
+    from mpnn import MPNN
+
+    class _Sp(object):
+        shape = (8,)
+
+    eps = [220, 650, 1240, 1600, 2520]
+    G = A = 5
+    N, B = G + A, 64
+    g = torch.Generator().manual_seed(505)
+    obs = torch.randn((B, N, 6), generator=g)
+    obs[:, :, 0] = (torch.rand((B, N), generator=g) > 0.25).float()
+    obs[:, :, 1:3] = obs[:, :, 1:3].clamp(-1, 1) * 0.8
+    obs[:, :, 3] = obs[:, :, 3] * 2 + 3.1
+    rec = {"episodes": np.array(eps, np.int64), "obs": obs.numpy(), "meta": np.array([G, A, B], np.int64)}
+    for e in eps:
+        ck = torch.load(os.path.join(rh.REFERENCE_ROOT, "marlsave", "tmp_1", "ep%d.pt" % e), map_location="cpu", weights_only=False)
+        sd = ck["models"][-1]
+        net = MPNN(action_space=_Sp(), num_agents=A, num_opp_agents=G, num_entities=0, input_size=6, pos_index=2,
+                   mask_dist=None, entity_mp=False, policy_layers=1)
+        net.load_state_dict(sd)
+        for k, v in sd.items():
+            rec["ep%d.%s" % (e, k)] = v.numpy()
+        with torch.no_grad():
+            inp = obs[:, G:].transpose(0, 1).reshape(-1, 6)          # agent-major (learner.py:150-152)
+            oin = obs[:, :G].transpose(0, 1).reshape(-1, 6)
+            x = net._fwd(inp, oin, None)
+            rec["ep%d.out.value" % e] = net._value(x).view(A, B).transpose(0, 1).numpy()
+            rec["ep%d.out.logp_all" % e] = net.dist(net._policy(x)).logits.view(A, B, 8).transpose(0, 1).numpy()
+    np.savez_compressed(os.path.join(OUT, "attackers_tmp1.npz"), **rec)
+    print("attackers_tmp1 ", eps, "max p(action) = %.3f" % max(float(np.exp(rec["ep%d.out.logp_all" % e]).max()) for e in eps))
+
+
 def gen_choice_fixture():
     """The ensemble path's RNG interleaving: train_fortattack_v2.py follows EVERY
     env.reset() -- the first one (:29-35) and each episode-end one (:104-111) -- with
@@ -377,7 +521,11 @@ def gen_choice_fixture():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["mt", "env", "collector", "mpnn", "mpnn128", "choice"]
+    which = sys.argv[1:] or ["mt", "env", "collector", "mpnn", "mpnn128", "choice", "ppo", "attackers"]
+    if "ppo" in which:
+        gen_ppo_update_fixture()
+    if "attackers" in which:
+        gen_attackers_fixture()
     if "choice" in which:
         gen_choice_fixture()
     if "mt" in which:

@@ -380,3 +380,34 @@ def test_flat_adam_step_matches_torch_adam_after_clip(fa):
                 assert (names[k].detach() - p.detach()).abs().max() <= 2e-6 * max(1.0, float(p.detach().abs().max())), (it, k)
                 assert (names[k].grad - p.grad).abs().max() <= 5e-5 * max(1e-3, float(p.grad.abs().max())), (it, k)   # (the norms are summed in different orders)
     assert float(fp.steps.min()) == 4.0 and float(fp.steps.max()) == 4.0
+
+
+def test_published_attackers_through_the_fused_kernel_and_the_ensemble_loader(fa, golden_dir):
+    """BASELINE config 5 with the PUBLISHED policies (reference learner.py:119-140, train_fortattack_v2.py:29-35): the
+    attacker policies of marlsave/tmp_1/ep{220,650,1240,1600,2520}.pt (tests/golden/attackers_tmp1.npz: weights as data +
+    the reference mpnn.py's outputs on a fixed 5v5 batch) loaded by BatchedLearner.load_attacker_ensemble and run by
+    fa_policy_kernel's grouped-by-strategy launch: every env's attacker values / log-probs are the reference's for the
+    strategy that env plays."""
+    from test_mpnn_cpu import attacker_pool_from_golden
+    z, pool, G, A = attacker_pool_from_golden(fa.MPNN, golden_dir)
+    N, K = G + A, len(pool)
+    obs = torch.from_numpy(z["obs"]).cuda().contiguous()
+    B = obs.shape[0]
+    eng = fa.BatchedFortAttack(B, G, A, 20)
+    L = fa.BatchedLearner(eng, num_steps=4, num_mini_batch=1, ppo_epoch=1)
+    assert L.policy_backend == "hip"
+    L.load_attacker_ensemble([{"models": [None] * G + [p.state_dict()] * A, "ob_rms": (None, None)} for p in pool])
+    assert L._packed_pool is not None and L._packed_pool.shape[0] == K and L.policy_backend == "hip"
+    eps = [int(e) for e in z["episodes"]]
+    for shift in range(K):                                        # every env meets every strategy once
+        strat = ((torch.arange(B) + shift) % K).to(torch.int32).cuda()
+        v, act, lp = eng.policy_act(obs, L._packed[0], None, deterministic=True, pool=L._packed_pool, env_strategy=strat)
+        want_v = torch.stack([torch.from_numpy(z["ep%d.out.value" % e]) for e in eps]).cuda()[strat.long(), torch.arange(B).cuda()]
+        want_lp = torch.stack([torch.from_numpy(z["ep%d.out.logp_all" % e]) for e in eps]).cuda()[strat.long(), torch.arange(B).cuda()]
+        # trained policies: values up to +-20, logits up to +-40 -- fp32 folded algebra is ~1e-6 RELATIVE to those
+        assert (v[:, G:] - want_v).abs().max() < 1e-5 * float(want_v.abs().max()) + 1e-5
+        got_lp = lp[:, G:]
+        assert (got_lp - want_lp.gather(-1, act[:, G:].unsqueeze(-1))[..., 0]).abs().max() < 2e-4
+        top2 = want_lp.topk(2, dim=-1).values
+        clear = (top2[..., 0] - top2[..., 1]) > 1e-3
+        assert torch.equal(act[:, G:][clear], want_lp.argmax(-1)[clear])

@@ -298,8 +298,8 @@ def test_bench_self_launches_two_ranks():
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-devices", "--backend",
-                          "gloo", "--envs", "512", "--rollout", "32", "--steps", "3", "--warmup", "1", "--min-seconds",
-                          "0", "--no-cpu-baseline", "--closed-loop-rollouts", "1"],
+                          "gloo", "--envs", "512", "--rollout", "32", "--steps", "3", "--warmup", "1",
+                          "--no-cpu-baseline", "--closed-loop-rollouts", "1"],
                          cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -309,3 +309,29 @@ def test_bench_self_launches_two_ranks():
     assert r["roofline"]["frac"] > 0 and r["closed_loop"]["rollout_env_steps_per_s"] > 0
     assert r["closed_loop"]["train_env_steps_per_s"] > 0
     assert r["collective"]["ranks"] == 2 and r["collective"]["backend"] == "gloo"
+
+
+def test_bench_eight_rank_rehearsal_on_one_gpu(tmp_path):
+    """The 8-way form of BASELINE configs 4 / 5 as far as one GPU can rehearse it: `bench.py --gpus 8 --share-devices
+    --backend gloo` -- eight ranks, eight env shards, the all-gather of the advantage moments over eight ranks, the
+    per-team process groups and the fused two-chain update with event-ordered all-reduces -- must rendezvous, finish,
+    report eight ranks in the collective and leave every rank with bit-identical parameters."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--share-devices", "--backend",
+                          "gloo", "--envs", "512", "--rollout", "32", "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
+                          "--closed-loop-rollouts", "2", "--closed-loop-updates", "1"],
+                         cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 8 and r["steps"] == 3 and r["steps_requested"] == 3 and r["value"] > 0
+    assert r["collective"]["ranks"] == 8 and len(r["collective"]["rank_binding"]) == 8
+    assert sorted(b["rank"] for b in r["collective"]["rank_binding"]) == list(range(8))
+    assert r["closed_loop"]["ranks_hold_identical_parameters"] is True
+    assert r["closed_loop"]["train_env_steps_per_s"] > 0
+    rec = os.environ.get("FA_REHEARSAL_RECORD")
+    if rec:
+        open(rec, "w").write(lines[0] + "\n")

@@ -276,3 +276,32 @@ def test_flat_policy_layout_on_cpu():
     p.data = p.data.clone()
     assert not fp.attached()
     assert mp_.FlatPolicy.of(pol) is not fp                                # a detached one is rebuilt, not reused
+
+
+def attacker_pool_from_golden(MPNN, golden_dir, device="cpu"):
+    """The reference's published attacker policies (marlsave/tmp_1/ep*.pt, exported as data into
+    tests/golden/attackers_tmp1.npz by oracle/gen_golden.py) as this repo's modules."""
+    z = np.load(os.path.join(golden_dir, "attackers_tmp1.npz"))
+    G, A, B = [int(v) for v in z["meta"]]
+    pool = []
+    for e in [int(e) for e in z["episodes"]]:
+        sd = {k[len("ep%d." % e):]: torch.from_numpy(z[k]) for k in z.files if k.startswith("ep%d." % e) and ".out." not in k}
+        pol = MPNN(num_agents=A, num_opp_agents=G, num_actions=8)
+        res = pol.load_state_dict(sd, strict=True)
+        assert not res.missing_keys and not res.unexpected_keys
+        pool.append(pol.to(device).eval())
+    return z, pool, G, A
+
+
+def test_published_attackers_forward_matches_the_reference(MPNN, golden_dir):
+    """Config 5's frozen strategies: the five shipped checkpoints' attacker policies through this repo's module
+    reproduce the reference mpnn.py's values and log-softmax logits on the fixture's 5v5 observations."""
+    z, pool, G, A = attacker_pool_from_golden(MPNN, golden_dir)
+    obs = torch.from_numpy(z["obs"])
+    for e, pol in zip([int(e) for e in z["episodes"]], pool):
+        with torch.no_grad():
+            lg, v = pol.logits_value(obs[:, G:], obs[:, :G])
+        # (trained policies: logits up to +-40, values up to +-30 -- float32 association differences scale with them)
+        want_v, want_lp = z["ep%d.out.value" % e], z["ep%d.out.logp_all" % e]
+        assert np.abs(v[..., 0].numpy() - want_v).max() < 2e-5 * max(1.0, np.abs(want_v).max()), e
+        assert np.abs(torch.log_softmax(lg, -1).numpy() - want_lp).max() < 1e-4, e
