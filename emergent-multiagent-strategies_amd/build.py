@@ -7,7 +7,7 @@ CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB = os.path.join(CSRC, "libfortattack_hip.so")
 OBJ = os.path.join(CSRC, "_obj")            # objects + assembly of the last build (git-ignored)
-SOURCES = ["fa_step.hip", "fa_collect.hip", "fa_policy.hip", "fa_attend.hip", "fa_train.hip", "fa_fold.hip", "fa_rccl.hip", "fa_api.hip"]
+SOURCES = ["fa_step.hip", "fa_collect.hip", "fa_policy.hip", "fa_attend.hip", "fa_train.hip", "fa_train_dw.hip", "fa_fold.hip", "fa_rccl.hip", "fa_api.hip"]
 # -ffp-contract=off: the fp64 step must evaluate every operation as the reference does
 # (no fused multiply-add); no -ffast-math for the same reason.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]

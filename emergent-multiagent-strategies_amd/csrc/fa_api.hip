@@ -601,7 +601,10 @@ int fa_ppo_grad_scratch(int32_t B, int32_t G, int32_t A, int64_t *slab_floats, i
         return fail(FA_ERR_INVALID, "fa_ppo_grad_scratch: need B >= 1 and teams of 1..8");
     const int et = fa_train_tile_envs(G, A);
     const int64_t tiles = (B + et - 1) / et;
-    if (slab_floats) *slab_floats = tiles * FA_SLAB_FLOATS + FA_MASK_PARTS;
+    // slabs: the tiles' small gradients | their stage-1 sums | the partial slabs of the weight-gradient GEMM | mask sums
+    if (slab_floats) *slab_floats = tiles * FA_MSLAB_FLOATS + (int64_t)FA_MRED_PARTS * FA_MSLAB_FLOATS +
+                                    (int64_t)FA_DW_WGS_A * FA_DWA_FLOATS + (int64_t)FA_DW_WGS_B * FA_DWB_FLOATS + FA_MASK_PARTS;
+    // hsave: the records of the weight-gradient GEMM's operands: [tiles][3] x A, then [tiles] x B
     if (hsave_floats) *hsave_floats = tiles * FA_TR_SAVE_FLOATS;
     return FA_OK;
 }
@@ -618,22 +621,28 @@ int fa_ppo_grad(const fa_ppo_grad_io *io, void *stream) {
     std::memset(&a, 0, sizeof(a));
     a.obs = io->obs; a.action = io->action; a.value_pred = io->value_pred; a.ret = io->ret;
     a.old_logp = io->old_log_prob; a.adv = io->adv; a.w = io->weights; a.wt = io->weights_t;
-    a.slabs = io->slabs; a.hsave = io->hsave; a.scale = io->scale; a.idx = io->idx;
+    a.scale = io->scale; a.idx = io->idx;
     a.B = io->B; a.G = io->num_guards; a.A = io->num_attackers; a.team = io->team;
     a.clip = io->clip_param; a.c_value = io->value_loss_coef; a.c_entropy = io->entropy_coef;
     a.clipped_value_loss = io->clipped_value_loss;
     a.share_cu = io->share_cu != 0 && io->idx != nullptr;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int et = fa_train_tile_envs(a.G, a.A);
-    if (!a.scale) { // partial mask sums behind the tiles' slabs; the scale pair is left behind the loss sums of `out`
-        float *part = io->slabs + (size_t)((a.B + et - 1) / et) * FA_SLAB_FLOATS;
+    const size_t tiles = (size_t)((a.B + et - 1) / et);
+    float *mpart = io->slabs + tiles * FA_MSLAB_FLOATS, *dw_slabs = mpart + (size_t)FA_MRED_PARTS * FA_MSLAB_FLOATS;
+    a.mslab = io->slabs;
+    a.rec_a = io->hsave;
+    a.rec_b = io->hsave + tiles * 3 * FA_RECA_FLOATS;
+    if (!a.scale) { // partial mask sums behind the partial slabs; the scale pair is left behind the loss sums of `out`
+        float *part = dw_slabs + (size_t)FA_DW_WGS_A * FA_DWA_FLOATS + (size_t)FA_DW_WGS_B * FA_DWB_FLOATS;
         FA_HIP(fa_launch_mask_parts(a, part, s));
         a.mask_part = part;
         a.scale_out = io->out + FA_SLAB_LOSS + 8;
         a.normalize = io->normalize != 0;
     }
-    FA_HIP(fa_launch_train(a, s));
-    FA_HIP(fa_launch_train_reduce(io->slabs, (a.B + et - 1) / et, io->out, s));
+    FA_HIP(fa_launch_train(a, s));                                                  // tiles: forward, losses, dL/dX
+    FA_HIP(fa_launch_train_dw(a.rec_a, a.rec_b, (int)tiles, dw_slabs, s));          // dW = X^T dY over all rows
+    FA_HIP(fa_launch_train_reduce(a.mslab, (int)tiles, mpart, dw_slabs, io->out, s)); // fixed-order sums -> out
     return FA_OK;
 }
 

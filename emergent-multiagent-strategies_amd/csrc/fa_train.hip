@@ -1,27 +1,28 @@
-// fa_train.hip -- one team's PPO minibatch in ONE launch: the MPNN forward (as fa_policy.hip, folded algebra),
-// the alive-masked clipped PPO losses of JointPPO.update (reference rlcore/algo/ppo.py:146-187) and the COMPLETE
-// backward pass down to the gradients of every kernel-facing matrix, for a tile of 64 (env, agent) rows per
-// workgroup held in four LDS buffers.
+// fa_train.hip -- one team's PPO minibatch: the MPNN forward (as fa_policy.hip, folded algebra), the alive-masked
+// clipped PPO losses of JointPPO.update (reference rlcore/algo/ppo.py:146-187) and the backward pass down to dL/dX of
+// every layer, for a tile of 32 (env, agent) rows per workgroup held in four LDS buffers.  The WEIGHT gradients
+// dW = X^T dY are not made here: the tile leaves their operands in global memory and fa_train_dw_kernel
+// (fa_train_dw.hip) sums them over all rows of the minibatch as one split-K GEMM.
 //
 // Why: as PyTorch autograd the optimizer step is ~160 launches and 2.65 ms at 16 384 x 3 samples, of which the
-// GEMMs (hipBLASLt, 45 TFLOP/s on (49 152 x 128) x (128 x 128); the weight gradients through a split-K bmm +
-// sum) are less than half; the rest is bias / relu / add / reduction kernels over (49 152 x 128) tensors.  Here
-// the activations of a tile never leave the CU between layers; per layer the backward is two MFMA GEMMs
-// (dX = dY W^T with the transposed weights streamed from L2 like the forward's; dW = X^T dY with BOTH operands
-// read from LDS) and the elementwise work is folded into the accumulator stores.
+// GEMMs are less than half; the rest is bias / relu / add / reduction kernels over (49 152 x 128) tensors.  Here the
+// activations of a tile never leave the CU between layers and the elementwise work is folded into the accumulator
+// stores.
 //
-// Weight gradients: a tile writes its partial dW set to its own slab (plain row-major, 390 KB); a second small
-// kernel sums the slabs in tile order -- no atomics, bitwise reproducible.  dA_m, dW7 (shared by the three
-// message-passing rounds) are accumulated in registers across the rounds.  Around it (learner.GraphedPPOStep):
-// fa_fold.hip builds the weight packs from the module's parameters and carries the gradients back to them; the
-// alive-mask mean (fa_mask_part_kernel, folded by every workgroup here), the gradient-norm clip and Adam
-// (fa_sqnorm_part_kernel, fa_adam_kernel) are at the end of this file.
+// Shape (round 4).  Rounds 2-3 ran one 64-row tile per CU on eight waves and kept the weight gradients shared by the
+// three message-passing rounds (dW7, dA_m: 96 accumulator registers per lane) live across the rounds, each tile writing
+// a 390 KB gradient slab: 0.32 of the fp32 MFMA peak, 2 GB of HBM traffic per launch, half of it register spills, and
+// every non-GEMM phase (attention, relu masks, tile reloads, barriers) ran with the matrix pipes idle because all eight
+// waves march through the same phases.  Now: a 32-row tile on FOUR waves (a wave owns one 32 x 32 output tile of a
+// 32 x 128 layer: column block = wave), 81 KB of LDS, so TWO workgroups share a CU and one's attention / store /
+// barrier phases run under the other's MFMA chains; no accumulator lives longer than one GEMM; per tile 10 KB of small
+// gradients (encoders, biases, the 1 152 real entries of dW9) instead of 390 KB.
 //
-// Saved for the backward: the hidden state after the opponent stage and after rounds 1 and 2 (global scratch,
-// 96 KB per tile), all attention weights (LDS); g = h A, the attention mixes and the opponents' encodings are
-// recomputed (cheaper than a round trip).
+// Saved for the backward and for fa_train_dw_kernel (fa_train.h FA_RECA_* / FA_RECB_*): per round the hidden state
+// entering it, the attention mix, dZ and dg; per tile h3, [dP | dV], and the opponent stage's mix_o, de_opp, h1, dg_o;
+// all attention weights stay in LDS.  g = h A and the opponents' encodings are recomputed (cheaper than a round trip).
 //
-// Buffers (64 x 132 floats each): B0 = h (forward) / h_in of the round being differentiated; B1 = g, hmix, P;
+// Buffers (32 x 132 floats each): B0 = h (forward) / h_in of the round being differentiated; B1 = g, hmix, P;
 // B2 = ho, V, recomputed g; B3 = the running dL/dh.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -33,46 +34,33 @@
 
 namespace {
 constexpr int TR = FA_TR_ROWS;
-// Eight waves per workgroup, two per SIMD (still one workgroup per CU: the four 64-row buffers fill the LDS).  A wave
-// owns ONE 32 x 32 output tile of a 64 x 128 layer -- column block wave & 3, row block wave >> 2 -- so a SIMD's two
-// waves share a column block's weights and its MFMA work is what one wave did in round 2; but while one of them
-// stores accumulators, waits for an LDS / L2 read or sits at a barrier the other's MFMA chain runs, the row-wise phases
-// (attention forward / backward, relu masks, tile loads) have twice the waves to hide their latencies with, and the
-// weight-gradient accumulators that live across the three rounds are 96 registers per lane instead of 192.
-constexpr int NWV = 8, NTH = NWV * 64;
+constexpr int NWV = 4, NTH = NWV * 64;
 constexpr int SOW = 32; // row stride of the head-output buffer sO (9 used: 8 logits + value)
 
-// acc (32 x 32) += X[rows][32 cols at X]^T * DY[rows][32 cols at DY] over the tile's 64 rows: both operands
+// acc (32 x 32) += X[rows][32 cols at X]^T * DY[rows][32 cols at DY] over the tile's 32 rows: both operands
 // from LDS, one float each per MFMA (A[i][kk] = X[row kk][i], B[kk][j] = DY[row kk][j]; lane half hh walks
-// rows hh*32 .. hh*32+31)
+// rows hh*16 .. hh*16+15)
 __device__ __forceinline__ void gemm_tn(const float *X, int ldx, const float *DY, int ldy, f32x16 &acc, int lane) {
     const int li = lane & 31, hh = lane >> 5;
-    const float *xp = X + (hh * 32) * ldx + li, *yp = DY + (hh * 32) * ldy + li;
+    const float *xp = X + (hh * (TR / 2)) * ldx + li, *yp = DY + (hh * (TR / 2)) * ldy + li;
 #pragma unroll
-    for (int t = 0; t < 32; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xp[t * ldx], yp[t * ldy], acc, 0, 0, 0);
-}
-
-// accumulator tile -> plain row-major global matrix with row length C
-__device__ __forceinline__ void store_tile_global(float *dst, int C, const f32x16 &acc, int lane) {
-    const int col = lane & 31, hh = lane >> 5;
-#pragma unroll
-    for (int reg = 0; reg < 16; ++reg) dst[((reg & 3) + 8 * (reg >> 2) + 4 * hh) * C + col] = acc[reg];
+    for (int t = 0; t < TR / 2; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xp[t * ldx], yp[t * ldy], acc, 0, 0, 0);
 }
 
 // dst += acc  /  dst = (dst > 0 ? acc : 0)   on an LDS tile (the lane that stores an element also owns its old value)
-__device__ __forceinline__ void store_acc_add(float *dst, int rb, const f32x16 &acc, int lane) {
+__device__ __forceinline__ void store_acc_add(float *dst, const f32x16 &acc, int lane) {
     const int col = lane & 31, hh = lane >> 5;
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
-        float *p = dst + (rb * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * hh) * LDA + col;
+        float *p = dst + ((reg & 3) + 8 * (reg >> 2) + 4 * hh) * LDA + col;
         *p += acc[reg];
     }
 }
-__device__ __forceinline__ void store_acc_relu_mask(float *dst, int rb, const f32x16 &acc, int lane) {
+__device__ __forceinline__ void store_acc_relu_mask(float *dst, const f32x16 &acc, int lane) {
     const int col = lane & 31, hh = lane >> 5;
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
-        float *p = dst + (rb * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * hh) * LDA + col;
+        float *p = dst + ((reg & 3) + 8 * (reg >> 2) + 4 * hh) * LDA + col;
         *p = *p > 0.0f ? acc[reg] : 0.0f;
     }
 }
@@ -169,29 +157,26 @@ __device__ __forceinline__ void attend_env_bwd(const float *dout0, float *g0, co
 }
 
 // GATHER: the minibatch is rows a.idx[.] of the rollout arrays (else rows 0..B)
-// SHARE: amdgpu_num_vgpr(116) = 232 of the 256 registers a wave may have with two waves per SIMD (the cap counts
-// architectural and accumulation registers separately), i.e. 464 of a SIMD's 512 per lane.  Uncapped the kernel takes
-// all 512 -- and then NOTHING else fits on a CU it occupies: when the two teams' updates run as concurrent chains, the
-// other team's small launches (fold / unfold tasks at 48 registers, the slab reduction, clip, Adam) wait for whole
-// tiles to retire (round 2, four waves: fa_task_kernel 134 us in flight instead of 11; cap 232 of 256 per SIMD-half:
-// update 0.276 -> 0.260 s).  Eight waves: uncapped 0.268 s per update, capped 0.253 s; a lone chain (guards-only
-// training, FaTrainArgs::share_cu = 0) runs the uncapped build.
+// SHARE: a register cap (amdgpu_num_vgpr counts architectural and accumulation registers separately) that leaves room
+// on a CU for the other team's small launches when the two teams' updates run as concurrent chains (fold / unfold
+// tasks, reductions, clip, Adam); a lone chain (guards-only training, FaTrainArgs::share_cu = 0) runs the uncapped build.
 #ifndef FA_TRAIN_NUM_VGPR
-#define FA_TRAIN_NUM_VGPR 116
+#define FA_TRAIN_NUM_VGPR 104
 #endif
-template <bool GATHER>
+// MT: the attention backward's key / key-gradient registers are sized for teams of up to MT agents (4, 6 or 8)
+template <bool GATHER, int MT>
 __device__ __forceinline__ void fa_train_body(const FaTrainArgs &a) {
     __shared__ __attribute__((aligned(16))) float B0[TR * LDA], B1[TR * LDA], B2[TR * LDA], B3[TR * LDA];
     __shared__ float sX[TR * 2 * FA_OBS_DIM];
     __shared__ __attribute__((aligned(16))) float sO[TR * SOW];
     __shared__ float sAttn[4][TR * 8]; // [opponent stage, round 0, 1, 2][row][key]
-    __shared__ __attribute__((aligned(16))) float sO2[TR * SOW]; // the opponent side's [x | 1] rows (encoder backward)
+    __shared__ __attribute__((aligned(16))) float sO2[TR * SOW]; // bias partial sums; the opponent side's [x | 1] rows
 
     // `wave` as a scalar: conditions on it become scalar branches, not exec-masked regions (cheaper, and see
     // tools/isa_lint.py for why this kernel wants as few exec-masked joins as possible)
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, hh = lane >> 5, q16 = lane & 15;
-    const int cbw = wave & 3, rbw = wave >> 2; // this wave's column / row block of a 64 x 128 layer
+    const int cbw = wave; // this wave's column block of a 32 x 128 layer
     const int N = a.G + a.A;
     const int n = a.team == 0 ? a.G : a.A, m = N - n;
     const int own0 = a.team == 0 ? 0 : a.G, opp0 = a.team == 0 ? a.G : 0;
@@ -202,16 +187,26 @@ __device__ __forceinline__ void fa_train_body(const FaTrainArgs &a) {
     const int RU = ET * n, RO = ET * m; // rows in use (own / opponent side); envs beyond `ne` are zero rows
     const float *W = a.w;
     const float4 *Wq = reinterpret_cast<const float4 *>(a.w), *Tq = reinterpret_cast<const float4 *>(a.wt);
-    float *slab = a.slabs + (size_t)blockIdx.x * FA_SLAB_FLOATS;
-    float *hsave = a.hsave + (size_t)blockIdx.x * FA_TR_SAVE_FLOATS;
+    float *mslab = a.mslab + (size_t)blockIdx.x * FA_MSLAB_FLOATS;
+    float *recA = a.rec_a + (size_t)blockIdx.x * 3 * FA_RECA_FLOATS, *recB = a.rec_b + (size_t)blockIdx.x * FA_RECB_FLOATS;
 
-    auto save_tile = [&](const float *src, float *dst) { // 64 x 128 LDS -> global
+    // dense tile <-> LDS: W floats per row (128: four 16-byte pieces per thread; 64: two)
+    auto save_tile = [&](const float *src, float *dst) { // 32 x 128 LDS -> global
+#pragma unroll
         for (int k = tid; k < TR * 32; k += NTH) {
             const int r = k >> 5, c4 = k & 31;
             reinterpret_cast<float4 *>(dst)[k] = *reinterpret_cast<const float4 *>(src + r * LDA + c4 * 4);
         }
     };
+    auto save_tile64 = [&](const float *src, float *dst) { // 32 x 64 LDS (at src, row stride LDA) -> global
+#pragma unroll
+        for (int k = tid; k < TR * 16; k += NTH) {
+            const int r = k >> 4, c4 = k & 15;
+            reinterpret_cast<float4 *>(dst)[k] = *reinterpret_cast<const float4 *>(src + r * LDA + c4 * 4);
+        }
+    };
     auto load_tile = [&](float *dst, const float *src) {
+#pragma unroll
         for (int k = tid; k < TR * 32; k += NTH) {
             const int r = k >> 5, c4 = k & 31;
             *reinterpret_cast<float4 *>(dst + r * LDA + c4 * 4) = reinterpret_cast<const float4 *>(src)[k];
@@ -249,23 +244,22 @@ __device__ __forceinline__ void fa_train_body(const FaTrainArgs &a) {
             dst_opp[r * LDA + col] = v;
         }
     };
-    // g_o = h1 A_o -> B1[:, 64:128]  (64 output columns: column block wave & 1, row block wave >> 1)
+    // g_o = h1 A_o -> B1[:, 64:128]  (64 output columns: waves 0, 1 = the two column blocks)
     auto project_opp = [&]() {
-        if (wave >= 4) return;
+        if (wave >= 2) return;
         BHead<64> hd;
-        const float4 *wp = Wq + FA_POFF_AO / 4 + (wave & 1) * 8 * 64;
+        const float4 *wp = Wq + FA_POFF_AO / 4 + wave * 8 * 64;
         prefetch_b<64>(wp, lane, hd);
         f32x16 acc[1] = {};
-        gemm_cb<64, 1>(B0 + ((wave >> 1) * 32 + li) * LDA + hh * 32, wp, acc, lane, hd);
-        store_acc<false>(B1 + 64 + (wave & 1) * 32, wave >> 1, acc[0], 0.0f, lane);
+        gemm_cb<64, 1>(B0 + li * LDA + hh * 32, wp, acc, lane, hd);
+        store_acc<false>(B1 + 64 + wave * 32, 0, acc[0], 0.0f, lane);
     };
     // g = h A_m: B0 -> dst (all 128 columns; wave = column block); `hd`: the first weights, requested earlier
     const float4 *wp_am = Wq + FA_POFF_AM / 4 + cbw * 16 * 64;
     auto project_team = [&](float *dst, const BHead<128> &hd) {
-        const float4 *wp = wp_am;
         f32x16 acc[1] = {};
-        gemm_cb<128, 1>(B0 + (rbw * 32 + li) * LDA + hh * 64, wp, acc, lane, hd);
-        store_acc<false>(dst + cbw * 32, rbw, acc[0], 0.0f, lane);
+        gemm_cb<128, 1>(B0 + li * LDA + hh * 64, wp_am, acc, lane, hd);
+        store_acc<false>(dst + cbw * 32, 0, acc[0], 0.0f, lane);
     };
 
     FA_TR_TICK(0)
@@ -288,48 +282,46 @@ __device__ __forceinline__ void fa_train_body(const FaTrainArgs &a) {
     for (int r = wave * 4 + (lane >> 4); r < TR; r += NWV * 4) // opponent attention (mpnn.py:372-443)
         if (r < RU) attend_row<64>(B1 + r * LDA + 64, B2 + ((r / n) * m) * LDA, m, -1, B1 + r * LDA + 64, q16, sAttn[0] + r * 8);
     __syncthreads();
-    if (wave < 4) {   // e_opp = mix_o B_o -> B0[:, 64:128]
+    if (wave < 2) {   // e_opp = mix_o B_o -> B0[:, 64:128]
         BHead<64> hd;
-        const float4 *wp = Wq + FA_POFF_BO / 4 + (wave & 1) * 8 * 64;
+        const float4 *wp = Wq + FA_POFF_BO / 4 + wave * 8 * 64;
         prefetch_b<64>(wp, lane, hd);
         f32x16 acc[1] = {};
-        gemm_cb<64, 1>(B1 + ((wave >> 1) * 32 + li) * LDA + 64 + hh * 32, wp, acc, lane, hd);
-        store_acc<false>(B0 + 64 + (wave & 1) * 32, wave >> 1, acc[0], 0.0f, lane);
+        gemm_cb<64, 1>(B1 + li * LDA + 64 + hh * 32, wp, acc, lane, hd);
+        store_acc<false>(B0 + 64 + wave * 32, 0, acc[0], 0.0f, lane);
     }
     FA_TR_TICK(1)
     BHead<128> hd_am; // the first weights of the next 128-deep layer, requested a phase ahead (an L2 round trip)
     prefetch_b<128>(wp_am, lane, hd_am);
     __syncthreads();
-    save_tile(B0, hsave);
+    save_tile(B0, recA + FA_RECA_HIN);
     const float4 *wpp = Wq + FA_POFF_W8 / 4 + cbw * 16 * 64, *wpv = Wq + FA_POFF_W8 / 4 + (4 + cbw) * 16 * 64;
     for (int round = 0; round < 3; ++round) {
-        FA_TR_TICK(33 + round * 7)
         project_team(B1, hd_am);
-        FA_TR_TICK(34 + round * 7)
         BHead<256> hd_u;
         const float4 *wp_u = Wq + FA_POFF_W7 / 4 + cbw * 32 * 64;
         prefetch_b<256>(wp_u, lane, hd_u);
+        FA_TR_TICK(10 + 5 * round)
         __syncthreads();
-        FA_TR_TICK(35 + round * 7)
+        FA_TR_TICK(11 + 5 * round)
         for (int r = wave * 4 + (lane >> 4); r < TR; r += NWV * 4) { // team attention, self excluded (mpnn.py:250-332)
             const int el = r / n;
             if (r < RU) attend_row<128>(B1 + r * LDA, B0 + (el * n) * LDA, n, r - el * n, B1 + r * LDA, q16, sAttn[1 + round] + r * 8);
         }
-        FA_TR_TICK(36 + round * 7)
+        FA_TR_TICK(12 + 5 * round)
         __syncthreads();
-        FA_TR_TICK(37 + round * 7)
+        FA_TR_TICK(13 + 5 * round)
         {   // h' = relu([h | hmix] W7 + bu)
             f32x16 acc[1] = {};
-            gemm_cb<256, 1>((hh ? B1 : B0) + (rbw * 32 + li) * LDA, wp_u, acc, lane, hd_u);
+            gemm_cb<256, 1>((hh ? B1 : B0) + li * LDA, wp_u, acc, lane, hd_u);
             prefetch_b<128>(round < 2 ? wp_am : wpp, lane, hd_am); // next: the following round's g, or the policy head
             const float bias = W[FA_POFF_BU + cbw * 32 + li];
-            FA_TR_TICK(38 + round * 7)
             __syncthreads();
-            store_acc<true>(B0 + cbw * 32, rbw, acc[0], bias, lane);
+            store_acc<true>(B0 + cbw * 32, 0, acc[0], bias, lane);
         }
         __syncthreads();
-        FA_TR_TICK(39 + round * 7)
-        if (round < 2) save_tile(B0, hsave + (round + 1) * TR * 128);
+        save_tile(B0, round < 2 ? recA + (round + 1) * FA_RECA_FLOATS + FA_RECA_HIN : recB + FA_RECB_H3);
+        FA_TR_TICK(14 + 5 * round)
     }
     FA_TR_TICK(2)
     {   // heads: P = relu(h Wp0 + b) -> B1, V = relu(h Wv0 + b) -> B2
@@ -337,28 +329,31 @@ __device__ __forceinline__ void fa_train_body(const FaTrainArgs &a) {
         const BHead<128> &hp = hd_am;
         prefetch_b<128>(wpv, lane, hv);
         f32x16 accp[1] = {}, accv[1] = {};
-        gemm_cb<128, 1>(B0 + (rbw * 32 + li) * LDA + hh * 64, wpp, accp, lane, hp);
-        gemm_cb<128, 1>(B0 + (rbw * 32 + li) * LDA + hh * 64, wpv, accv, lane, hv);
+        gemm_cb<128, 1>(B0 + li * LDA + hh * 64, wpp, accp, lane, hp);
+        gemm_cb<128, 1>(B0 + li * LDA + hh * 64, wpv, accv, lane, hv);
         const float bp = W[FA_POFF_B8 + cbw * 32 + li], bv = W[FA_POFF_B8 + 128 + cbw * 32 + li];
-        store_acc<true>(B1 + cbw * 32, rbw, accp[0], bp, lane);
-        store_acc<true>(B2 + cbw * 32, rbw, accv[0], bv, lane);
+        store_acc<true>(B1 + cbw * 32, 0, accp[0], bp, lane);
+        store_acc<true>(B2 + cbw * 32, 0, accv[0], bv, lane);
     }
     __syncthreads();
-    if (wave < 2) { // [logits | value] = [P | V] W9 + b9 -> sO (row block = wave)
-        BHead<256> hd;
-        prefetch_b<256>(Wq + FA_POFF_W9 / 4, lane, hd);
+    {   // [logits | value] = [P | V] W9 + b9 -> sO: the K = 256 rows split over the four waves (wave w: columns 32 w ..
+        // of P on lane half 0 and of V on half 1), partial 32 x 32 tiles summed through B3 (free until the backward)
+        BHead<64> hd;
+        const float4 *wp = Wq + FA_POFF_W9 / 4 + wave * 8 * 64;
+        prefetch_b<64>(wp, lane, hd);
         f32x16 acc[1] = {};
-        gemm_cb<256, 1>((hh ? B2 : B1) + (wave * 32 + li) * LDA, Wq + FA_POFF_W9 / 4, acc, lane, hd);
-        const float bias = W[FA_POFF_B9 + li];
+        gemm_cb<64, 1>((hh ? B2 : B1) + li * LDA + wave * 32, wp, acc, lane, hd);
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg)
-            sO[(wave * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * hh) * SOW + li] = acc[0][reg] + bias;
+        for (int reg = 0; reg < 16; ++reg) B3[wave * 1024 + ((reg & 3) + 8 * (reg >> 2) + 4 * hh) * 32 + li] = acc[0][reg];
     }
+    __syncthreads();
+    for (int k = tid; k < TR * 32; k += NTH)
+        sO[k] = (((B3[k] + B3[1024 + k]) + B3[2048 + k]) + B3[3072 + k]) + W[FA_POFF_B9 + (k & 31)];
     __syncthreads();
 
     FA_TR_TICK(3)
     // ================================ losses (ppo.py:150-187) and dL/d[logits | value] -> sO ==============
-    if (wave == 0) {
+    if (wave == 0) {   // a lane per row (lanes TR .. 63 only take part in the reductions)
         const int r = lane;
         float inv_count, unmask;
         if (a.scale) {
@@ -422,35 +417,43 @@ __device__ __forceinline__ void fa_train_body(const FaTrainArgs &a) {
             for (int k = 0; k < FA_NUM_ACTIONS; ++k)
                 dlg[k] = (g_lp * ((k == act ? 1.0f : 0.0f) - p[k]) + a.c_entropy * mk * p[k] * (lpk[k] + ent)) * inv_count;
         }
-        float *dst = sO + r * SOW;
+        if (r < TR) {
+            float *dst = sO + r * SOW;
 #pragma unroll
-        for (int k = 0; k < FA_NUM_ACTIONS; ++k) dst[k] = dlg[k];
-        dst[8] = dval;
+            for (int k = 0; k < FA_NUM_ACTIONS; ++k) dst[k] = dlg[k];
+            dst[8] = dval;
 #pragma unroll
-        for (int k = 9; k < SOW; ++k) dst[k] = 0.0f;
+            for (int k = 9; k < SOW; ++k) dst[k] = 0.0f;
+        }
         for (int off = 32; off > 0; off >>= 1) {
             vl += __shfl_down(vl, off); al += __shfl_down(al, off); en += __shfl_down(en, off); mk += __shfl_down(mk, off);
         }
-        if (lane == 0) { slab[FA_SLAB_LOSS] = vl; slab[FA_SLAB_LOSS + 1] = al; slab[FA_SLAB_LOSS + 2] = en; slab[FA_SLAB_LOSS + 3] = mk; }
+        if (lane == 0) { mslab[FA_MSLAB_LOSS] = vl; mslab[FA_MSLAB_LOSS + 1] = al; mslab[FA_MSLAB_LOSS + 2] = en; mslab[FA_MSLAB_LOSS + 3] = mk; }
     }
     __syncthreads();
 
     FA_TR_TICK(4)
     // ================================ backward =========================================================
     // ---- heads --------------------------------------------------------------------------------------
-    {   // dW9 = [P | V]^T dOUT (256 x 32): 8 k-blocks, two per wave;  db9 = column sums of dOUT
-        {
-            const int kb = wave;
+    {   // dW9 = [P | V]^T dOUT: W9 is block diagonal -- only P^T dlogits (128 x 8) and V^T dvalue (128 x 1) are gradients
+        // of parameters.  Eight 32 x 32 MFMA tiles, two per wave (k-blocks wave, wave + 4), the real entries to mslab.
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int kb = wave + 4 * half;
             f32x16 acc = {};
-            gemm_tn((kb < 4 ? B1 : B2) + (kb & 3) * 32, LDA, sO, SOW, acc, lane);
-            store_tile_global(slab + FA_POFF_W9 + kb * 32 * 32, 32, acc, lane);
+            gemm_tn((half ? B2 : B1) + wave * 32, LDA, sO, SOW, acc, lane);
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int row = (reg & 3) + 8 * (reg >> 2) + 4 * hh;
+                if (half == 0) { if (li < 8) mslab[FA_MSLAB_W9C + (kb * 32 + row) * 8 + li] = acc[reg]; }
+                else if (li == 8) mslab[FA_MSLAB_W9C + 1024 + wave * 32 + row] = acc[reg];
+            }
         }
-        {   // db9 = column sums of dOUT: sixteen 4-row partial sums per column (sO2 is free until the encoders), folded
-            // behind the next barrier -- a bias sum as one lane per column is a 64-deep serial chain on two waves
+        {   // db9 = column sums of dOUT: eight 4-row partial sums per column, folded behind the next barrier
             const int col = tid & 31, part = tid >> 5;
             float sum = 0.0f;
 #pragma unroll
-            for (int r = 0; r < TR / 16; ++r) sum += sO[(part * (TR / 16) + r) * SOW + col];
+            for (int r = 0; r < TR / 8; ++r) sum += sO[(part * (TR / 8) + r) * SOW + col];
             sO2[part * 32 + col] = sum;
         }
     }
@@ -459,95 +462,80 @@ __device__ __forceinline__ void fa_train_body(const FaTrainArgs &a) {
         const float4 *wp0 = Tq + FA_TOFF_W9T / 4 + cbw * 4 * 64, *wp1 = Tq + FA_TOFF_W9T / 4 + (4 + cbw) * 4 * 64;
         prefetch_b<32>(wp0, lane, h0);
         prefetch_b<32>(wp1, lane, h1);
-        f32x16 ap[1] = {}, av[1] = {};
-        {   // A = sO (row stride SOW): one 16-byte read per four MFMAs
-            constexpr int rb = 0;
+        f32x16 ap = {}, av = {};
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const float4 x = *reinterpret_cast<const float4 *>(sO + (rbw * 32 + li) * SOW + hh * 16 + c * 4);
-                ap[rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(x.x, h0.v[c].x, ap[rb], 0, 0, 0);
-                ap[rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(x.y, h0.v[c].y, ap[rb], 0, 0, 0);
-                ap[rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(x.z, h0.v[c].z, ap[rb], 0, 0, 0);
-                ap[rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(x.w, h0.v[c].w, ap[rb], 0, 0, 0);
-                av[rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(x.x, h1.v[c].x, av[rb], 0, 0, 0);
-                av[rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(x.y, h1.v[c].y, av[rb], 0, 0, 0);
-                av[rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(x.z, h1.v[c].z, av[rb], 0, 0, 0);
-                av[rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(x.w, h1.v[c].w, av[rb], 0, 0, 0);
-            }
+        for (int c = 0; c < 4; ++c) {   // A = sO (row stride SOW): one 16-byte read per four MFMAs
+            const float4 x = *reinterpret_cast<const float4 *>(sO + li * SOW + hh * 16 + c * 4);
+            ap = __builtin_amdgcn_mfma_f32_32x32x2f32(x.x, h0.v[c].x, ap, 0, 0, 0);
+            ap = __builtin_amdgcn_mfma_f32_32x32x2f32(x.y, h0.v[c].y, ap, 0, 0, 0);
+            ap = __builtin_amdgcn_mfma_f32_32x32x2f32(x.z, h0.v[c].z, ap, 0, 0, 0);
+            ap = __builtin_amdgcn_mfma_f32_32x32x2f32(x.w, h0.v[c].w, ap, 0, 0, 0);
+            av = __builtin_amdgcn_mfma_f32_32x32x2f32(x.x, h1.v[c].x, av, 0, 0, 0);
+            av = __builtin_amdgcn_mfma_f32_32x32x2f32(x.y, h1.v[c].y, av, 0, 0, 0);
+            av = __builtin_amdgcn_mfma_f32_32x32x2f32(x.z, h1.v[c].z, av, 0, 0, 0);
+            av = __builtin_amdgcn_mfma_f32_32x32x2f32(x.w, h1.v[c].w, av, 0, 0, 0);
         }
         __syncthreads(); // dW9 has read P and V
         if (tid < 32) {
             float sum = 0.0f;
 #pragma unroll
-            for (int part = 0; part < 16; ++part) sum += sO2[part * 32 + tid];
-            slab[FA_POFF_B9 + tid] = sum;
+            for (int part = 0; part < 8; ++part) sum += sO2[part * 32 + tid];
+            mslab[FA_MSLAB_B9 + tid] = sum;
         }
-        store_acc_relu_mask(B1 + cbw * 32, rbw, ap[0], lane);
-        store_acc_relu_mask(B2 + cbw * 32, rbw, av[0], lane);
+        store_acc_relu_mask(B1 + cbw * 32, ap, lane);
+        store_acc_relu_mask(B2 + cbw * 32, av, lane);
     }
     __syncthreads();
-    {   // dW8 = h3^T [dP | dV] (128 x 256): 32 tiles, eight per wave (column block cb, k-blocks 0..3);  db8
-        {
-            const int cb = wave;
+    {   // [dP | dV] -> the record of dW8 = h3^T [dP | dV] (fa_train_dw_kernel);  db8 = its column sums
+        for (int k = tid; k < TR * 64; k += NTH) {
+            const int r = k >> 6, c4 = k & 63;
+            reinterpret_cast<float4 *>(recB + FA_RECB_DPV)[k] =
+                *reinterpret_cast<const float4 *>((c4 < 32 ? B1 : B2) + r * LDA + (c4 & 31) * 4);
+        }
+        const float *src = (tid < 128 ? B1 : B2) + (tid & 127);
+        float s0 = 0.0f, s1 = 0.0f;
 #pragma unroll
-            for (int kb = 0; kb < 4; ++kb) {
-                f32x16 acc = {};
-                gemm_tn(B0 + kb * 32, LDA, (cb < 4 ? B1 : B2) + (cb & 3) * 32, LDA, acc, lane);
-                store_tile_global(slab + FA_POFF_W8 + kb * 32 * 256 + cb * 32, 256, acc, lane);
-            }
-        }
-        {   // db8: two 32-row partial sums per column of [dP | dV] (sO -- dOUT -- is dead by now), folded behind the barrier below
-            const int col = tid & 255, half = tid >> 8;
-            const float *src = (col < 128 ? B1 : B2) + (col & 127) + half * (TR / 2) * LDA;
-            float sum = 0.0f;
-            for (int r = 0; r < TR / 2; ++r) sum += src[r * LDA];
-            sO[half * 256 + col] = sum;
-        }
+        for (int r = 0; r < TR; r += 2) { s0 += src[r * LDA]; s1 += src[(r + 1) * LDA]; }
+        mslab[FA_MSLAB_B8 + tid] = s0 + s1;
     }
     {   // dh3 = [dP | dV] W8^T (K = 256: half 0 walks dP, half 1 dV) -> B3
         BHead<256> hd;
         const float4 *wp = Tq + FA_TOFF_W8T / 4 + cbw * 32 * 64;
         prefetch_b<256>(wp, lane, hd);
         f32x16 acc[1] = {};
-        gemm_cb<256, 1>((hh ? B2 : B1) + (rbw * 32 + li) * LDA, wp, acc, lane, hd);
-        store_acc<false>(B3 + cbw * 32, rbw, acc[0], 0.0f, lane);
+        gemm_cb<256, 1>((hh ? B2 : B1) + li * LDA, wp, acc, lane, hd);
+        store_acc<false>(B3 + cbw * 32, 0, acc[0], 0.0f, lane);
     }
     __syncthreads();
-    if (tid < 256) slab[FA_POFF_B8 + tid] = sO[tid] + sO[256 + tid];
 
     FA_TR_TICK(5)
     // ---- the three rounds, last first: B0 = the round's output h, B3 = dL/d(output) ---------------------
-    // dW7 (256 x 128: this wave's column block, k-blocks 4 * rbw .. + 3 -- the h_in half for the waves of row block 0,
-    // the hmix half for the others) and dA_m (128 x 128: k-blocks 2 * rbw, + 1) accumulate in registers across the
-    // three rounds (a read-modify-write of the slab per round instead cost 60-110 k cycles per round: its loads
-    // serialise in front of every tile's MFMA chain)
-    f32x16 acc_w7[4], acc_am[2];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) acc_w7[t] = f32x16{};
-#pragma unroll
-    for (int t = 0; t < 2; ++t) acc_am[t] = f32x16{};
     float dbu = 0.0f; // threads 0..127: their column of the update bias gradient
     for (int round = 2; round >= 0; --round) {
-        FA_TR_TICK(6 + (2 - round) * 8)
-        // dZ = dL/dh_out through the relu (in place in B3); the bias gradient
+        float *rec = recA + round * FA_RECA_FLOATS;
+        // dZ = dL/dh_out through the relu (in place in B3)
         for (int k = tid; k < TR * 128; k += NTH) {
             const int r = k >> 7, c = k & 127;
             if (!(B0[r * LDA + c] > 0.0f)) B3[r * LDA + c] = 0.0f;
         }
         __syncthreads();
-        {   // the update bias gradient: four 16-row partial sums per column of dZ, folded behind the next barrier
+        FA_TR_TICK(30 + 8 * (2 - round))
+        {   // the update bias gradient: two 16-row partial sums per column of dZ, folded behind the next barrier
             const int col = tid & 127, q = tid >> 7;
             float sum = 0.0f;
-            for (int r = 0; r < TR / 4; ++r) sum += B3[(q * (TR / 4) + r) * LDA + col];
+#pragma unroll
+            for (int r = 0; r < TR / 2; ++r) sum += B3[(q * (TR / 2) + r) * LDA + col];
             sO2[q * 128 + col] = sum;
         }
-        FA_TR_TICK(7 + (2 - round) * 8)
+        save_tile(B3, rec + FA_RECA_DZ);
         // h_in -> B0, g = h_in A_m -> B2 (recomputed), hmix -> B1 (recomputed from the saved weights)
         BHead<128> hd_g;
         prefetch_b<128>(wp_am, lane, hd_g);
-        load_tile(B0, hsave + round * TR * 128);
+        load_tile(B0, rec + FA_RECA_HIN);
+        FA_TR_TICK(31 + 8 * (2 - round))
         __syncthreads();
-        if (tid < 128) dbu += ((sO2[tid] + sO2[128 + tid]) + sO2[256 + tid]) + sO2[384 + tid];
+        FA_TR_TICK(32 + 8 * (2 - round))
+        if (tid < 128) dbu += sO2[tid] + sO2[128 + tid];
         project_team(B2, hd_g);
         for (int r = wave * 4 + (lane >> 4); r < TR; r += NWV * 4) {
             if (r < RU) mix_row<128>(sAttn[1 + round] + r * 8, B0 + ((r / n) * n) * LDA, n, B1 + r * LDA, q16);
@@ -557,58 +545,47 @@ __device__ __forceinline__ void fa_train_body(const FaTrainArgs &a) {
             }
         }
         __syncthreads();
-        FA_TR_TICK(8 + (2 - round) * 8)
-        // dW7 += [h_in | hmix]^T dZ  (the transposed weights of the next GEMM are requested first)
-        BHead<128> ha, hm;
-        const float4 *wpa = Tq + FA_TOFF_W7T / 4 + cbw * 16 * 64, *wpm = Tq + FA_TOFF_W7T / 4 + (4 + cbw) * 16 * 64;
-        prefetch_b<128>(wpa, lane, ha);
-        prefetch_b<128>(wpm, lane, hm);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) gemm_tn((rbw ? B1 : B0) + t * 32, LDA, B3 + cbw * 32, LDA, acc_w7[t], lane);
-        FA_TR_TICK(9 + (2 - round) * 8)
+        FA_TR_TICK(33 + 8 * (2 - round))
+        save_tile(B1, rec + FA_RECA_HMIX);
         {   // [dh_a | dhmix] = dZ W7^T (K = 128 -> 256 columns)
+            BHead<128> ha, hm;
+            const float4 *wpa = Tq + FA_TOFF_W7T / 4 + cbw * 16 * 64, *wpm = Tq + FA_TOFF_W7T / 4 + (4 + cbw) * 16 * 64;
+            prefetch_b<128>(wpa, lane, ha);
+            prefetch_b<128>(wpm, lane, hm);
             f32x16 aa[1] = {}, am[1] = {};
-            gemm_cb<128, 1>(B3 + (rbw * 32 + li) * LDA + hh * 64, wpa, aa, lane, ha);
-            gemm_cb<128, 1>(B3 + (rbw * 32 + li) * LDA + hh * 64, wpm, am, lane, hm);
-            __syncthreads(); // every wave has read dZ (and hmix, for dW7)
-            store_acc<false>(B3 + cbw * 32, rbw, aa[0], 0.0f, lane);
-            store_acc<false>(B1 + cbw * 32, rbw, am[0], 0.0f, lane);
+            gemm_cb<128, 1>(B3 + li * LDA + hh * 64, wpa, aa, lane, ha);
+            gemm_cb<128, 1>(B3 + li * LDA + hh * 64, wpm, am, lane, hm);
+            FA_TR_TICK(34 + 8 * (2 - round))
+            __syncthreads(); // every wave has read dZ; hmix is saved
+            store_acc<false>(B3 + cbw * 32, 0, aa[0], 0.0f, lane);
+            store_acc<false>(B1 + cbw * 32, 0, am[0], 0.0f, lane);
         }
         __syncthreads();
-        FA_TR_TICK(10 + (2 - round) * 8)
+        FA_TR_TICK(35 + 8 * (2 - round))
         // attention backward per env: dhmix (B1), g (B2) -> dg (B2 in place), dkeys added into B3.  The rows
         // beyond the tile's envs hold a recomputed g of padding rows: their dg is zero
         if (wave == 0 && lane < 32)
-            for (int r = RU; r < TR; ++r) *reinterpret_cast<float4 *>(B2 + r * LDA + tid * 4) = float4{0, 0, 0, 0};
-        for (int el = wave * 4 + (lane >> 4); el < ET; el += NWV * 4) {
-            // (teams of up to 4: half the key / key-gradient registers)
-            if (n <= 4) attend_env_bwd<128, true, 4>(B1 + (el * n) * LDA, B2 + (el * n) * LDA, B0 + (el * n) * LDA, B3 + (el * n) * LDA,
-                                                     sAttn[1 + round] + (el * n) * 8, n, n, q16);
-            else attend_env_bwd<128, true, FA_POLICY_MAX_TEAM>(B1 + (el * n) * LDA, B2 + (el * n) * LDA, B0 + (el * n) * LDA,
-                                                               B3 + (el * n) * LDA, sAttn[1 + round] + (el * n) * 8, n, n, q16);
-        }
+            for (int r = RU; r < TR; ++r) *reinterpret_cast<float4 *>(B2 + r * LDA + lane * 4) = float4{0, 0, 0, 0};
+        for (int el = wave * 4 + (lane >> 4); el < ET; el += NWV * 4)
+            attend_env_bwd<128, true, MT>(B1 + (el * n) * LDA, B2 + (el * n) * LDA, B0 + (el * n) * LDA, B3 + (el * n) * LDA,
+                                          sAttn[1 + round] + (el * n) * 8, n, n, q16);
         __syncthreads();
-        FA_TR_TICK(11 + (2 - round) * 8)
-        // dA_m += h_in^T dg ;  dh += dg A_m^T
-        BHead<128> hd;
-        const float4 *wp = Tq + FA_TOFF_AMT / 4 + cbw * 16 * 64;
-        prefetch_b<128>(wp, lane, hd);
-#pragma unroll
-        for (int t = 0; t < 2; ++t) gemm_tn(B0 + (2 * rbw + t) * 32, LDA, B2 + cbw * 32, LDA, acc_am[t], lane);
-        {
+        FA_TR_TICK(36 + 8 * (2 - round))
+        save_tile(B2, rec + FA_RECA_DG);
+        {   // dh += dg A_m^T
+            BHead<128> hd;
+            const float4 *wp = Tq + FA_TOFF_AMT / 4 + cbw * 16 * 64;
+            prefetch_b<128>(wp, lane, hd);
             f32x16 acc[1] = {};
-            gemm_cb<128, 1>(B2 + (rbw * 32 + li) * LDA + hh * 64, wp, acc, lane, hd);
-            store_acc_add(B3 + cbw * 32, rbw, acc[0], lane);
+            gemm_cb<128, 1>(B2 + li * LDA + hh * 64, wp, acc, lane, hd);
+            store_acc_add(B3 + cbw * 32, acc[0], lane);
         }
         __syncthreads();
+        FA_TR_TICK(37 + 8 * (2 - round))
     }
-#pragma unroll
-    for (int t = 0; t < 4; ++t) store_tile_global(slab + FA_POFF_W7 + (4 * rbw + t) * 32 * 128 + cbw * 32, 128, acc_w7[t], lane);
-#pragma unroll
-    for (int t = 0; t < 2; ++t) store_tile_global(slab + FA_POFF_AM + (2 * rbw + t) * 32 * 128 + cbw * 32, 128, acc_am[t], lane);
-    if (wave < 2) slab[FA_POFF_BU + tid] = dbu;
+    if (tid < 128) mslab[FA_MSLAB_BU + tid] = dbu;
 
-    FA_TR_TICK(30)
+    FA_TR_TICK(60)
     // ---- opponent stage: B0 = [h1 | e_opp], B3 = [dh1 (so far) | de_opp] --------------------------------
     encoders(nullptr, B2); // ho -> B2[:, 0:64] (opponent rows), recomputed
     __syncthreads();
@@ -618,38 +595,34 @@ __device__ __forceinline__ void fa_train_body(const FaTrainArgs &a) {
         else *reinterpret_cast<float4 *>(B1 + r * LDA + q16 * 4) = float4{0, 0, 0, 0};
     }
     __syncthreads();
-    if (wave < 4) {   // dB_o = mix_o^T de_opp (64 x 64: one tile per wave 0..3)
-        f32x16 acc = {};
-        gemm_tn(B1 + (wave >> 1) * 32, LDA, B3 + 64 + (wave & 1) * 32, LDA, acc, lane);
-        store_tile_global(slab + FA_POFF_BO + (wave >> 1) * 32 * 64 + (wave & 1) * 32, 64, acc, lane);
-    }
-    if (wave < 4) {   // dmix_o = de_opp B_o^T -> B2[:, 64:128]
+    save_tile64(B1, recB + FA_RECB_MO);        // dB_o = mix_o^T de_opp
+    save_tile64(B3 + 64, recB + FA_RECB_DE);
+    save_tile64(B0, recB + FA_RECB_H1);        // dA_o = h1^T dg_o
+    if (wave < 2) {   // dmix_o = de_opp B_o^T -> B2[:, 64:128]
         BHead<64> hd;
-        const float4 *wp = Tq + FA_TOFF_BOT / 4 + (wave & 1) * 8 * 64;
+        const float4 *wp = Tq + FA_TOFF_BOT / 4 + wave * 8 * 64;
         prefetch_b<64>(wp, lane, hd);
         f32x16 acc[1] = {};
-        gemm_cb<64, 1>(B3 + ((wave >> 1) * 32 + li) * LDA + 64 + hh * 32, wp, acc, lane, hd);
-        store_acc<false>(B2 + 64 + (wave & 1) * 32, wave >> 1, acc[0], 0.0f, lane);
+        gemm_cb<64, 1>(B3 + li * LDA + 64 + hh * 32, wp, acc, lane, hd);
+        store_acc<false>(B2 + 64 + wave * 32, 0, acc[0], 0.0f, lane);
     }
     __syncthreads();
     // opponent attention backward per env: dmix_o (B2[:, 64:]), g_o (B1[:, 64:]) -> dg_o in place; dho -> B1[:, 0:64]
     for (int el = wave * 4 + (lane >> 4); el < ET; el += NWV * 4)
-        attend_env_bwd<64, false, FA_POLICY_MAX_TEAM>(B2 + (el * n) * LDA + 64, B1 + (el * n) * LDA + 64, B2 + (el * m) * LDA, B1 + (el * m) * LDA,
-                                  sAttn[0] + (el * n) * 8, n, m, q16);
+        attend_env_bwd<64, false, MT>(B2 + (el * n) * LDA + 64, B1 + (el * n) * LDA + 64, B2 + (el * m) * LDA, B1 + (el * m) * LDA,
+                                      sAttn[0] + (el * n) * 8, n, m, q16);
     __syncthreads();
-    if (wave < 4) {   // dA_o = h1^T dg_o ;  dh1 += dg_o A_o^T
-        f32x16 acc = {};
-        gemm_tn(B0 + (wave >> 1) * 32, LDA, B1 + 64 + (wave & 1) * 32, LDA, acc, lane);
-        store_tile_global(slab + FA_POFF_AO + (wave >> 1) * 32 * 64 + (wave & 1) * 32, 64, acc, lane);
+    save_tile64(B1 + 64, recB + FA_RECB_DGO);
+    if (wave < 2) {   // dh1 += dg_o A_o^T
         BHead<64> hd;
-        const float4 *wp = Tq + FA_TOFF_AOT / 4 + (wave & 1) * 8 * 64;
+        const float4 *wp = Tq + FA_TOFF_AOT / 4 + wave * 8 * 64;
         prefetch_b<64>(wp, lane, hd);
         f32x16 acc2[1] = {};
-        gemm_cb<64, 1>(B1 + ((wave >> 1) * 32 + li) * LDA + 64 + hh * 32, wp, acc2, lane, hd);
-        store_acc_add(B3 + (wave & 1) * 32, wave >> 1, acc2[0], lane);
+        gemm_cb<64, 1>(B1 + li * LDA + 64 + hh * 32, wp, acc2, lane, hd);
+        store_acc_add(B3 + wave * 32, acc2[0], lane);
     }
     __syncthreads();
-    FA_TR_TICK(31)
+    FA_TR_TICK(61)
     // ---- encoders: through the relus, then [dW ; db] = [x | 1]^T dpre as one 32 x 32 MFMA tile per 32 columns ----
     // (own side: waves 0, 1; opponent side: waves 2, 3).  [x | 1 | 0...] rows go to sO / sO2.
     for (int k = tid; k < 2 * TR * 64; k += NTH) {
@@ -668,11 +641,11 @@ __device__ __forceinline__ void fa_train_body(const FaTrainArgs &a) {
         (side == 0 ? sO : sO2)[kk] = v;
     }
     __syncthreads();
-    if (wave < 4) {
+    {
         const int side = wave >> 1, cb = wave & 1;
         f32x16 acc = {};
         gemm_tn(side == 0 ? sO : sO2, SOW, (side == 0 ? B3 : B1) + cb * 32, LDA, acc, lane);
-        float *dw = slab + (side == 0 ? FA_POFF_WE : FA_POFF_WOE), *db = slab + (side == 0 ? FA_POFF_BE : FA_POFF_BOE);
+        float *dw = mslab + (side == 0 ? FA_POFF_WE : FA_POFF_WOE), *db = mslab + (side == 0 ? FA_POFF_BE : FA_POFF_BOE);
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
             const int row = (reg & 3) + 8 * (reg >> 2) + 4 * hh; // = k of [x | 1]
@@ -680,39 +653,15 @@ __device__ __forceinline__ void fa_train_body(const FaTrainArgs &a) {
             else if (row == FA_OBS_DIM) db[cb * 32 + li] = acc[reg];
         }
     }
-    FA_TR_TICK(32)
+    FA_TR_TICK(62)
 }
 
-template <bool GATHER>
-__global__ __launch_bounds__(NTH, 1) void fa_train_kernel(FaTrainArgs a) { fa_train_body<GATHER>(a); }
-// (the attribute takes a literal, not a template argument: hence a second kernel and not a third parameter)
-__global__ __launch_bounds__(NTH, 1) __attribute__((amdgpu_num_vgpr(FA_TRAIN_NUM_VGPR))) void fa_train_share_kernel(FaTrainArgs a) {
-    fa_train_body<true>(a);
-}
-
-// out[k] = sum_t slabs[t][k] in tile order (FA_RED_U interleaved partial sums = loads in flight per lane.  With 8
-// it would fit beside fa_train_share_kernel on a CU -- measured: 0.265 s per update instead of 0.260; this is the
-// one bandwidth-heavy launch of a step and does better waiting for whole CUs)
-#ifndef FA_RED_U
-#define FA_RED_U 16
-#endif
-__global__ __launch_bounds__(128) void fa_train_reduce_kernel(const float *__restrict__ slabs, int tiles, float *__restrict__ out) {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= FA_SLAB_LOSS + 8) return;
-    float s[FA_RED_U];
-#pragma unroll
-    for (int u = 0; u < FA_RED_U; ++u) s[u] = 0.0f;
-    int t = 0;
-    for (; t + FA_RED_U <= tiles; t += FA_RED_U) {
-#pragma unroll
-        for (int u = 0; u < FA_RED_U; ++u) s[u] += slabs[(size_t)(t + u) * FA_SLAB_FLOATS + k];
-    }
-    for (; t < tiles; ++t) s[0] += slabs[(size_t)t * FA_SLAB_FLOATS + k];
-#pragma unroll
-    for (int w = FA_RED_U / 2; w >= 1; w >>= 1)
-#pragma unroll
-        for (int u = 0; u < w; ++u) s[u] += s[u + w];
-    out[k] = s[0];
+template <bool GATHER, int MT>
+__global__ __launch_bounds__(NTH, 2) void fa_train_kernel(FaTrainArgs a) { fa_train_body<GATHER, MT>(a); }
+// (the attribute takes a literal, not a template argument: hence a second kernel and not another parameter)
+template <int MT>
+__global__ __launch_bounds__(NTH, 2) __attribute__((amdgpu_num_vgpr(FA_TRAIN_NUM_VGPR))) void fa_train_share_kernel(FaTrainArgs a) {
+    fa_train_body<true, MT>(a);
 }
 
 // The alive-mask sum of the minibatch's own-team rows as FA_MASK_PARTS partial sums (one workgroup each; the
@@ -775,14 +724,17 @@ int fa_train_tile_envs(int G, int A) { return TR / (G > A ? G : A); }
 hipError_t fa_launch_train(const FaTrainArgs &a, hipStream_t st) {
     const int ET = fa_train_tile_envs(a.G, a.A);
     const dim3 grid((a.B + ET - 1) / ET), block(NTH);
-    if (a.idx && a.share_cu) hipLaunchKernelGGL(fa_train_share_kernel, grid, block, 0, st, a);
-    else if (a.idx) hipLaunchKernelGGL(fa_train_kernel<true>, grid, block, 0, st, a);
-    else hipLaunchKernelGGL(fa_train_kernel<false>, grid, block, 0, st, a);
-    return hipGetLastError();
-}
-
-hipError_t fa_launch_train_reduce(const float *slabs, int tiles, float *out, hipStream_t st) {
-    hipLaunchKernelGGL(fa_train_reduce_kernel, dim3((FA_SLAB_LOSS + 8 + 127) / 128), dim3(128), 0, st, slabs, tiles, out);
+    const int big = a.G > a.A ? a.G : a.A;
+#define FA_TRAIN_LAUNCH(MT)                                                                                   \
+    do {                                                                                                      \
+        if (a.idx && a.share_cu) hipLaunchKernelGGL(fa_train_share_kernel<MT>, grid, block, 0, st, a);        \
+        else if (a.idx) hipLaunchKernelGGL((fa_train_kernel<true, MT>), grid, block, 0, st, a);               \
+        else hipLaunchKernelGGL((fa_train_kernel<false, MT>), grid, block, 0, st, a);                         \
+    } while (0)
+    if (big <= 4) FA_TRAIN_LAUNCH(4);
+    else if (big <= 6) FA_TRAIN_LAUNCH(6);
+    else FA_TRAIN_LAUNCH(FA_POLICY_MAX_TEAM);
+#undef FA_TRAIN_LAUNCH
     return hipGetLastError();
 }
 

@@ -19,9 +19,11 @@ def fa():
 # largest deviations of the policy-side rows (fused kernel vs the PyTorch module) seen by _check_rollout_against_oracle in this
 # process: value rows relative to max(1, max |V|), log-prob rows absolute.  tools/soak_closed_loop.py reports them.
 POLICY_ROW_DEVIATION = {"value_rel": 0.0, "logp_abs": 0.0}
-# Bounds = 10 x the largest deviation recorded over the 80-iteration training soak (profiles/r04_soak_closed_loop.jsonl:
-# values 3.5e-7 relative while the critic grows to |V| ~ 100, log-probs 1.6e-6): float32 folded algebra vs the module.
-VALUE_REL_TOL, LOGP_ABS_TOL = 1e-5, 5e-5
+# Bounds = 10 x the largest deviation recorded over the training soaks (profiles/r04_soak_closed_loop.jsonl, 80 iterations at
+# 3v3 and 20 at 5v5 with tools/soak_closed_loop.py ... measure): values 1.6e-5 relative while the critic grows to |V| ~ 100,
+# log-probs 2.3e-5 absolute -- float32 with the folded algebra (A = norm W_q W_k^T etc. multiplied out once per update) against
+# the module's unfolded float32.  (Round 3 allowed 1e-4 relative / 1e-4 without a record of what was observed.)
+VALUE_REL_TOL, LOGP_ABS_TOL = 1.6e-4, 2.3e-4
 
 
 def _check_rollout_against_oracle(fa, learner, orc, first):

@@ -264,7 +264,14 @@ def test_fused_ppo_grad_matches_torch_autograd(fa, G, A, team, B, clipped):
     for k, gk in grads.items():
         ref = P[k].grad
         if k == "W9":
-            assert float(gk[:, 9:].abs().max()) == 0.0
+            # W9 is block diagonal: rows 0..127 x columns 0..7 are dist.linear.weight^T, rows 128..255 x column 8 is
+            # value_head.2.weight^T.  The kernel produces the gradients of those PARAMETER entries; the structural zeros
+            # have none (the autograd reference, which treats W9 as a dense matrix, does give them one: masked here)
+            real = torch.zeros_like(ref, dtype=torch.bool)
+            real[:128, :8] = True
+            real[128:, 8] = True
+            assert float(gk[~real].abs().max()) == 0.0
+            ref = ref * real
         if k == "B9":
             gk, ref = gk[:9], ref[:9]
         scale_k = max(float(ref.abs().max()), 1e-6)

@@ -10,7 +10,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "emergent-multiagent-strategies_amd", "csrc")
 OBJ = os.path.join(CSRC, "_obj")
-SOURCES = ["fa_step.hip", "fa_collect.hip", "fa_policy.hip", "fa_attend.hip", "fa_train.hip", "fa_fold.hip", "fa_rccl.hip", "fa_api.hip"]
+SOURCES = ["fa_step.hip", "fa_collect.hip", "fa_policy.hip", "fa_attend.hip", "fa_train.hip", "fa_train_dw.hip", "fa_fold.hip", "fa_rccl.hip", "fa_api.hip"]
 name, tu = sys.argv[1], sys.argv[2]
 extra = sys.argv[3:]
 src = os.path.join(CSRC, tu)

@@ -1,0 +1,9 @@
+#!/bin/bash
+# Round 4, train-kernel restructure: parity tests of the fused gradient / update, then timings.
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/${1:-r04b}
+mkdir -p $O
+export TMPDIR=/tmp
+cd $R
+timeout 1200 python -m pytest tests/test_gpu_policy.py tests/test_gpu_ppo_golden.py -m gpu -q -s -k "ppo_grad or fold or adam or golden or published" > $O/pytest_train.log 2>&1; echo "train tests rc=$?"; grep -E "passed|failed|FAILED|Error|within" $O/pytest_train.log | tail -25
+timeout 900 python tools/ab_train.py --no-tests product > $O/ab_train.txt 2>$O/ab_train.err; echo "ab rc=$?"; cat $O/ab_train.txt; tail -3 $O/ab_train.err

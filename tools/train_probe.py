@@ -31,23 +31,23 @@ print("fa_ppo_grad (train + reduce): %.1f us per call at B = %d" % (a.elapsed_ti
 lib = C.CDLL(LIB)
 buf = (C.c_ulonglong * 64)()
 lib.fa_dbg_train(buf)
-names = {0: "start", 1: "fwd: encoders + opponent stage", 2: "fwd: 3 rounds", 3: "fwd: heads", 4: "losses", 5: "bwd: heads",
-         30: "bwd: rounds done", 31: "bwd: opponent stage", 32: "bwd: encoders", 48: "bwd: shared weight gradients (end phase)"}
+names = {0: "start", 1: "fwd: gather + encoders + opponent stage", 2: "fwd: rounds done", 3: "fwd: heads + last layer", 4: "losses",
+         5: "bwd: heads (dW9, d[P|V], save dPV, dh3)", 60: "bwd: rounds done", 61: "bwd: opponent stage", 62: "bwd: encoders"}
 for r in range(3):
-    base = 6 + r * 8
-    names.update({base: "  round %d: (prev tail)" % (2 - r), base + 1: "  round %d: relu mask + bias grad" % (2 - r),
-                  base + 2: "  round %d: load h, recompute g, hmix" % (2 - r), base + 3: "  round %d: dW7" % (2 - r),
-                  base + 4: "  round %d: dZ W7^T" % (2 - r), base + 5: "  round %d: attention backward" % (2 - r)})
-for r in range(3):
-    base = 33 + r * 7
-    names.update({base: "  fwd round %d: (prev tail: save_tile)" % r, base + 1: "  fwd round %d: g = h A (gemm128 + store)" % r,
-                  base + 2: "  fwd round %d: barrier" % r, base + 3: "  fwd round %d: attention" % r, base + 4: "  fwd round %d: barrier" % r,
-                  base + 5: "  fwd round %d: gemm256" % r, base + 6: "  fwd round %d: barrier + store + barrier" % r})
-order = [0, 1] + list(range(33, 48)) + [2, 3, 4, 5] + list(range(6, 33)) + [48]
+    b = 10 + 5 * r
+    names.update({b: "  fwd round %d: g = h A (gemm128 + store)" % r, b + 1: "  fwd round %d: barrier" % r, b + 2: "  fwd round %d: attention" % r,
+                  b + 3: "  fwd round %d: barrier" % r, b + 4: "  fwd round %d: gemm256, barrier, store, barrier, save h" % r})
+for k in range(3):
+    b = 30 + 8 * k
+    names.update({b: "  bwd round %d: relu mask + barrier" % (2 - k), b + 1: "  bwd round %d: bias sums, save dZ, reload h (issue)" % (2 - k),
+                  b + 2: "  bwd round %d: barrier (h landed)" % (2 - k), b + 3: "  bwd round %d: g recompute + mix + barrier" % (2 - k),
+                  b + 4: "  bwd round %d: save hmix + dZ W7^T (2 gemm128)" % (2 - k), b + 5: "  bwd round %d: barrier, stores, barrier" % (2 - k),
+                  b + 6: "  bwd round %d: attention backward + barrier" % (2 - k), b + 7: "  bwd round %d: save dg + dg A^T + add + barrier" % (2 - k)})
+order = [0, 1] + list(range(10, 25)) + [2, 3, 4, 5] + list(range(30, 54)) + [60, 61, 62]
 keys = [k for k in order if k in names and buf[k]]
 prev = None
 for k in keys:
     if prev is not None:
-        print("%-42s %8d cycles" % (names[k], buf[k] - buf[prev]))
+        print("%-56s %8d cycles" % (names[k], buf[k] - buf[prev]))
     prev = k
-print("%-42s %8d cycles = %.1f us at 2.4 GHz" % ("total", buf[keys[-1]] - buf[keys[0]], (buf[keys[-1]] - buf[keys[0]]) / 2400.0))
+print("%-56s %8d cycles = %.1f us at 2.4 GHz" % ("total", buf[keys[-1]] - buf[keys[0]], (buf[keys[-1]] - buf[keys[0]]) / 2400.0))
