@@ -633,6 +633,7 @@ int fa_ppo_grad(const fa_ppo_grad_io *io, void *stream) {
     a.mslab = io->slabs;
     a.rec_a = io->hsave;
     a.rec_b = io->hsave + tiles * 3 * FA_RECA_FLOATS;
+    a.rec_g = a.rec_b + tiles * FA_RECB_FLOATS;
     if (!a.scale) { // partial mask sums behind the partial slabs; the scale pair is left behind the loss sums of `out`
         float *part = dw_slabs + (size_t)FA_DW_WGS_A * FA_DWA_FLOATS + (size_t)FA_DW_WGS_B * FA_DWB_FLOATS;
         FA_HIP(fa_launch_mask_parts(a, part, s));

@@ -45,7 +45,8 @@
 #define FA_RECB_H1 (4 * FA_REC_PLANE)                  // 32 x 64: the own encodings
 #define FA_RECB_DGO (4 * FA_REC_PLANE + FA_TR_ROWS * 64) // 32 x 64: dL/dg_o, g_o = h1 A_o
 #define FA_RECB_FLOATS (5 * FA_REC_PLANE)  // dW8 = H3^T DPV ;  dB_o = MO^T DE ;  dA_o = H1^T DGO
-#define FA_TR_SAVE_FLOATS (3 * FA_RECA_FLOATS + FA_RECB_FLOATS) // per tile
+// (3) g = h_in A_m of every round (32 x 128 each): what the tile's own backward reloads instead of recomputing
+#define FA_TR_SAVE_FLOATS (3 * FA_RECA_FLOATS + FA_RECB_FLOATS + 3 * FA_REC_PLANE) // per tile
 // (2) The tile's SMALL gradients: encoders and biases at their FA_POFF_* offsets (0 .. 895), then the update / head
 //     biases, the 1 152 real entries of dW9 (W9 is block diagonal: 128 x 8 logits weights + 128 value weights) and the
 //     tile's loss sums.  Summed over the tiles in two stages (fa_train_mred_kernel, then the final reduction).
@@ -77,11 +78,12 @@ struct FaTrainArgs {
     float *mslab;              // [tiles][FA_MSLAB_FLOATS]
     float *rec_a;              // [tiles][3][FA_RECA_FLOATS]
     float *rec_b;              // [tiles][FA_RECB_FLOATS]
+    float *rec_g;              // [tiles][3][FA_REC_PLANE]
     int32_t B, G, A, team;     // team 0: the guards' policy on the guards' rows; 1: the attackers'
     const float *mask_part;    // with scale == null: FA_MASK_PARTS partial alive-mask sums (fa_launch_mask_parts); the
     float *scale_out;          // kernel derives the scale pair itself (`normalize`: divide by the mask mean) and
     int32_t normalize;         // workgroup 0 leaves it at scale_out[0..1]
-    int32_t share_cu;          // leave 48 registers per lane of every CU to concurrent small launches (fa_train.hip)
+    int32_t share_cu;          // (ignored since round 4: see fa_train.hip)
     const float *scale;        // device float[2]: {1 / (B n mask_mean'), mask_mean'} with mask_mean' = the alive-mask
                                // mean of the minibatch (1 where that is 0, or when the caller normalises later:
                                // several ranks).  [0] multiplies every loss gradient; [1] undoes it for the

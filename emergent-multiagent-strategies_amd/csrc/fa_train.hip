@@ -56,6 +56,24 @@ __device__ __forceinline__ void store_acc_add(float *dst, const f32x16 &acc, int
         *p += acc[reg];
     }
 }
+// dst = (gate > 0 ? dst + acc : 0): the last contribution to dL/dh of a round together with the relu gate of the round
+// below (gate = that round's output h, same tile position) -- no separate masking pass over the tile
+__device__ __forceinline__ void store_acc_add_gate(float *dst, const float *gate, const f32x16 &acc, int lane) {
+    const int col = lane & 31, hh = lane >> 5;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const int o = ((reg & 3) + 8 * (reg >> 2) + 4 * hh) * LDA + col;
+        dst[o] = gate[o] > 0.0f ? dst[o] + acc[reg] : 0.0f;
+    }
+}
+__device__ __forceinline__ void store_acc_gate(float *dst, const float *gate, const f32x16 &acc, int lane) {
+    const int col = lane & 31, hh = lane >> 5;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const int o = ((reg & 3) + 8 * (reg >> 2) + 4 * hh) * LDA + col;
+        dst[o] = gate[o] > 0.0f ? acc[reg] : 0.0f;
+    }
+}
 __device__ __forceinline__ void store_acc_relu_mask(float *dst, const f32x16 &acc, int lane) {
     const int col = lane & 31, hh = lane >> 5;
 #pragma unroll
@@ -63,28 +81,6 @@ __device__ __forceinline__ void store_acc_relu_mask(float *dst, const f32x16 &ac
         float *p = dst + ((reg & 3) + 8 * (reg >> 2) + 4 * hh) * LDA + col;
         *p = *p > 0.0f ? acc[reg] : 0.0f;
     }
-}
-
-// out[r] = sum_j attn[j] key[j]  (recomputing a mix from saved attention weights), 16 lanes per row
-template <int W>
-__device__ __forceinline__ void mix_row(const float *attn_row, const float *key0, int nk, float *orow, int q) {
-    constexpr int C = W / 16;
-    float ov[C];
-#pragma unroll
-    for (int c = 0; c < C; ++c) ov[c] = 0.0f;
-#pragma unroll
-    for (int j = 0; j < FA_POLICY_MAX_TEAM; ++j)
-        if (j < nk) {
-            const float a = attn_row[j];
-#pragma unroll
-            for (int c = 0; c < C; c += 4) {
-                const float4 kv = *reinterpret_cast<const float4 *>(key0 + j * LDA + q * C + c);
-                ov[c] = fmaf(a, kv.x, ov[c]); ov[c + 1] = fmaf(a, kv.y, ov[c + 1]);
-                ov[c + 2] = fmaf(a, kv.z, ov[c + 2]); ov[c + 3] = fmaf(a, kv.w, ov[c + 3]);
-            }
-        }
-#pragma unroll
-    for (int c = 0; c < C; c += 4) *reinterpret_cast<float4 *>(orow + q * C + c) = *reinterpret_cast<const float4 *>(ov + c);
 }
 
 // Backward of the attention of ONE env by a 16-lane sub-group (cf. fa_attend.hip): rows r0 .. r0+n-1 of
@@ -157,12 +153,6 @@ __device__ __forceinline__ void attend_env_bwd(const float *dout0, float *g0, co
 }
 
 // GATHER: the minibatch is rows a.idx[.] of the rollout arrays (else rows 0..B)
-// SHARE: a register cap (amdgpu_num_vgpr counts architectural and accumulation registers separately) that leaves room
-// on a CU for the other team's small launches when the two teams' updates run as concurrent chains (fold / unfold
-// tasks, reductions, clip, Adam); a lone chain (guards-only training, FaTrainArgs::share_cu = 0) runs the uncapped build.
-#ifndef FA_TRAIN_NUM_VGPR
-#define FA_TRAIN_NUM_VGPR 104
-#endif
 // MT: the attention backward's key / key-gradient registers are sized for teams of up to MT agents (4, 6 or 8)
 template <bool GATHER, int MT>
 __device__ __forceinline__ void fa_train_body(const FaTrainArgs &a) {
@@ -189,6 +179,7 @@ __device__ __forceinline__ void fa_train_body(const FaTrainArgs &a) {
     const float4 *Wq = reinterpret_cast<const float4 *>(a.w), *Tq = reinterpret_cast<const float4 *>(a.wt);
     float *mslab = a.mslab + (size_t)blockIdx.x * FA_MSLAB_FLOATS;
     float *recA = a.rec_a + (size_t)blockIdx.x * 3 * FA_RECA_FLOATS, *recB = a.rec_b + (size_t)blockIdx.x * FA_RECB_FLOATS;
+    float *recG = a.rec_g + (size_t)blockIdx.x * 3 * FA_REC_PLANE;
 
     // dense tile <-> LDS: W floats per row (128: four 16-byte pieces per thread; 64: two)
     auto save_tile = [&](const float *src, float *dst) { // 32 x 128 LDS -> global
@@ -262,6 +253,21 @@ __device__ __forceinline__ void fa_train_body(const FaTrainArgs &a) {
         store_acc<false>(dst + cbw * 32, 0, acc[0], 0.0f, lane);
     };
 
+#if defined(FA_TRAIN_STAGGER) && FA_TRAIN_STAGGER > 0
+    // (experiment: two workgroups that start together on a CU march through the same phases in lock step -- both in a
+    //  GEMM, then both outside one; delay every second first-round workgroup)
+    if (blockIdx.x < 512 && ((FA_TRAIN_STAGGER == 1 ? blockIdx.x : (blockIdx.x >> 8)) & 1))
+        for (int k = 0; k < FA_TRAIN_STAGGER_SLEEPS; ++k) __builtin_amdgcn_s_sleep(127);
+#endif
+    // the loss inputs of this lane's row (wave 0: a lane per row), requested now: two dependent HBM round trips (index, then
+    // row) that would otherwise stand in front of the single-wave loss phase
+    float l_vp = 0.0f, l_rt = 0.0f, l_adv = 0.0f, l_olp = 0.0f;
+    int l_act = 0;
+    if (wave == 0 && lane < ne * n) {
+        const int el = lane / n, i = lane - el * n;
+        const size_t o = (size_t)(GATHER ? a.idx[e0 + el] : (int64_t)(e0 + el)) * N + own0 + i;
+        l_act = (int)a.action[o]; l_vp = a.value_pred[o]; l_rt = a.ret[o]; l_adv = a.adv[o]; l_olp = a.old_logp[o];
+    }
     FA_TR_TICK(0)
     // ================================ forward ==========================================================
     if (GATHER) {
@@ -279,9 +285,21 @@ __device__ __forceinline__ void fa_train_body(const FaTrainArgs &a) {
     __syncthreads();
     project_opp();
     __syncthreads();
-    for (int r = wave * 4 + (lane >> 4); r < TR; r += NWV * 4) // opponent attention (mpnn.py:372-443)
-        if (r < RU) attend_row<64>(B1 + r * LDA + 64, B2 + ((r / n) * m) * LDA, m, -1, B1 + r * LDA + 64, q16, sAttn[0] + r * 8);
+    {   // opponent attention (mpnn.py:372-443): both of a sub-group's rows computed before either is stored
+        float ov[2][4];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int r = wave * 4 + (lane >> 4) + k * NWV * 4, rr = r < RU ? r : RU - 1;
+            attend_row_regs<64, MT>(B1 + rr * LDA + 64, B2 + ((rr / n) * m) * LDA, m, -1, q16, ov[k], r < RU ? sAttn[0] + r * 8 : nullptr);
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int r = wave * 4 + (lane >> 4) + k * NWV * 4;
+            if (r < RU) store_row_regs<64>(B1 + r * LDA + 64, q16, ov[k]);
+        }
+    }
     __syncthreads();
+    save_tile64(B1 + 64, recB + FA_RECB_MO); // (an operand of dB_o = mix_o^T de_opp)
     if (wave < 2) {   // e_opp = mix_o B_o -> B0[:, 64:128]
         BHead<64> hd;
         const float4 *wp = Wq + FA_POFF_BO / 4 + wave * 8 * 64;
@@ -304,13 +322,38 @@ __device__ __forceinline__ void fa_train_body(const FaTrainArgs &a) {
         FA_TR_TICK(10 + 5 * round)
         __syncthreads();
         FA_TR_TICK(11 + 5 * round)
-        for (int r = wave * 4 + (lane >> 4); r < TR; r += NWV * 4) { // team attention, self excluded (mpnn.py:250-332)
-            const int el = r / n;
-            if (r < RU) attend_row<128>(B1 + r * LDA, B0 + (el * n) * LDA, n, r - el * n, B1 + r * LDA, q16, sAttn[1 + round] + r * 8);
+        {   // team attention, self excluded (mpnn.py:250-332); rows beyond the tile's envs: hmix = 0
+            float ov[2][8];
+#ifndef FA_TRAIN_RECOMPUTE_G
+            // g is saved for the backward (a GEMM and a barrier less per round there) by the sub-group that is about to
+            // overwrite the row with the mix -- no other wave touches it in this phase
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int r = wave * 4 + (lane >> 4) + k * NWV * 4;
+                float4 *dst = reinterpret_cast<float4 *>(recG + round * FA_REC_PLANE + r * 128 + q16 * 8);
+                dst[0] = *reinterpret_cast<const float4 *>(B1 + r * LDA + q16 * 8);
+                dst[1] = *reinterpret_cast<const float4 *>(B1 + r * LDA + q16 * 8 + 4);
+            }
+#endif
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int r = wave * 4 + (lane >> 4) + k * NWV * 4, rr = r < RU ? r : RU - 1, el = rr / n;
+                attend_row_regs<128, MT>(B1 + rr * LDA, B0 + (el * n) * LDA, n, rr - el * n, q16, ov[k], r < RU ? sAttn[1 + round] + r * 8 : nullptr);
+            }
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int r = wave * 4 + (lane >> 4) + k * NWV * 4;
+                if (r >= RU) {
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) ov[k][c] = 0.0f;
+                }
+                store_row_regs<128>(B1 + r * LDA, q16, ov[k]);
+            }
         }
         FA_TR_TICK(12 + 5 * round)
         __syncthreads();
         FA_TR_TICK(13 + 5 * round)
+        save_tile(B1, recA + round * FA_RECA_FLOATS + FA_RECA_HMIX); // (an operand of dW7; the backward does not need it)
         {   // h' = relu([h | hmix] W7 + bu)
             f32x16 acc[1] = {};
             gemm_cb<256, 1>((hh ? B1 : B0) + li * LDA, wp_u, acc, lane, hd_u);
@@ -373,7 +416,6 @@ __device__ __forceinline__ void fa_train_body(const FaTrainArgs &a) {
         for (int k = 0; k < FA_NUM_ACTIONS; ++k) dlg[k] = 0.0f;
         if (r < ne * n) {
             const int el = r / n, i = r - el * n;
-            const size_t o = (size_t)(GATHER ? a.idx[e0 + el] : (int64_t)(e0 + el)) * N + own0 + i;
             const float *lo = sO + r * SOW;
             mk = sX[(el * N + own0 + i) * FA_OBS_DIM]; // the alive flag (ppo.py:224)
             float lg[FA_NUM_ACTIONS], mx = -INFINITY;
@@ -383,7 +425,7 @@ __device__ __forceinline__ void fa_train_body(const FaTrainArgs &a) {
 #pragma unroll
             for (int k = 0; k < FA_NUM_ACTIONS; ++k) se += expf(lg[k] - mx);
             const float lse = mx + logf(se);
-            const int act = (int)a.action[o];
+            const int act = l_act;
             float p[FA_NUM_ACTIONS], lpk[FA_NUM_ACTIONS], ent = 0.0f, lp = 0.0f;
 #pragma unroll
             for (int k = 0; k < FA_NUM_ACTIONS; ++k) {
@@ -392,8 +434,8 @@ __device__ __forceinline__ void fa_train_body(const FaTrainArgs &a) {
                 ent -= p[k] * lpk[k];
                 lp = (k == act) ? lpk[k] : lp;
             }
-            const float value = lo[8], vp = a.value_pred[o], rt = a.ret[o], adv = a.adv[o];
-            const float ratio = mk * expf(lp - a.old_logp[o]);
+            const float value = lo[8], vp = l_vp, rt = l_rt, adv = l_adv;
+            const float ratio = mk * expf(lp - l_olp);
             const float s1 = ratio * adv, rc = fminf(fmaxf(ratio, 1.0f - a.clip), 1.0f + a.clip), s2 = rc * adv;
             al = mk * -fminf(s1, s2);
             // d(-min(s1, s2))/dlp: through s1 when it is the smaller (ties: both paths agree), else through the
@@ -504,7 +546,7 @@ __device__ __forceinline__ void fa_train_body(const FaTrainArgs &a) {
         prefetch_b<256>(wp, lane, hd);
         f32x16 acc[1] = {};
         gemm_cb<256, 1>((hh ? B2 : B1) + li * LDA, wp, acc, lane, hd);
-        store_acc<false>(B3 + cbw * 32, 0, acc[0], 0.0f, lane);
+        store_acc_gate(B3 + cbw * 32, B0 + cbw * 32, acc[0], lane); // = dZ of round 2: through the relu of h3 (B0)
     }
     __syncthreads();
 
@@ -513,13 +555,14 @@ __device__ __forceinline__ void fa_train_body(const FaTrainArgs &a) {
     float dbu = 0.0f; // threads 0..127: their column of the update bias gradient
     for (int round = 2; round >= 0; --round) {
         float *rec = recA + round * FA_RECA_FLOATS;
-        // dZ = dL/dh_out through the relu (in place in B3)
-        for (int k = tid; k < TR * 128; k += NTH) {
-            const int r = k >> 7, c = k & 127;
-            if (!(B0[r * LDA + c] > 0.0f)) B3[r * LDA + c] = 0.0f;
-        }
-        __syncthreads();
-        FA_TR_TICK(30 + 8 * (2 - round))
+        // B3 = dZ of this round (the relu gate was applied by the store that completed it).  h_in is requested now and
+        // lands in B0 behind the first GEMM, which needs dZ only.
+        // (order of the requests: the vector-memory counter retires in order, so the first GEMM's weights go first and
+        //  h_in -- an HBM round trip that the GEMM covers -- last)
+        BHead<128> ha, hm;
+        const float4 *wpa = Tq + FA_TOFF_W7T / 4 + cbw * 16 * 64, *wpm = Tq + FA_TOFF_W7T / 4 + (4 + cbw) * 16 * 64;
+        prefetch_b<128>(wpa, lane, ha);
+        prefetch_b<128>(wpm, lane, hm);
         {   // the update bias gradient: two 16-row partial sums per column of dZ, folded behind the next barrier
             const int col = tid & 127, q = tid >> 7;
             float sum = 0.0f;
@@ -528,60 +571,73 @@ __device__ __forceinline__ void fa_train_body(const FaTrainArgs &a) {
             sO2[q * 128 + col] = sum;
         }
         save_tile(B3, rec + FA_RECA_DZ);
-        // h_in -> B0, g = h_in A_m -> B2 (recomputed), hmix -> B1 (recomputed from the saved weights)
-        BHead<128> hd_g;
-        prefetch_b<128>(wp_am, lane, hd_g);
-        load_tile(B0, rec + FA_RECA_HIN);
-        FA_TR_TICK(31 + 8 * (2 - round))
-        __syncthreads();
-        FA_TR_TICK(32 + 8 * (2 - round))
-        if (tid < 128) dbu += sO2[tid] + sO2[128 + tid];
-        project_team(B2, hd_g);
-        for (int r = wave * 4 + (lane >> 4); r < TR; r += NWV * 4) {
-            if (r < RU) mix_row<128>(sAttn[1 + round] + r * 8, B0 + ((r / n) * n) * LDA, n, B1 + r * LDA, q16);
-            else {
-                *reinterpret_cast<float4 *>(B1 + r * LDA + q16 * 8) = float4{0, 0, 0, 0};
-                *reinterpret_cast<float4 *>(B1 + r * LDA + q16 * 8 + 4) = float4{0, 0, 0, 0};
-            }
-        }
-        __syncthreads();
-        FA_TR_TICK(33 + 8 * (2 - round))
-        save_tile(B1, rec + FA_RECA_HMIX);
+        float4 hin[TR * 32 / NTH];
+#pragma unroll
+        for (int j = 0; j < TR * 32 / NTH; ++j) hin[j] = reinterpret_cast<const float4 *>(rec + FA_RECA_HIN)[tid + j * NTH];
+#ifndef FA_TRAIN_RECOMPUTE_G
+        float4 gin[TR * 32 / NTH];
+#pragma unroll
+        for (int j = 0; j < TR * 32 / NTH; ++j) gin[j] = reinterpret_cast<const float4 *>(recG + round * FA_REC_PLANE)[tid + j * NTH];
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+        FA_TR_TICK(30 + 8 * (2 - round))
         {   // [dh_a | dhmix] = dZ W7^T (K = 128 -> 256 columns)
-            BHead<128> ha, hm;
-            const float4 *wpa = Tq + FA_TOFF_W7T / 4 + cbw * 16 * 64, *wpm = Tq + FA_TOFF_W7T / 4 + (4 + cbw) * 16 * 64;
-            prefetch_b<128>(wpa, lane, ha);
-            prefetch_b<128>(wpm, lane, hm);
             f32x16 aa[1] = {}, am[1] = {};
             gemm_cb<128, 1>(B3 + li * LDA + hh * 64, wpa, aa, lane, ha);
             gemm_cb<128, 1>(B3 + li * LDA + hh * 64, wpm, am, lane, hm);
-            FA_TR_TICK(34 + 8 * (2 - round))
-            __syncthreads(); // every wave has read dZ; hmix is saved
+            FA_TR_TICK(31 + 8 * (2 - round))
+            __syncthreads(); // every wave has read dZ (and the gate in B0, when the store above was the previous round's)
             store_acc<false>(B3 + cbw * 32, 0, aa[0], 0.0f, lane);
             store_acc<false>(B1 + cbw * 32, 0, am[0], 0.0f, lane);
         }
+#pragma unroll
+        for (int j = 0; j < TR * 32 / NTH; ++j) {
+            const int k = tid + j * NTH;
+            *reinterpret_cast<float4 *>(B0 + (k >> 5) * LDA + (k & 31) * 4) = hin[j];
+        }
+#ifdef FA_TRAIN_RECOMPUTE_G
+        BHead<128> hd_g;
+        prefetch_b<128>(wp_am, lane, hd_g);
         __syncthreads();
-        FA_TR_TICK(35 + 8 * (2 - round))
-        // attention backward per env: dhmix (B1), g (B2) -> dg (B2 in place), dkeys added into B3.  The rows
-        // beyond the tile's envs hold a recomputed g of padding rows: their dg is zero
+        FA_TR_TICK(32 + 8 * (2 - round))
+        if (tid < 128) dbu += sO2[tid] + sO2[128 + tid];
+        project_team(B2, hd_g); // g = h_in A_m -> B2, recomputed
+        BHead<128> hd;
+        const float4 *wp = Tq + FA_TOFF_AMT / 4 + cbw * 16 * 64;
+        prefetch_b<128>(wp, lane, hd);
+        __syncthreads();
+        FA_TR_TICK(33 + 8 * (2 - round))
         if (wave == 0 && lane < 32)
             for (int r = RU; r < TR; ++r) *reinterpret_cast<float4 *>(B2 + r * LDA + lane * 4) = float4{0, 0, 0, 0};
+#else
+        // g -> B2 (rows beyond the tile's envs hold the g of padding rows: their dg is zero)
+#pragma unroll
+        for (int j = 0; j < TR * 32 / NTH; ++j) {
+            const int k = tid + j * NTH;
+            *reinterpret_cast<float4 *>(B2 + (k >> 5) * LDA + (k & 31) * 4) = (k >> 5) < RU ? gin[j] : float4{0, 0, 0, 0};
+        }
+        BHead<128> hd;
+        const float4 *wp = Tq + FA_TOFF_AMT / 4 + cbw * 16 * 64;
+        prefetch_b<128>(wp, lane, hd);
+        __syncthreads();
+        FA_TR_TICK(33 + 8 * (2 - round))
+        if (tid < 128) dbu += sO2[tid] + sO2[128 + tid];
+#endif
+        // attention backward per env: dhmix (B1), g (B2) -> dg (B2 in place), dkeys added into B3
         for (int el = wave * 4 + (lane >> 4); el < ET; el += NWV * 4)
             attend_env_bwd<128, true, MT>(B1 + (el * n) * LDA, B2 + (el * n) * LDA, B0 + (el * n) * LDA, B3 + (el * n) * LDA,
                                           sAttn[1 + round] + (el * n) * 8, n, n, q16);
         __syncthreads();
-        FA_TR_TICK(36 + 8 * (2 - round))
+        FA_TR_TICK(34 + 8 * (2 - round))
         save_tile(B2, rec + FA_RECA_DG);
-        {   // dh += dg A_m^T
-            BHead<128> hd;
-            const float4 *wp = Tq + FA_TOFF_AMT / 4 + cbw * 16 * 64;
-            prefetch_b<128>(wp, lane, hd);
+        {   // dh += dg A_m^T, and -- rounds 2, 1 -- through the relu of the round below (its output is this round's h_in)
             f32x16 acc[1] = {};
             gemm_cb<128, 1>(B2 + li * LDA + hh * 64, wp, acc, lane, hd);
-            store_acc_add(B3 + cbw * 32, acc[0], lane);
+            if (round > 0) store_acc_add_gate(B3 + cbw * 32, B0 + cbw * 32, acc[0], lane);
+            else store_acc_add(B3 + cbw * 32, acc[0], lane);
         }
         __syncthreads();
-        FA_TR_TICK(37 + 8 * (2 - round))
+        FA_TR_TICK(35 + 8 * (2 - round))
     }
     if (tid < 128) mslab[FA_MSLAB_BU + tid] = dbu;
 
@@ -590,13 +646,7 @@ __device__ __forceinline__ void fa_train_body(const FaTrainArgs &a) {
     encoders(nullptr, B2); // ho -> B2[:, 0:64] (opponent rows), recomputed
     __syncthreads();
     project_opp();         // g_o -> B1[:, 64:128], recomputed
-    for (int r = wave * 4 + (lane >> 4); r < TR; r += NWV * 4) { // mix_o -> B1[:, 0:64], from the saved weights
-        if (r < RU) mix_row<64>(sAttn[0] + r * 8, B2 + ((r / n) * m) * LDA, m, B1 + r * LDA, q16);
-        else *reinterpret_cast<float4 *>(B1 + r * LDA + q16 * 4) = float4{0, 0, 0, 0};
-    }
-    __syncthreads();
-    save_tile64(B1, recB + FA_RECB_MO);        // dB_o = mix_o^T de_opp
-    save_tile64(B3 + 64, recB + FA_RECB_DE);
+    save_tile64(B3 + 64, recB + FA_RECB_DE);   // dB_o = mix_o^T de_opp (mix_o: saved by the forward)
     save_tile64(B0, recB + FA_RECB_H1);        // dA_o = h1^T dg_o
     if (wave < 2) {   // dmix_o = de_opp B_o^T -> B2[:, 64:128]
         BHead<64> hd;
@@ -658,11 +708,9 @@ __device__ __forceinline__ void fa_train_body(const FaTrainArgs &a) {
 
 template <bool GATHER, int MT>
 __global__ __launch_bounds__(NTH, 2) void fa_train_kernel(FaTrainArgs a) { fa_train_body<GATHER, MT>(a); }
-// (the attribute takes a literal, not a template argument: hence a second kernel and not another parameter)
-template <int MT>
-__global__ __launch_bounds__(NTH, 2) __attribute__((amdgpu_num_vgpr(FA_TRAIN_NUM_VGPR))) void fa_train_share_kernel(FaTrainArgs a) {
-    fa_train_body<true, MT>(a);
-}
+// (Rounds 2-3 had a second, register-capped build for the two teams' concurrent update chains -- it left room on a CU for
+//  the other chain's small launches.  With two 4-wave workgroups per CU the capped build spills more than the sharing
+//  gains: 0.229 s per update capped, 0.207 s uncapped.  FaTrainArgs::share_cu is accepted and ignored.)
 
 // The alive-mask sum of the minibatch's own-team rows as FA_MASK_PARTS partial sums (one workgroup each; the
 // train kernel's workgroups fold them in a fixed order: reproducible, and no single-workgroup latency chain)
@@ -727,8 +775,7 @@ hipError_t fa_launch_train(const FaTrainArgs &a, hipStream_t st) {
     const int big = a.G > a.A ? a.G : a.A;
 #define FA_TRAIN_LAUNCH(MT)                                                                                   \
     do {                                                                                                      \
-        if (a.idx && a.share_cu) hipLaunchKernelGGL(fa_train_share_kernel<MT>, grid, block, 0, st, a);        \
-        else if (a.idx) hipLaunchKernelGGL((fa_train_kernel<true, MT>), grid, block, 0, st, a);               \
+        if (a.idx) hipLaunchKernelGGL((fa_train_kernel<true, MT>), grid, block, 0, st, a);                    \
         else hipLaunchKernelGGL((fa_train_kernel<false, MT>), grid, block, 0, st, a);                         \
     } while (0)
     if (big <= 4) FA_TRAIN_LAUNCH(4);

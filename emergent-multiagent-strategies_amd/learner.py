@@ -672,7 +672,7 @@ class BatchedLearner(object):
             if key not in g:
                 g[key] = GraphedPPOStep(self.policies[ti], self.optimizers[ti], self.team_slices[ti], self.team_slices[1 - ti],
                                         rows, mb, self.clip_param, self.value_loss_coef, self.entropy_coef, self.max_grad_norm,
-                                        self.clipped_value_loss, self._team_groups[ti], fused=True, share_cu=True,
+                                        self.clipped_value_loss, self._team_groups[ti], fused=True, share_cu=g.get("share_cu", True),
                                         exchange=self._team_exch[ti])
             steps.append(g[key])
             assert all(a.data_ptr() == b.data_ptr() for a, b in zip(rows, g[key].rows)), "the captured step reads the rollout in place"

@@ -318,8 +318,8 @@ typedef struct fa_ppo_grad_io {
     float clip_param, value_loss_coef, entropy_coef;
     int32_t clipped_value_loss;
     int32_t normalize;         /* with scale == NULL: 1 = divide by the alive-mask mean here, 0 = the caller will */
-    int32_t share_cu;          /* 1: run the build that leaves 48 registers per lane free on every CU it occupies, for
-                                  launches of another stream to run beside it (two teams updated concurrently) */
+    int32_t share_cu;          /* accepted and ignored (rounds 2-3: a register-capped build of the tile kernel that left
+                                  room on its CUs for another stream's launches; the round-4 kernel does better uncapped) */
 } fa_ppo_grad_io;
 int fa_ppo_grad(const fa_ppo_grad_io *io, void *stream);
 int64_t fa_ppo_grad_floats(void);

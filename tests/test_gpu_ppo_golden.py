@@ -25,8 +25,8 @@ def test_fused_step_matches_the_reference_golden(golden_dir, tag):
     before = {k: p.detach().clone() for k, p in pol.named_parameters()}
     losses = step.run(c["rows"], torch.arange(B, device="cuda"))
     torch.cuda.synchronize()
-    # the fused kernels sum in another order than autograd (observed: <= 1e-5 of a tensor largest entry; bound 10 x)
-    # autograd comparisons use; observed here: see the printed line
+    # the fused kernels sum in another order than autograd: observed <= 1e-5 of a tensor's largest entry (the printed
+    # line); the bound is 10 x that
     dl, worst = ppo_golden.compare(c, losses.cpu().numpy(), before, grad_tol=1e-4)
     print("%s: losses within %.1e, gradients within %.1e of each tensor's largest entry" % (tag, dl, worst))
     assert dl < 1e-5

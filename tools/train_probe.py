@@ -39,10 +39,9 @@ for r in range(3):
                   b + 3: "  fwd round %d: barrier" % r, b + 4: "  fwd round %d: gemm256, barrier, store, barrier, save h" % r})
 for k in range(3):
     b = 30 + 8 * k
-    names.update({b: "  bwd round %d: relu mask + barrier" % (2 - k), b + 1: "  bwd round %d: bias sums, save dZ, reload h (issue)" % (2 - k),
-                  b + 2: "  bwd round %d: barrier (h landed)" % (2 - k), b + 3: "  bwd round %d: g recompute + mix + barrier" % (2 - k),
-                  b + 4: "  bwd round %d: save hmix + dZ W7^T (2 gemm128)" % (2 - k), b + 5: "  bwd round %d: barrier, stores, barrier" % (2 - k),
-                  b + 6: "  bwd round %d: attention backward + barrier" % (2 - k), b + 7: "  bwd round %d: save dg + dg A^T + add + barrier" % (2 - k)})
+    names.update({b: "  bwd round %d: request h_in, bias sums, save dZ" % (2 - k), b + 1: "  bwd round %d: dZ W7^T (2 gemm128)" % (2 - k),
+                  b + 2: "  bwd round %d: barrier, stores, h_in -> LDS, barrier" % (2 - k), b + 3: "  bwd round %d: g recompute + barrier" % (2 - k),
+                  b + 4: "  bwd round %d: attention backward + barrier" % (2 - k), b + 5: "  bwd round %d: save dg + dg A^T + gated add + barrier" % (2 - k)})
 order = [0, 1] + list(range(10, 25)) + [2, 3, 4, 5] + list(range(30, 54)) + [60, 61, 62]
 keys = [k for k in order if k in names and buf[k]]
 prev = None
