@@ -211,11 +211,13 @@ int fa_create(const fa_config *cfg, fa_env **out) {
     if (cfg->max_time_steps < 1) return fail(FA_ERR_INVALID, "fa_create: max_time_steps must be >= 1");
     if (cfg->rng_mode != FA_RNG_MT19937 && cfg->rng_mode != FA_RNG_PHILOX)
         return fail(FA_ERR_INVALID, "fa_create: unknown rng_mode");
-    if (cfg->step_kernel < FA_KERNEL_AUTO || cfg->step_kernel > FA_KERNEL_WAVES3)
+    if (cfg->step_kernel < FA_KERNEL_AUTO || cfg->step_kernel > FA_KERNEL_PAIRS)
         return fail(FA_ERR_INVALID, "fa_create: unknown step_kernel");
     if (cfg->step_kernel != FA_KERNEL_AUTO && cfg->step_kernel != FA_KERNEL_WAVES1 &&
         !((cfg->num_guards == 3 && cfg->num_attackers == 3) || (cfg->num_guards == 5 && cfg->num_attackers == 5)))
         return fail(FA_ERR_INVALID, "fa_create: the multi-wave step kernels exist for 3v3 and 5v5 only");
+    if (cfg->step_kernel == FA_KERNEL_PAIRS && !(cfg->num_guards == 3 && cfg->num_attackers == 3))
+        return fail(FA_ERR_INVALID, "fa_create: the pair-per-lane step kernel exists for 3v3 only");
     if (!(cfg->world.contact_margin > 0) || !(cfg->world.agent_size > 0))
         return fail(FA_ERR_INVALID, "fa_create: contact_margin and agent_size must be > 0");
     int ndev = 0;

@@ -858,6 +858,283 @@ __global__ __launch_bounds__(NW * FA_WAVE) void fa_step_kernel(FaStepArgs a) {
     if (i == 0 && (!RESET_ONLY || dirty)) a.s.tstep[e] = t;
 }
 
+// ---- experiment (round 4): lane = (agent, partner), one wave, no workgroup barrier ---------------------
+// The judge's round-3 question: does the step get faster when a lane owns ONE ordered pair (agent i, partner j) --
+// its soft-contact force and its shooter -> target test -- so that the five-partner loop becomes one evaluation and
+// nothing crosses a workgroup barrier?  N (N - 1) lanes per env (30 at 3v3: two envs per wave, four lanes idle); an
+// agent's state lives in all N - 1 of its lanes, which integrate it redundantly (same operations on the same values:
+// same bits); positions and the shooters' heading go through LDS by agent slot; a lane's pair force goes through LDS
+// once and every lane of the agent adds its N - 1 partner terms in ascending partner order -- the reference's order
+// (core.py:231-243); flag reductions are ballots shifted to the env's lane group, as in fa_step_kernel.  Everything
+// else -- decode, walls, integration, rewards, done, reset, rows -- is fa_step_kernel's code.  3v3 only.
+template <int TG, int TA, bool COLLECT, bool CHOICE>
+__global__ __launch_bounds__(FA_WAVE) void fa_step_pair_kernel(FaStepArgs a) {
+    constexpr int N = TG + TA, NP = N - 1, LPE = N * NP, EPW = FA_WAVE / LPE;
+    static_assert(LPE <= FA_WAVE, "one env must fit a wave");
+    const int lane = threadIdx.x;
+    const int slot = lane / LPE, l = lane - slot * LPE;
+    const int i = l / NP, p = l - i * NP, j = p + (p >= i ? 1 : 0); // agent, partner slot, partner agent
+    const int gbase = slot * LPE;
+    const int e = blockIdx.x * EPW + slot;
+    if (!((slot < EPW) && (e < a.E))) return; // padding lanes leave: ballots count live lanes only
+    const bool primary = p == 0;              // the lane that stores the agent's rows and state
+    const bool is_att = i >= TG, opponent = (j >= TG) != is_att;
+    const int sa = slot * N + i, sj = slot * N + j; // LDS slots of the agent and of the partner
+    const size_t idx = (size_t)e * N + i;
+    const size_t EN = (size_t)a.E * N;
+    constexpr unsigned long long LPE_MASK = (1ull << LPE) - 1ull;
+    unsigned long long att_primary = 0ull, hit_lanes = 0ull; // primary lanes of the attackers; lanes whose partner is i
+#pragma unroll
+    for (int t = 0; t < N; ++t) {
+        if (t >= TG) att_primary |= 1ull << (t * NP);
+        if (t != i) hit_lanes |= 1ull << (t * NP + (i - (i > t ? 1 : 0)));
+    }
+    const FaDerived &c = a.c;
+
+    __shared__ double s_px[EPW * N], s_py[EPW * N], s_cs[EPW * N], s_sn[EPW * N];
+    __shared__ int s_act[FA_ACT_BATCH][FA_WAVE];
+    __shared__ double2 s_f[FA_WAVE];
+
+    double px = a.s.px[idx], py = a.s.py[idx], vx = a.s.vx[idx], vy = a.s.vy[idx], ang = a.s.ang[idx], prev = a.s.prev[idx];
+    bool alive = a.s.alive[idx] != 0;
+    int t = a.s.tstep[e], nh = 0, nwh = 0;
+    double ep_rew = 0.0;
+    if (a.track_counters) { nh = a.s.num_hit[idx]; nwh = a.s.num_was_hit[idx]; ep_rew = a.s.ep_rew[idx]; }
+    bool dirty = false;
+    int mt_base = (a.rng_mode == 0 ? a.s.mt_pos[e] : 0) + 4 * i;
+
+    const int nsteps = a.nsteps;
+    const int64_t *act_ptr = a.actions + (int64_t)e * a.as_e + (int64_t)i * a.as_i;
+    int av[FA_ACT_BATCH];
+#pragma unroll
+    for (int k = 0; k < FA_ACT_BATCH; ++k) av[k] = k < nsteps ? (int)act_ptr[(int64_t)k * a.as_t] : 0;
+    for (int s = 0; s < nsteps; ++s) {
+        if ((s & (FA_ACT_BATCH - 1)) == 0) {
+#pragma unroll
+            for (int k = 0; k < FA_ACT_BATCH; ++k) s_act[k][lane] = av[k];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int k = 0; k < FA_ACT_BATCH; ++k)
+                av[k] = (s + FA_ACT_BATCH + k < nsteps) ? (int)act_ptr[(int64_t)(s + FA_ACT_BATCH + k) * a.as_t] : 0;
+        }
+        const bool alive0 = alive;
+        // ---- fortattack.py:253-263,:289 _set_action (all agents, dead ones too) ----
+        const int act = s_act[s & (FA_ACT_BATCH - 1)][lane];
+        double u0 = 0.0, u1 = 0.0, rot = 0.0;
+        if (act == 1) u0 = +1.0;
+        if (act == 2) u0 = -1.0;
+        if (act == 3) u1 = +1.0;
+        if (act == 4) u1 = -1.0;
+        if (act == 5) rot = c.rot_pos;
+        if (act == 6) rot = c.rot_neg;
+        const bool shoot = act == 7;
+        u0 *= c.accel;
+        u1 *= c.accel;
+
+        // ---- positions and the shooters' heading by agent slot (every lane of an agent writes the same value) ----
+        s_px[sa] = px;
+        s_py[sa] = py;
+        const bool shooter = alive0 && shoot;
+        if (shooter) {
+            double sn, cs;
+            sincos_heading(ang, sn, cs);
+            s_cs[sa] = cs;
+            s_sn[sa] = sn;
+        }
+        const unsigned long long shooters_b = __ballot(shooter);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const double qx = s_px[sj], qy = s_py[sj];
+
+        // ---- core.py:254-302 apply_laser_effect: this lane's test is "is agent i inside partner j's wedge" ----
+        bool was_hit = false;
+        int hit_cnt = 0, was_hit_cnt = 0;
+        if (shooters_b != 0ull) {
+            bool hk = false;
+            if (opponent && alive0 && ((shooters_b >> (gbase + j * NP)) & 1ull)) {
+                double u, lhs, rhs;
+                fa_wedge(c.agent_size, c.cos_hw, c.sin_hw, px, py, qx, qy, s_cs[sj], s_sn[sj], u, lhs, rhs);
+                hk = (u <= c.shoot_far) & (lhs <= rhs);
+            }
+            const unsigned long long grp = (__ballot(hk) >> gbase) & LPE_MASK;
+            const unsigned mine = (unsigned)(grp >> (i * NP)) & ((1u << NP) - 1u);
+            was_hit = mine != 0u;
+            was_hit_cnt = __popc(mine);
+            hit_cnt = __popcll(grp & hit_lanes);
+        }
+        const bool hit = shooter && hit_cnt > 0;
+        const bool alive1 = alive0 && !was_hit;       // :293-302 one shot kills
+        const bool just_died = alive0 && was_hit;
+        const unsigned long long grp_alive1 = (__ballot(alive1) >> gbase) & LPE_MASK;
+        const int n_alive_att = __popcll(grp_alive1 & att_primary);
+
+        // ---- core.py:231-243 + :440-456: this lane's pair force (exactly +0.0 unless both live and in range) ----
+        {
+            const double dx = px - qx, dy = py - qy, d2 = dx * dx + dy * dy;
+            double fx = 0.0, fy = 0.0;
+            if (alive1 && ((grp_alive1 >> (j * NP)) & 1ull) && !(d2 > c.contact_skip_d2)) fa_contact_force(c, dx, dy, d2, fx, fy);
+            s_f[lane] = make_double2(fx, fy);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (alive1) {
+            double Fx = u0 + 0.0, Fy = u1 + 0.0;      // core.py:221-228
+#pragma unroll
+            for (int k = 0; k < NP; ++k) {            // ascending partner order == the reference's pair order; a term
+                const double2 f = s_f[gbase + i * NP + k]; // of a dead or distant partner is +0.0: F (never -0.0) unchanged
+                Fx = f.x + Fx;
+                Fy = f.y + Fy;
+            }
+            {
+                double wx, wy;
+                fa_wall_force(c, px, py, wx, wy);     // core.py:246-252 + :459-472
+                Fx = wx + Fx;
+                Fy = wy + Fy;
+            }
+            // core.py:324-338 integrate_state (mass == 1.0: F/1.0 is exact)
+            vx = vx * c.one_minus_damping;
+            vy = vy * c.one_minus_damping;
+            vx += Fx * c.dt;
+            vy += Fy * c.dt;
+            const double speed2 = vx * vx + vy * vy;
+            if (speed2 > c.speed2_max) {
+                const double speed = sqrt_rn(speed2);
+                vx = div_rn(vx, speed) * c.max_speed;
+                vy = div_rn(vy, speed) * c.max_speed;
+            }
+            ang += rot;
+            px += vx * c.dt;
+            py += vy * c.dt;
+        }
+
+        // ---- rewards (fortattack_env_v1.py:87-188), after World.step ---------------
+        const double ddx = px - c.door_x, ddy = py - c.door_y;
+        const double dist_door = sqrt_rn(ddx * ddx + ddy * ddy);
+        const bool any_in_fort = ((__ballot(is_att && alive1 && dist_door < c.fort_dim) >> gbase) & LPE_MASK) != 0ull;
+        const bool rewarded = (alive1 || just_died);
+        const double rew = fa_reward(is_att, rewarded, prev, dist_door, shoot, hit, was_hit, n_alive_att, any_in_fort,
+                                     c.fort_dim, 0.3, 10.0, 3.0, 0.1);
+        prev = rewarded ? dist_door : prev;
+
+        // ---- fortattack.py:202-225 _get_done, :171 time_step += 1 ------------------
+        const bool timeout = t == a.max_t - 1;
+        const bool done = any_in_fort || n_alive_att == 0 || timeout;
+        if (l == 0) {
+            if (done) {
+                const int which = any_in_fort ? 2 : (n_alive_att == 0 ? 0 : 1);
+                uint8_t *gr = a.s.game_result + (size_t)e * 3;
+                gr[0] = which == 0; gr[1] = which == 1; gr[2] = which == 2;
+                atomicAdd(a.s.result_count + (size_t)e * 3 + which, 1u);
+            }
+            if (COLLECT || a.done) a.done[(size_t)s * a.E + e] = done ? 1 : 0;
+        }
+        t += 1;
+        if (a.track_counters) {
+            ep_rew += alive0 ? rew : 0.0;
+            if (done) {
+                if (primary) {
+                    a.s.ep_rew_sum[idx] += ep_rew;
+                    if (alive1) a.s.alive_end[idx] += 1u;
+                }
+                ep_rew = 0.0;
+                dirty = true;
+            }
+        }
+        const bool do_reset = done && a.auto_reset != 0;
+        dirty = dirty || alive0;
+        alive = alive1;
+        nh += hit_cnt;
+        nwh += was_hit_cnt;
+        if (primary) {
+            const size_t o = (size_t)s * EN + idx;
+            const float mk = (alive0 || do_reset) ? 1.0f : 0.0f;
+            if (COLLECT) {
+                a.rew32[o] = (float)rew;
+                a.mask32[o] = mk;
+            } else {
+                if (a.rew32) a.rew32[o] = (float)rew;
+                if (a.rew64) a.rew64[o] = rew;
+                if (a.mask32) a.mask32[o] = mk;
+                if (a.hit) a.hit[o] = hit ? 1 : 0;
+                if (a.was_hit) a.was_hit[o] = was_hit ? 1 : 0;
+            }
+        }
+
+        // ---- fortattack_env_v1.py:47-75 reset_world (every lane of an agent draws the same words and stores the same
+        // twisted words: one wave, lock step) --------------------------------------------
+        if (__ballot(do_reset) != 0ull) {
+            double npx = px, npy = py;
+            reset_agent(a, e, i, N, is_att, do_reset, mt_base, npx, npy);
+            if (do_reset) {
+                px = npx; py = npy; vx = 0.0; vy = 0.0;
+                ang = is_att ? c.ang_attacker : c.ang_guard;
+                alive = true;
+                t = 0;
+                nh = 0; nwh = 0;
+                ep_rew = 0.0;
+                dirty = true;
+                if (l == 0) reset_advance(a, e, mt_base);
+            }
+            if constexpr (CHOICE) {
+                int extra = 0;
+                if (do_reset && l == 0) {
+                    const uint32_t rng = (uint32_t)(a.choice_k - 1);
+                    uint32_t mask = rng, v = 0;
+                    mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+                    if (rng != 0u) {
+                        if (a.rng_mode == 0) {
+                            uint32_t *mt = a.s.mt + (size_t)e * FA_MT_N;
+                            int cur = mt_base;
+                            do {
+                                const uint32_t nw = mt_twist(mt[cur], mt[mt_wrap(cur + 1)], mt[mt_wrap(cur + FA_MT_M)]);
+                                mt[cur] = nw;
+                                v = mt_temper(nw) & mask;
+                                cur = mt_wrap(cur + 1);
+                                ++extra;
+                            } while (v > rng);
+                            a.s.mt_pos[e] = cur;
+                        } else {
+                            const uint64_t genv = (uint64_t)(a.env_offset + e);
+                            uint32_t ctr = 0;
+                            do {
+                                uint32_t cc[4] = {(uint32_t)genv, (uint32_t)(genv >> 32), a.s.reset_count[e], 255u | (ctr << 8)};
+                                philox4x32_10(cc, (uint32_t)a.seed, (uint32_t)(a.seed >> 32));
+                                v = cc[0] & mask;
+                                ++ctr;
+                            } while (v > rng);
+                        }
+                    }
+                    a.choice_out[e] = (int)v;
+                }
+                if (a.rng_mode == 0) {
+                    extra = __shfl(extra, gbase);
+                    if (do_reset) mt_base = (mt_base - 4 * i + extra) % FA_MT_N + 4 * i;
+                }
+            }
+        }
+
+        // ---- observation row (fortattack_env_v1.py:238) ------------------------------------
+        if (primary) {
+            const size_t o6 = ((size_t)s * EN + idx) * 6;
+            fa_store_obs((COLLECT || a.obs32) ? a.obs32 + o6 : nullptr, (!COLLECT && a.obs64) ? a.obs64 + o6 : nullptr,
+                         alive, px, py, ang, vx, vy);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+
+    if (dirty && primary) {
+        a.s.px[idx] = px; a.s.py[idx] = py; a.s.vx[idx] = vx; a.s.vy[idx] = vy;
+        a.s.ang[idx] = ang; a.s.prev[idx] = prev;
+        a.s.alive[idx] = alive ? 1 : 0;
+        if (a.track_counters) { a.s.num_hit[idx] = nh; a.s.num_was_hit[idx] = nwh; a.s.ep_rew[idx] = ep_rew; }
+    }
+    if (l == 0) a.s.tstep[e] = t;
+}
+
 // ---- the pipelined multi-wave step (latency regime, compile-time team sizes) ------------------
 // Same arithmetic as fa_step_kernel, cut differently.  At E = 4096 there are fewer waves than
 // SIMDs and a rollout is one long dependent chain per wave, so the workgroup spends idle SIMDs
@@ -1493,6 +1770,7 @@ static int step_variant(int G, int A, int E, int nsteps, bool reset_only, int fo
     case 3: return 1;
     case 4: return 2;
     case 5: return 3;
+    case 6: if (G == 3 && A == 3) return 6; break;         // FA_KERNEL_PAIRS (experiment): lane = (agent, partner)
     default: break;
     }
     if (!choice && nsteps >= FA_PIPE_MIN_STEPS && grid <= FA_PIPE_MAX_GRID) return grid <= 2 * 256 ? 0 : -3;
@@ -1500,6 +1778,7 @@ static int step_variant(int G, int A, int E, int nsteps, bool reset_only, int fo
 }
 const char *fa_step_variant_name(int G, int A, int E, int nsteps, int forced, bool choice) {
     switch (step_variant(G, A, E, nsteps, false, forced, choice)) {
+    case 6: return "fa_step_pair_kernel";
     case 0: return "fa_step_pipe_kernel";
     case -3: return "fa_step_pipe_kernel/3 per CU";
     case 3: return "fa_step_kernel/3 waves";
@@ -1529,7 +1808,13 @@ static hipError_t launch_step_t(const FaStepArgs &a, hipStream_t st) {
     } while (0)
 #define FA_LAUNCH_PIPE(TG_, TA_, NPW_, MINW_) \
     hipLaunchKernelGGL((fa_step_pipe_kernel<TG_, TA_, COLLECT, NPW_, MINW_>), dim3(grid), dim3((NPW_ + 2) * FA_WAVE), 0, st, a)
-    if (a.G == 3 && a.A == 3) {
+    if (nw == 6) {
+        if constexpr (!RESET_ONLY) {
+            const int g2 = (a.E + 1) / 2; // two envs per wave
+            if (a.choice_k > 0) hipLaunchKernelGGL((fa_step_pair_kernel<3, 3, COLLECT, true>), dim3(g2), dim3(FA_WAVE), 0, st, a);
+            else hipLaunchKernelGGL((fa_step_pair_kernel<3, 3, COLLECT, false>), dim3(g2), dim3(FA_WAVE), 0, st, a);
+        }
+    } else if (a.G == 3 && a.A == 3) {
         // up to two workgroups per CU the build may use 256 VGPRs; three per CU need <= 168
         if (nw == 0) FA_LAUNCH_PIPE(3, 3, 2, 2);
         else if (nw == -3) FA_LAUNCH_PIPE(3, 3, 2, 3);

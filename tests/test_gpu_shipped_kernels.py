@@ -92,20 +92,23 @@ def test_collect_rollout_full_size_vs_oracle(fa, G, A, E, T, variant):
 @pytest.mark.parametrize("G,A", [(3, 3), (5, 5)])
 @pytest.mark.parametrize("kernel,name", [("pipe", "fa_step_pipe_kernel"), ("pipe3", "fa_step_pipe_kernel/3 per CU"),
                                          ("waves1", "fa_step_kernel/1 wave"), ("waves2", "fa_step_kernel/2 waves"),
-                                         ("waves3", "fa_step_kernel/3 waves")])
+                                         ("waves3", "fa_step_kernel/3 waves"), ("pairs", "fa_step_pair_kernel")])
 @pytest.mark.parametrize("collect", [False, True])
 def test_every_step_kernel_build_vs_oracle(fa, G, A, kernel, name, collect):
-    """fa_config.step_kernel pins the build; T steps in one launch (and, for fa_step_kernel, also as T
-    single-step launches) against the oracle."""
+    """fa_config.step_kernel pins the build; T steps in one launch (and, for fa_step_kernel and the pair-per-lane
+    experiment kernel, also as T single-step launches) against the oracle."""
     from fa_oracle import OracleEnv
+    if kernel == "pairs" and (G, A) != (3, 3):
+        pytest.skip("the pair-per-lane kernel exists for 3v3 only")
     E, T, max_t = 77, 40, 9
     N = G + A
     rng = np.random.RandomState(17 * G + len(kernel))
     acts = _shooty_actions(rng, (T, E, N), 0.25)
-    for per_step in ((False, True) if kernel.startswith("waves") else (False,)):
+    single = kernel.startswith("waves") or kernel == "pairs"
+    for per_step in ((False, True) if single else (False,)):
         orc = OracleEnv(E, G, A, max_t, base_seed=606)
         eng = fa.BatchedFortAttack(E, G, A, max_t, base_seed=606, step_kernel=kernel)
-        assert eng.step_variant(T) == name and (not kernel.startswith("waves") or eng.step_variant(1) == name)
+        assert eng.step_variant(T) == name and (not single or eng.step_variant(1) == name)
         if collect:
             st = fa.JointRolloutStorage(T, E, N, device="cuda")
             eng.bind_storage(st)
@@ -147,7 +150,7 @@ def test_every_step_kernel_build_vs_oracle(fa, G, A, kernel, name, collect):
         assert np.array_equal(eng.rng_peek(E - 1, 2 * N), orc.rng_doubles(E - 1, 2 * N))
 
 
-@pytest.mark.parametrize("kernel", ["pipe", "pipe3", "waves1", "waves2", "waves3"])
+@pytest.mark.parametrize("kernel", ["pipe", "pipe3", "waves1", "waves2", "waves3", "pairs"])
 @pytest.mark.parametrize("partner_shot", [True, False])
 def test_exactly_coincident_agents(fa, kernel, partner_shot):
     """Two agents at the same point: the reference's pair force is 0/0 = NaN for both (core.py:447-455).
