@@ -7,8 +7,8 @@
 //   record B, one per tile:           dW8 (128 x 256) = h3^T [dP | dV] ;  dB_o (64 x 64) = mix_o^T de_opp ;
 //                                     dA_o (64 x 64) = h1^T dg_o
 // Here 256 workgroups (one per CU, eight waves) each walk a contiguous range of records: a record (64 / 80 KB) is
-// staged through registers into ONE LDS buffer while the previous record's MFMAs run (global -> registers at the top
-// of a stage, registers -> LDS behind the barrier at its end), every wave keeps 6 (A) / 5 (B) 32 x 32 accumulator tiles
+// staged through registers into one of TWO LDS images while the previous record's MFMAs run out of the other (global ->
+// registers at the top of a stage, registers -> LDS between its last MFMAs), every wave keeps 6 (A) / 5 (B) 32 x 32 accumulator tiles
 // for the whole range -- 48 / 40 tiles per workgroup -- and both operands of an MFMA are 4-byte LDS reads of one row
 // segment (A[i][kk] = X[row kk][i], B[kk][j] = dY[row kk][j]: bank-conflict free, 7-8 reads per 6 MFMAs).
 // A workgroup ends with ONE partial slab (192 / 160 KB): 47 MB per minibatch where rounds 2-3 wrote (and re-read)
@@ -65,41 +65,46 @@ __device__ __forceinline__ void dw_range(const float *__restrict__ rec, int q0, 
     const int r0 = hh * (FA_TR_ROWS / 2); // lane half hh walks rows 16 hh .. 16 hh + 15
     xa += r0 * rsx_a + li; xb += r0 * rsx_b + li; ya += r0 * rsy_a + li; yb += r0 * rsy_b + li;
 
-    // (the staging registers are loaded and written unconditionally -- the last stage re-reads its own record -- so that
-    //  they stay registers: behind a condition the compiler kept the array in scratch memory and waited for every load)
+    // Two LDS images of a record: while record q is multiplied out of one, record q + 1 travels global -> registers (requested
+    // at the top of the stage, pinned there: the scheduler otherwise sinks the loads to their use and the whole HBM round
+    // trip is exposed once per stage) -> the OTHER image, written between the MFMAs of the stage's last k-steps; one
+    // barrier per record.  (The staging registers are loaded and written unconditionally -- the last stage re-reads its own
+    // record -- so that they stay registers: behind a condition the compiler kept the array in scratch memory.)
+    constexpr int WRITE_AT = FA_TR_ROWS / 2 - 4; // k-step at which the next record's registers go to LDS
     f32x4 stage[NS];
     const f32x4 *src = reinterpret_cast<const f32x4 *>(rec + (size_t)q0 * RF);
-    f32x4 *lds4 = reinterpret_cast<f32x4 *>(sT);
     if (q0 < q1) {
 #pragma unroll
         for (int j = 0; j < NS; ++j) stage[j] = src[tid + j * DW_NT];
 #pragma unroll
-        for (int j = 0; j < NS; ++j) lds4[tid + j * DW_NT] = stage[j];
+        for (int j = 0; j < NS; ++j) reinterpret_cast<f32x4 *>(sT)[tid + j * DW_NT] = stage[j];
     }
     __syncthreads();
     for (int q = q0; q < q1; ++q) {
+        const int cur = ((q - q0) & 1) * FA_RECB_FLOATS, nxt = FA_RECB_FLOATS - cur; // float offsets of the two images
         src = reinterpret_cast<const f32x4 *>(rec + (size_t)(q + 1 < q1 ? q + 1 : q) * RF);
 #pragma unroll
         for (int j = 0; j < NS; ++j) stage[j] = src[tid + j * DW_NT];
-        // keep the requests HERE, ahead of the stage's MFMAs (the scheduler otherwise sinks them to their use behind the
-        // loop, and the whole HBM round trip of a record is exposed once per stage)
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int t = 0; t < FA_TR_ROWS / 2; ++t) {
-            const float a0 = xa[t * rsx_a], a1 = xb[t * rsx_b];
+            const float a0 = xa[cur + t * rsx_a], a1 = xb[cur + t * rsx_b];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, ya[t * rsy_a + c * 32], acc[c], 0, 0, 0);
+            for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, ya[cur + t * rsy_a + c * 32], acc[c], 0, 0, 0);
             if (JOB == 0) {
-                acc[4] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, yb[t * rsy_b], acc[4], 0, 0, 0);
-                acc[5] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, yb[t * rsy_b + 32], acc[5], 0, 0, 0);
+                acc[4] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, yb[cur + t * rsy_b], acc[4], 0, 0, 0);
+                acc[5] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, yb[cur + t * rsy_b + 32], acc[5], 0, 0, 0);
             } else {
-                acc[4] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, yb[t * rsy_b], acc[4], 0, 0, 0);
+                acc[4] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, yb[cur + t * rsy_b], acc[4], 0, 0, 0);
+            }
+            if (t == WRITE_AT) {
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < NS; ++j) reinterpret_cast<f32x4 *>(sT + nxt)[tid + j * DW_NT] = stage[j];
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
-        __syncthreads(); // every wave has read the record
-#pragma unroll
-        for (int j = 0; j < NS; ++j) lds4[tid + j * DW_NT] = stage[j];
-        __syncthreads();
+        __syncthreads(); // the next image is complete, and every wave has read this one
     }
     if (JOB == 0) {
 #pragma unroll
@@ -115,7 +120,7 @@ __device__ __forceinline__ void dw_range(const float *__restrict__ rec, int q0, 
 
 __global__ __launch_bounds__(DW_NT) void fa_train_dw_kernel(const float *__restrict__ rec_a, const float *__restrict__ rec_b, int tiles,
                                                             float *__restrict__ dw_slabs) {
-    __shared__ __attribute__((aligned(16))) float sT[FA_RECB_FLOATS]; // 80 KB: one record
+    __shared__ __attribute__((aligned(16))) float sT[2 * FA_RECB_FLOATS]; // 2 x 80 KB: two records (all of a CU's LDS)
     const int b = blockIdx.x;
     if (b < FA_DW_WGS_A) {
         const int cnt = tiles * 3, per = (cnt + FA_DW_WGS_A - 1) / FA_DW_WGS_A;
