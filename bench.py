@@ -730,17 +730,21 @@ def closed_loop_rooflines(fa, L, E, G, A, T):
         scratch = [None]
 
         def grad():
-            _, scratch[0] = ppo_grad(*rows, w, wt, None, 0, G, A, L.clip_param, L.value_loss_coef, L.entropy_coef,
-                                     L.clipped_value_loss, scratch=scratch[0], out=outbuf, idx=idx, normalize=True)
+            # (as the update's graphs call it: advantages normalised inside the kernel from the rollout's mean / std)
+            _, scratch[0] = ppo_grad(*rows[:5], None, w, wt, None, 0, G, A, L.clip_param, L.value_loss_coef, L.entropy_coef,
+                                     L.clipped_value_loss, scratch=scratch[0], out=outbuf, idx=idx, normalize=True,
+                                     adv_stats=(L._adv_mean, L._adv_std))
 
         sec = timed(grad, 20)
         flops = mb * G * train_flops_per_row(G, A)
-        out["train"] = {"bound": "mfma", "kernel": "fa_ppo_grad = fa_mask_part_kernel + fa_train_kernel<true> + fa_train_reduce_kernel",
+        out["train"] = {"bound": "mfma", "kernel": "fa_ppo_grad = fa_mask_part_kernel + fa_train_kernel<true, %d> (32-row tiles, two workgroups per CU) + "
+                                                   "fa_train_dw_kernel (weight gradients: split-K MFMA GEMM over all rows) + fa_train_mred_kernel + "
+                                                   "fa_train_reduce_kernel" % (4 if max(G, A) <= 4 else (6 if max(G, A) <= 6 else 8)),
                         "achieved": flops / sec / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": flops / sec / 1e12 / MFMA_F32_PEAK_TFLOPS, "traffic": None, "flops_per_launch": flops,
                         "avg_launch_us": sec * 1e6, "minibatch_rows": mb * G,
-                        "timed_by": "hipEvents on the launch stream, 20 eager fa_ppo_grad calls (three launches each; the "
-                                    "train kernel alone is in profiles/ rocprofv3 stats)"}
+                        "timed_by": "hipEvents on the launch stream, 20 eager fa_ppo_grad calls (five launches each; the "
+                                    "kernels one by one are in profiles/ rocprofv3 stats)"}
     else:
         out["train"] = None
     return out

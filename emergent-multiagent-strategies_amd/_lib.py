@@ -52,7 +52,8 @@ class PPOGradIO(C.Structure):
                 ("idx", c_p), ("weights", c_p), ("weights_t", c_p), ("scale", c_p), ("slabs", c_p), ("hsave", c_p), ("out", c_p),
                 ("B", C.c_int32), ("num_guards", C.c_int32), ("num_attackers", C.c_int32), ("team", C.c_int32),
                 ("clip_param", C.c_float), ("value_loss_coef", C.c_float), ("entropy_coef", C.c_float),
-                ("clipped_value_loss", C.c_int32), ("normalize", C.c_int32), ("share_cu", C.c_int32)]
+                ("clipped_value_loss", C.c_int32), ("normalize", C.c_int32), ("share_cu", C.c_int32),
+                ("adv_mean", c_p), ("adv_std", c_p)]
 
 
 class Task(C.Structure):

@@ -613,9 +613,11 @@ int fa_ppo_grad_scratch(int32_t B, int32_t G, int32_t A, int64_t *slab_floats, i
 
 int fa_ppo_grad(const fa_ppo_grad_io *io, void *stream) {
     if (!io) return fail(FA_ERR_INVALID, "fa_ppo_grad: null io");
-    if (!io->obs || !io->action || !io->value_pred || !io->ret || !io->old_log_prob || !io->adv || !io->weights ||
+    if (!io->obs || !io->action || !io->value_pred || !io->ret || !io->old_log_prob || !io->weights ||
         !io->weights_t || !io->slabs || !io->hsave || !io->out)
-        return fail(FA_ERR_INVALID, "fa_ppo_grad: every pointer but idx and scale is required");
+        return fail(FA_ERR_INVALID, "fa_ppo_grad: every pointer but idx, scale and adv / adv_mean / adv_std is required");
+    if ((io->adv_mean == nullptr) != (io->adv_std == nullptr) || (!io->adv && !io->adv_mean))
+        return fail(FA_ERR_INVALID, "fa_ppo_grad: pass adv, or adv_mean and adv_std together");
     if (io->B < 1 || io->num_guards < 1 || io->num_attackers < 1 || io->num_guards > FA_POLICY_MAX_TEAM ||
         io->num_attackers > FA_POLICY_MAX_TEAM || (io->team != 0 && io->team != 1))
         return fail(FA_ERR_INVALID, "fa_ppo_grad: need B >= 1, teams of 1..8, team 0 or 1");
@@ -623,6 +625,7 @@ int fa_ppo_grad(const fa_ppo_grad_io *io, void *stream) {
     std::memset(&a, 0, sizeof(a));
     a.obs = io->obs; a.action = io->action; a.value_pred = io->value_pred; a.ret = io->ret;
     a.old_logp = io->old_log_prob; a.adv = io->adv; a.w = io->weights; a.wt = io->weights_t;
+    a.adv_mean = io->adv_mean; a.adv_std = io->adv_std;
     a.scale = io->scale; a.idx = io->idx;
     a.B = io->B; a.G = io->num_guards; a.A = io->num_attackers; a.team = io->team;
     a.clip = io->clip_param; a.c_value = io->value_loss_coef; a.c_entropy = io->entropy_coef;

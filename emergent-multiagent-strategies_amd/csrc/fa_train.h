@@ -71,7 +71,8 @@ struct FaTrainArgs {
     const float *value_pred;   // (B, N) value_preds of the rollout
     const float *ret;          // (B, N) returns
     const float *old_logp;     // (B, N) action_log_probs of the rollout
-    const float *adv;          // (B, N) normalised advantages
+    const float *adv;          // (B, N) normalised advantages, or null with adv_mean / adv_std
+    const double *adv_mean, *adv_std; // per agent (N): the kernel normalises ret - value_pred itself (ppo.py:121-124)
     const int64_t *idx;        // the minibatch: sample b is row idx[b] of the six arrays above (null: row b)
     const float *w;            // forward pack (FA_POFF_*)
     const float *wt;           // transposed pack (FA_TOFF_*)

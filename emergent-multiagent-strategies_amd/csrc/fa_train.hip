@@ -266,7 +266,9 @@ __device__ __forceinline__ void fa_train_body(const FaTrainArgs &a) {
     if (wave == 0 && lane < ne * n) {
         const int el = lane / n, i = lane - el * n;
         const size_t o = (size_t)(GATHER ? a.idx[e0 + el] : (int64_t)(e0 + el)) * N + own0 + i;
-        l_act = (int)a.action[o]; l_vp = a.value_pred[o]; l_rt = a.ret[o]; l_adv = a.adv[o]; l_olp = a.old_logp[o];
+        l_act = (int)a.action[o]; l_vp = a.value_pred[o]; l_rt = a.ret[o]; l_olp = a.old_logp[o];
+        // (the arithmetic of fa_adv_norm_kernel: float32 with float32 mean / std)
+        l_adv = a.adv_mean ? ((l_rt - l_vp) - (float)a.adv_mean[own0 + i]) / ((float)a.adv_std[own0 + i] + 1e-5f) : a.adv[o];
     }
     FA_TR_TICK(0)
     // ================================ forward ==========================================================

@@ -526,18 +526,22 @@ def make_fortattack_env(num_steps, benchmark=False, num_guards=5, num_attackers=
 
 
 def ppo_grad(obs, action, value_pred, ret, old_logp, adv, w, wt, scale, team, G, A, clip, c_value, c_entropy,
-             clipped_value_loss=True, scratch=None, out=None, idx=None, normalize=True, share_cu=False):
+             clipped_value_loss=True, scratch=None, out=None, idx=None, normalize=True, share_cu=False, adv_stats=None):
     """fa_ppo_grad: one team's PPO minibatch forward + losses + backward in one fused launch (+ reduction).
     obs (rows, N, 6) float32; action (rows, N[, 1]) int64; value_pred / ret / old_logp / adv (rows, N[, 1]) float32;
     idx: int64 row indices of the minibatch (None: every row); w / wt the packed weights and their transposes
     (mpnn_pack.FlatPolicy.fold_pack / pack_from_params); scale: device float32[2], or None -> the library takes the
-    alive-mask mean itself and (normalize) divides by it.  Returns (out, scratch): out = FA_SLAB floats (plain-layout
-    gradients + loss sums), scratch reusable."""
+    alive-mask mean itself and (normalize) divides by it.  adv_stats = (mean, std) float64 (N,) device tensors: the kernel
+    normalises ret - value_pred itself (ppo.py:121-124) and `adv` may be None.  Returns (out, scratch): out = FA_SLAB floats
+    (plain-layout gradients + loss sums), scratch reusable."""
     lib = _lib.load()
     N = obs.shape[1]
     B = obs.shape[0] if idx is None else idx.numel()
-    for t in (obs, value_pred, ret, old_logp, adv, w, wt) + (() if scale is None else (scale,)):
+    for t in (obs, value_pred, ret, old_logp, w, wt) + (() if scale is None else (scale,)) + (() if adv is None else (adv,)):
         assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
+    assert adv is not None or adv_stats is not None
+    if adv_stats is not None:
+        assert all(t.is_cuda and t.dtype == torch.float64 and t.is_contiguous() and t.numel() == N for t in adv_stats)
     assert action.dtype == torch.int64 and action.is_contiguous() and N == G + A
     assert idx is None or (idx.is_cuda and idx.dtype == torch.int64 and idx.is_contiguous())
     if scratch is None:
@@ -547,7 +551,9 @@ def ppo_grad(obs, action, value_pred, ret, old_logp, adv, w, wt, scale, team, G,
     if out is None:
         out = torch.empty(lib.fa_ppo_grad_floats(), device=obs.device)
     io = _lib.PPOGradIO()
-    io.obs, io.action, io.value_pred, io.ret, io.old_log_prob, io.adv = [_ptr(t) for t in (obs, action, value_pred, ret, old_logp, adv)]
+    io.obs, io.action, io.value_pred, io.ret, io.old_log_prob = [_ptr(t) for t in (obs, action, value_pred, ret, old_logp)]
+    io.adv = None if adv is None else _ptr(adv)
+    io.adv_mean, io.adv_std = (None, None) if adv_stats is None else (_ptr(adv_stats[0]), _ptr(adv_stats[1]))
     io.weights, io.weights_t, io.slabs, io.hsave, io.out = [_ptr(t) for t in (w, wt, scratch[0], scratch[1], out)]
     io.scale = None if scale is None else _ptr(scale)
     io.idx = None if idx is None else _ptr(idx)

@@ -81,7 +81,9 @@ class GraphedPPOStep(object):
     restored) before the first real step."""
 
     def __init__(self, pol, opt, own_sl, opp_sl, rows, mb, clip_param, value_loss_coef, entropy_coef, max_grad_norm,
-                 clipped_value_loss, group, fused=False, share_cu=False, exchange=None):
+                 clipped_value_loss, group, fused=False, share_cu=False, exchange=None, adv_stats=None):
+        # adv_stats (fused only): persistent (mean, std) float64 (N,) device tensors -> the kernel normalises the advantages
+        # itself from returns - value_preds (ppo.py:121-124) and rows[5] is never read
         # the gradient exchange: `exchange` (dist.LibraryExchange: RCCL inside the library) or torch.distributed on
         # `group`; a world of one rank exchanges nothing unless dist.FORCE_COLLECTIVE / an explicit exchange says so
         self.pol, self.opt, self.group = pol, opt, group
@@ -117,9 +119,9 @@ class GraphedPPOStep(object):
             autograd, GEMM or gather; left to torch are four scalar ops on the loss sums"""
             fp = self.fp
             w, wt = fp.fold_pack()
-            _, self._scratch = ppo_grad(*self.rows, w, wt, None, team, G, N - G, clip_param, value_loss_coef, entropy_coef,
-                                        clipped_value_loss, scratch=self._scratch, out=self._out, idx=self.idx,
-                                        normalize=not exchanging, share_cu=share_cu)
+            _, self._scratch = ppo_grad(*self.rows[:5], None if adv_stats is not None else self.rows[5], w, wt, None, team, G, N - G,
+                                        clip_param, value_loss_coef, entropy_coef, clipped_value_loss, scratch=self._scratch,
+                                        out=self._out, idx=self.idx, normalize=not exchanging, share_cu=share_cu, adv_stats=adv_stats)
             fp.attach_grads()               # every parameter's .grad is its slice of fp.gflat
             fp.unfold(self._out)
             sums = self._out[LOSS:LOSS + 3] * inv_count
@@ -233,7 +235,7 @@ class GraphedPPOStep(object):
 
 def joint_ppo_update(pol, opt, own_sl, opp_sl, rows, clip_param, ppo_epoch, num_mini_batch, value_loss_coef,
                      entropy_coef, max_grad_norm, clipped_value_loss=True, group=None, sampler=None, graphs=None,
-                     exchange=None):
+                     exchange=None, adv_stats=None):
     """JointPPO.update (ppo.py:116-204) for one team's shared policy over flattened rollout rows.
 
     rows = (obs, actions, value_preds, returns, old_log_probs, advantages), each (B, N, .) with B = T * E
@@ -275,7 +277,7 @@ def joint_ppo_update(pol, opt, own_sl, opp_sl, rows, clip_param, ppo_epoch, num_
                     graphs[key] = GraphedPPOStep(pol, opt, own_sl, opp_sl, rows, mb, clip_param, value_loss_coef,
                                                  entropy_coef, max_grad_norm, clipped_value_loss, group,
                                                  fused=graphs.get("fused", False) and mpnn_pack.supported(pol),
-                                                 exchange=exchange)
+                                                 exchange=exchange, adv_stats=adv_stats)
                 acc += graphs[key].run(rows, idx)
                 continue
             obs_b = obs_f[idx]
@@ -360,6 +362,9 @@ class BatchedLearner(object):
         eng.bind_storage(self.storage)
         self.team_slices = [slice(0, self.G), slice(self.G, self.N)]
         self.adv = torch.empty((num_steps, self.E, self.N, 1), device=self.device)
+        # the advantage mean / std of the last collect() in buffers that captured update graphs may point at
+        self._adv_mean = torch.zeros(self.N, dtype=torch.float64, device=self.device)
+        self._adv_std = torch.ones(self.N, dtype=torch.float64, device=self.device)
         self.use_graph = use_graph
         self._graphs = None
         self.episode_rewards = torch.zeros((self.E, self.N), device=self.device)
@@ -626,6 +631,8 @@ class BatchedLearner(object):
             self._value_last()
         # compute_returns + the advantage mean / std of ppo.py:121-123 (over ALL ranks) in one pass
         self._adv_mean_std = gae_adv_mean_std(self.eng, self.gamma, self.tau, self.group, exchange=self._exch)
+        self._adv_mean.copy_(self._adv_mean_std[0])
+        self._adv_std.copy_(self._adv_mean_std[1])
         # train_fortattack.py:88: episode_rewards += reward * masks (alive before the step)
         self.episode_rewards = (st.rewards * st.masks[1:]).sum(0)[..., 0]
 
@@ -634,20 +641,30 @@ class BatchedLearner(object):
         """-> float tensor (n_trained_teams, 3) = mean (value_loss, action_loss, entropy)."""
         st, T, E = self.storage, self.T, self.E
         mean, std = self._adv_mean_std                           # ppo.py:121-123, from collect()
-        self.eng.adv_normalize(mean, std, out=self.adv)          # ppo.py:123
+        # The fused optimizer steps normalise the advantages inside the kernel from (mean, std): the (T, E, N) advantage
+        # tensor is only materialised for the paths that read it (PyTorch autograd, a caller's sampler, a ragged last
+        # minibatch that runs eagerly)
+        batch = T * E
+        mb = int(batch / self.num_mini_batch) if batch >= self.num_mini_batch else 0
+        g = self._update_graphs
+        in_kernel = (g is not None and g.get("fused", False) and sampler is None and mb > 0 and batch % mb == 0
+                     and all(mpnn_pack.supported(p) for p in self.policies))
+        adv_stats = (self._adv_mean, self._adv_std) if in_kernel else None
+        if not in_kernel:
+            self.eng.adv_normalize(mean, std, out=self.adv)      # ppo.py:123
         flat = lambda t: t.view(T * E, *t.shape[2:])
         rows = (flat(st.obs[:-1]), flat(st.actions), flat(st.value_preds[:-1]), flat(st.returns[:-1]),
                 flat(st.action_log_probs), flat(self.adv))
         out = []
         teams = [0] if train_guards_only else [0, 1]             # learner.py:177
         if len(teams) == 2 and sampler is None and self._teams_step_ok(rows):
-            return self._update_teams_together(rows)
+            return self._update_teams_together(rows, adv_stats)
         for ti in teams:
             out.append(joint_ppo_update(
                 self.policies[ti], self.optimizers[ti], self.team_slices[ti], self.team_slices[1 - ti], rows,
                 self.clip_param, self.ppo_epoch, self.num_mini_batch, self.value_loss_coef, self.entropy_coef,
                 self.max_grad_norm, self.clipped_value_loss, self._team_groups[ti], sampler,
-                graphs=None if sampler is not None else self._update_graphs, exchange=self._team_exch[ti]))
+                graphs=None if sampler is not None else self._update_graphs, exchange=self._team_exch[ti], adv_stats=adv_stats))
         return torch.stack(out)
 
     def _teams_step_ok(self, rows):
@@ -657,7 +674,7 @@ class BatchedLearner(object):
         return (g is not None and g.get("fused", False) and g.get("teams_together", True)
                 and mb > 0 and batch % mb == 0 and all(mpnn_pack.supported(p) for p in self.policies))
 
-    def _update_teams_together(self, rows):
+    def _update_teams_together(self, rows, adv_stats=None):
         """Both teams' JointPPO.update (learner.py:175-188 runs them one after the other; they share nothing but the
         read-only rollout) as two concurrent chains of optimizer steps.  The minibatch permutations are drawn in the
         sequential order -- all of the guards' epochs, then all of the attackers' -- so the result is the
@@ -673,7 +690,7 @@ class BatchedLearner(object):
                 g[key] = GraphedPPOStep(self.policies[ti], self.optimizers[ti], self.team_slices[ti], self.team_slices[1 - ti],
                                         rows, mb, self.clip_param, self.value_loss_coef, self.entropy_coef, self.max_grad_norm,
                                         self.clipped_value_loss, self._team_groups[ti], fused=True, share_cu=g.get("share_cu", True),
-                                        exchange=self._team_exch[ti])
+                                        exchange=self._team_exch[ti], adv_stats=adv_stats)
             steps.append(g[key])
             assert all(a.data_ptr() == b.data_ptr() for a, b in zip(rows, g[key].rows)), "the captured step reads the rollout in place"
         acc = torch.zeros(2, 3, device=dev)

@@ -322,6 +322,11 @@ typedef struct fa_ppo_grad_io {
     int32_t normalize;         /* with scale == NULL: 1 = divide by the alive-mask mean here, 0 = the caller will */
     int32_t share_cu;          /* accepted and ignored (rounds 2-3: a register-capped build of the tile kernel that left
                                   room on its CUs for another stream's launches; the round-4 kernel does better uncapped) */
+    /* Advantage normalisation inside the kernel (rlcore/algo/ppo.py:121-124): when adv_mean / adv_std are given
+     * (device, one double per agent: what fa_gae_moments / fa_adv_mean_std / fa_adv_allreduce leave), `adv` may be NULL
+     * and a row's advantage is (ret - value_pred - (float)mean[agent]) / ((float)std[agent] + 1e-5f) -- bit for bit
+     * what fa_adv_normalize would have written -- so a trainer never materialises the (T, E, N) advantage tensor. */
+    const double *adv_mean, *adv_std;
 } fa_ppo_grad_io;
 int fa_ppo_grad(const fa_ppo_grad_io *io, void *stream);
 int64_t fa_ppo_grad_floats(void);

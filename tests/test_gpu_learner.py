@@ -90,7 +90,8 @@ def test_closed_loop_rollout_and_update(fa, use_graph, hidden, backend, tmp_path
         losses = L.update()
         assert losses.shape == (2, 3) and bool(torch.isfinite(losses).all())
         assert any(not torch.equal(b, p) for b, p in zip(before, L.policies[0].parameters()))
-        adv = L.adv.cpu().numpy()
+        # (the fused update normalises the advantages inside the kernel and never writes L.adv: fa_adv_normalize on demand)
+        adv = L.eng.adv_normalize(*L._adv_mean_std).cpu().numpy()
         for i in range(N):
             assert np.abs(adv[:, :, i] - co.normalized_advantages(rets[:, :, i], vals[:, :, i])).max() < 2e-5
         last_obs, last_mask = L.storage.obs[T].clone(), L.storage.masks[T].clone()

@@ -280,6 +280,33 @@ def test_fused_ppo_grad_matches_torch_autograd(fa, G, A, team, B, clipped):
     assert max(worst.values()) < 2e-3, worst
 
 
+def test_fused_ppo_grad_normalises_the_advantages_itself(fa):
+    """fa_ppo_grad with (adv_mean, adv_std) instead of an advantage tensor (ppo.py:121-124 inside the kernel): bit for bit
+    the result of passing what fa_adv_normalize writes -- (A - (float)mean) / ((float)std + 1e-5f) in float32."""
+    from emergent_multiagent_strategies_amd import mpnn_pack as mp_
+    from emergent_multiagent_strategies_amd.env import ppo_grad
+    G, A, B = 3, 3, 700
+    N = G + A
+    pols, _ = _policies(fa, G, A, 5)
+    g = torch.Generator(device="cuda").manual_seed(1)
+    obs = _obs(B, N, 3)
+    rnd = lambda *s: torch.randn(*s, device="cuda", generator=g)
+    action = torch.randint(0, 8, (B, N, 1), device="cuda", generator=g)
+    value_pred, ret = rnd(B, N, 1), rnd(B, N, 1) * 3 + 1
+    old_logp = -torch.rand((B, N, 1), device="cuda", generator=g) * 2.5
+    mean = (torch.rand(N, device="cuda", generator=g).double() - 0.5) * 2
+    std = torch.rand(N, device="cuda", generator=g).double() * 3 + 0.1
+    adv = ((ret - value_pred) - mean.float().view(1, N, 1)) / (std.float().view(1, N, 1) + 1e-5)
+    P = mp_.kernel_params(pols[1])
+    w, wt = torch.zeros(mp_.WEIGHT_FLOATS, device="cuda"), torch.zeros(mp_.TRANS_FLOATS, device="cuda")
+    mp_.pack_from_params(P, w, wt)
+    a, _ = ppo_grad(obs, action, value_pred, ret, old_logp, adv.contiguous(), w, wt, None, 1, G, A, 0.2, 0.5, 0.01, True)
+    b, _ = ppo_grad(obs, action, value_pred, ret, old_logp, None, w, wt, None, 1, G, A, 0.2, 0.5, 0.01, True, adv_stats=(mean, std))
+    torch.cuda.synchronize()
+    used = mp_.WEIGHT_FLOATS + 4                       # gradients + the four loss sums (the buffer's tail is scratch)
+    assert torch.equal(a[:used], b[:used]) and float(a[:used].abs().sum()) > 0
+
+
 @pytest.mark.parametrize("G,A", [(3, 3), (5, 2)])
 def test_flat_policy_fold_and_unfold_match_torch(fa, G, A):
     """mpnn_pack.FlatPolicy: parameters as one flat buffer; fold_pack (task-list kernel + pack kernel) == the torch
