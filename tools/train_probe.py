@@ -40,7 +40,7 @@ for r in range(3):
 for k in range(3):
     b = 30 + 8 * k
     names.update({b: "  bwd round %d: request h_in, bias sums, save dZ" % (2 - k), b + 1: "  bwd round %d: dZ W7^T (2 gemm128)" % (2 - k),
-                  b + 2: "  bwd round %d: barrier, stores, h_in -> LDS, barrier" % (2 - k), b + 3: "  bwd round %d: g recompute + barrier" % (2 - k),
+                  b + 2: "  bwd round %d: barrier, stores, h_in -> LDS" % (2 - k), b + 3: "  bwd round %d: g -> LDS + barrier" % (2 - k),
                   b + 4: "  bwd round %d: attention backward + barrier" % (2 - k), b + 5: "  bwd round %d: save dg + dg A^T + gated add + barrier" % (2 - k)})
 order = [0, 1] + list(range(10, 25)) + [2, 3, 4, 5] + list(range(30, 54)) + [60, 61, 62]
 keys = [k for k in order if k in names and buf[k]]
