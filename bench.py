@@ -416,7 +416,7 @@ def main():
     traffic, traffic_src = None, None
     kernel_name = eng.step_variant(T // launches_per_rollout)   # which step kernel these launches ran
     if (E, G, A, T) == (4096, 3, 3, 128):
-        for rnd in ("r03", "r02", "r01"):
+        for rnd in ("r04", "r03", "r02", "r01"):
             prof = os.path.join(ROOT, "profiles", "%s_%s_summary.json" % (rnd, "fused" if graph is None else "perstep"))
             if not os.path.isfile(prof):
                 continue
