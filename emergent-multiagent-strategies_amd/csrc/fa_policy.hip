@@ -65,6 +65,12 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32
 // work is what one wave did before (three 32 x 32 tiles per layer), but while one of its waves stores accumulators,
 // waits at a barrier or for an LDS read, the other's MFMA chain runs, and the phases no MFMA runs in (encoders,
 // attention, sampling: latency-bound LDS / DPP chains) have twice the waves to hide their latencies with.
+// A barrier INSIDE the wave split below: the two branches are taken by whole waves (`wave` is wave-uniform), so each wave
+// executes exactly one of the two barrier instructions.  The hardware barrier counts waves, whichever instruction they
+// arrive at; the HIP-level __syncthreads() does not promise that, so these are spelled as what they are -- the LDS
+// writes / reads of the wave drained, then s_barrier -- opaque to the compiler (it cannot duplicate, merge or move
+// memory operations across them).  Vector-memory requests (the weight prefetch) stay in flight across it.
+#define FA_WAVES_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #define FA_POLICY_SPLIT(...)                                                          \
     if constexpr (NW == 8) {                                                          \
         if (wave < 4) { constexpr int R0 = 0, NR = 2; __VA_ARGS__ }                   \
@@ -268,7 +274,7 @@ _Pragma("unroll")
             prefetch_b<128>(round < 2 ? wp_am : wp_w8p, lane, hd_m); // next: the following round's g, or the policy head
             const float bias = W[FA_POFF_BU + cbw * 32 + li];
             FA_PL_TICK(10 + round * 8)
-            __syncthreads(); // every wave has read the old h
+            FA_WAVES_BARRIER(); // every wave has read the old h
             FA_PL_TICK(11 + round * 8)
 _Pragma("unroll")
             for (int rb = 0; rb < NR; ++rb) store_acc<true>(sH + cbw * 32, R0 + rb, acc[rb], bias, lane);
@@ -294,7 +300,7 @@ _Pragma("unroll")
         gemm_cb<128, NR>(sH + (R0 * 32 + li) * LDA + hh * 64, wp_w8v, accv, lane, hd_v);
         if (wave < NRB) prefetch_b<256>(Wq + FA_POFF_W9 / 4, lane, hd_u);
         const float bv = W[FA_POFF_B8 + 128 + cbw * 32 + li];
-        __syncthreads(); // every wave has read h
+        FA_WAVES_BARRIER(); // every wave has read h
 _Pragma("unroll")
         for (int rb = 0; rb < NR; ++rb) store_acc<true>(sH + cbw * 32, R0 + rb, accv[rb], bv, lane);
     })
