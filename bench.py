@@ -342,7 +342,7 @@ def main():
                 eng.collect_step(s)
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        with torch.cuda.graph(graph, capture_error_mode="thread_local" if world > 1 else "global"):
             for s in range(T):
                 eng.collect_step(s)
 

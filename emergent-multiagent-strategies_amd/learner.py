@@ -59,6 +59,13 @@ def ppo_losses(pol, own, opp, actions, value_preds, returns, old_logp, adv, clip
     return value_loss, action_loss, dist_entropy
 
 
+def _capture_mode():
+    """cudaStreamCaptureMode for the hipGraph captures: with a process group alive another thread of the process -- the
+    NCCL / RCCL watchdog polling its events -- may call into the runtime while a capture is open; "global" mode turns
+    such a call into a capture error, "thread_local" only polices the capturing thread."""
+    return "thread_local" if (dist.is_available() and dist.is_initialized()) else "global"
+
+
 def _world(group=None):
     return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
 
@@ -203,13 +210,13 @@ class GraphedPPOStep(object):
         self.g1 = torch.cuda.CUDAGraph()
         self.g2 = None
         if not exchanging:
-            with torch.cuda.graph(self.g1):
+            with torch.cuda.graph(self.g1, capture_error_mode=_capture_mode()):
                 self.losses = eager()
         else:
-            with torch.cuda.graph(self.g1):
+            with torch.cuda.graph(self.g1, capture_error_mode=_capture_mode()):
                 l0, self.flat = fwd_bwd()
             self.g2 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.g2, pool=self.g1.pool()):
+            with torch.cuda.graph(self.g2, pool=self.g1.pool(), capture_error_mode=_capture_mode()):
                 self.losses = finish(l0, self.flat)
 
     def run(self, rows, idx, reduce_after=None, reduce_done=None):
@@ -592,7 +599,7 @@ class BatchedLearner(object):
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        with torch.cuda.graph(g, capture_error_mode=_capture_mode()):
             for s in range(self.T):
                 self.step(s)
             self._value_last()
