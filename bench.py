@@ -270,6 +270,10 @@ def main():
                     help="skip the 5v5 records of a default 3v3 run (fused launch, closed loop, closed loop with the "
                          "five-strategy attacker ensemble = BASELINE config 5's per-GPU shape)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL on ROCm)")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="with --gpus 1: open a process group of ONE rank and take the several-rank path anyway (the "
+                         "all-gather, the merge kernel, the second-stream exchange run on one rank and must change nothing): how "
+                         "a one-GPU box executes the RCCL path")
     ap.add_argument("--share-devices", action="store_true",
                     help="map ranks onto the visible GPUs round-robin (smoke-testing the multi-rank "
                          "path on a box with fewer GPUs than ranks; use with --backend gloo)")
@@ -301,15 +305,27 @@ def main():
                          % (local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    exchanging = world > 1 or args.force_collective     # the several-rank code path (see --force-collective)
+    if exchanging:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if "MASTER_PORT" not in os.environ:
+                with socket.socket() as sk:
+                    sk.bind(("127.0.0.1", 0))
+                    os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(args.backend)
 
     import emergent_multiagent_strategies_amd as fa
+    from emergent_multiagent_strategies_amd import dist as fa_dist
     from emergent_multiagent_strategies_amd.dist import gae_adv_mean_std
+    if args.force_collective:
+        fa_dist.FORCE_COLLECTIVE = True
 
     # which device and which CPUs every rank ended up on (a rank whose CPUs sit on the other socket, or two ranks on one
     # device, show up here and not as an unexplained slow rank)
@@ -352,12 +368,65 @@ def main():
         else:
             eng.collect_rollout(0, T)
 
+    # Several ranks: the exchange of rollout k -- all-gather of the N x 3 moments, exact merge, normalisation -- runs on a
+    # SECOND stream under rollout k + 1 (nothing in a rollout depends on the statistics of the previous one; only the next
+    # GAE pass, which rewrites `returns`, has to wait for the normalisation that reads them).  One rank: one stream.
+    main_stream = torch.cuda.current_stream()
+    xchg_stream = torch.cuda.Stream() if exchanging else None
+    pending = {"norm_done": None}
+    gather_buf = torch.zeros((world, N, 3), dtype=torch.float64, device=dev) if exchanging else None
+
+    local_graph = {"g": None}   # several ranks: GAE + local moments replayed as ONE graph (the host has the exchange to enqueue
+                                # as well, and must stay ahead of a 0.19 ms step)
+
+    def collector_tail():
+        if not exchanging:
+            mean, std = gae_adv_mean_std(eng, 0.99, 0.95)          # GAE + one-pass fp64 advantage moments
+            eng.adv_normalize(mean, std, out=adv)
+            return
+        if pending["norm_done"] is not None:
+            main_stream.wait_event(pending["norm_done"])           # the previous normalisation has read returns / the moments
+        mom, _, _ = eng.gae_moments(0.99, 0.95)                    # this rank's (n, mean, M2) per agent
+        exchange(mom)
+
+    def drain():
+        if xchg_stream is not None:
+            main_stream.wait_stream(xchg_stream)
+
+    def exchange(mom):
+        ready = torch.cuda.Event()
+        ready.record(main_stream)
+        with torch.cuda.stream(xchg_stream):
+            xchg_stream.wait_event(ready)
+            dist.all_gather_into_tensor(gather_buf.view(-1), mom.view(-1))   # the path's one collective (RCCL / xGMI)
+            mean, std = eng.adv_merge(gather_buf)                  # Chan-Golub-LeVeque in rank order: same bits on every rank
+            eng.adv_normalize(mean, std, out=adv)
+            done = torch.cuda.Event()
+            done.record(xchg_stream)
+        pending["norm_done"] = done
+
     def hot_path():
+        if exchanging and not args.no_collector and graph is None:
+            if local_graph["g"] is None:                           # capture GAE + local moments (three launches) once
+                cap = torch.cuda.Stream()
+                cap.wait_stream(main_stream)
+                with torch.cuda.stream(cap):
+                    local_graph["mom"] = eng.gae_moments(0.99, 0.95)[0]
+                main_stream.wait_stream(cap)
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    eng.gae_moments(0.99, 0.95)
+                local_graph["g"] = g
+            env_rollout()
+            if pending["norm_done"] is not None:
+                main_stream.wait_event(pending["norm_done"])       # the previous normalisation has read returns / the moments
+            local_graph["g"].replay()
+            exchange(local_graph["mom"])
+            return
         env_rollout()
         if not args.no_collector:
-            # GAE, one-pass fp64 advantage moments; one all-gather of N x 3 doubles when world > 1
-            mean, std = gae_adv_mean_std(eng, 0.99, 0.95)
-            eng.adv_normalize(mean, std, out=adv)
+            collector_tail()
 
     def barrier():
         if world > 1:
@@ -378,6 +447,7 @@ def main():
         torch.cuda.synchronize()
         est = (time.perf_counter() - t0) / 5
         steps = max(steps, int(min_seconds / max(est, 1e-6)) + 1)
+        drain()
         if world > 1:
             ts = torch.tensor([steps], device=dev, dtype=torch.int64)
             dist.all_reduce(ts, op=dist.ReduceOp.MAX)
@@ -392,8 +462,15 @@ def main():
         env_rollout()
         ev[k][1].record()
         if not args.no_collector:
-            mean, std = gae_adv_mean_std(eng, 0.99, 0.95)
-            eng.adv_normalize(mean, std, out=adv)
+            if exchanging and graph is None and local_graph["g"] is not None:
+                if pending["norm_done"] is not None:
+                    main_stream.wait_event(pending["norm_done"])
+                local_graph["g"].replay()
+                exchange(local_graph["mom"])
+            else:
+                collector_tail()
+    host_enqueue = time.perf_counter() - t0       # the host's share: everything above only ENQUEUES work
+    drain()
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -402,10 +479,15 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
+    # the second-stream exchange must leave what the one-stream form leaves (same launches, same order per buffer)
+    pipelined_ok = None
+    if exchanging and not args.no_collector:
+        mean, std = gae_adv_mean_std(eng, 0.99, 0.95)
+        pipelined_ok = bool(torch.equal(eng.adv_normalize(mean, std), adv))
     env_steps = world * E * T * steps
     value = env_steps / elapsed
     launches_per_rollout = T if graph is not None else 1
-    roll_ms = sum(a.elapsed_time(b) for a, b in ev) / steps
+    roll_ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
     launch_s = roll_ms * 1e-3 / launches_per_rollout
     bytes_per_launch = algorithmic_bytes_per_env_step(N) * E * (T // launches_per_rollout)
     achieved = bytes_per_launch / launch_s / 1e9
@@ -447,6 +529,7 @@ def main():
             "metric": "env-steps/sec FortAttack %dv%d, %d parallel envs per GPU" % (G, A, E),
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": steps, "steps_requested": steps_requested,
             "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / steps, "timed_seconds": elapsed,
+            "host_enqueue_ms_per_step": host_enqueue * 1e3 / steps,   # < ms_per_step: the GPU, not the Python loop, sets the pace
             "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {
@@ -477,15 +560,18 @@ def main():
                 "algorithmic_bytes_per_env_step": algorithmic_bytes_per_env_step(N),
                 "env_steps_per_launch": E * (T // launches_per_rollout),
                 "avg_launch_us": launch_s * 1e6, "timed_by": "hipEvents on the launch stream, %d launches" % (
-                    steps * launches_per_rollout)},
+                    len(ev) * launches_per_rollout)},
             "env_rollout_ms": roll_ms,
         }
         # which exchange carried the advantage statistics (and the closed loop's gradients), seen by how many ranks
-        res["collective"] = {"ranks": dist.get_world_size() if world > 1 else 1,
-                             "backend": dist.get_backend() if world > 1 else None,
-                             "rccl_ranks": (dist.get_world_size() if (world > 1 and dist.get_backend() == "nccl") else 0),
+        res["collective"] = {"ranks": dist.get_world_size() if exchanging else 1,
+                             "backend": dist.get_backend() if exchanging else None,
+                             "rccl_ranks": (dist.get_world_size() if (exchanging and dist.get_backend() == "nccl") else 0),
                              "rank_binding": binding,
-                             "per_rollout": "one all_gather_into_tensor of N x 3 f64 (advantage moments) + exact merge",
+                             "per_rollout": "one all_gather_into_tensor of N x 3 f64 (advantage moments) + exact merge + normalisation, "
+                                            "on a second stream under the next rollout",
+                             "forced_on_one_rank": bool(args.force_collective),
+                             "second_stream_exchange_equals_one_stream": pipelined_ok,
                              "per_optimizer_step": "one all_reduce of the flat f32 gradient buffer (149 908 floats) per team"}
         if closed is not None:
             res["closed_loop"] = closed
@@ -496,9 +582,16 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(E, G, A, T)
         sys.stdout.flush()
+        try:                                   # what C libraries printf'ed while fd 1 pointed at stderr (RCCL's version
+            import ctypes                      # banner sits in the C stdio buffer until exit) must not follow the line
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
         os.dup2(real_stdout, 1)
         print(json.dumps(res), flush=True)
-    if world > 1:
+        sys.stdout.flush()
+        os.dup2(2, 1)                          # anything printed after the line (process-group teardown) goes to stderr again
+    if exchanging:
         dist.destroy_process_group()
 
 
