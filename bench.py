@@ -270,6 +270,10 @@ def main():
                     help="skip the 5v5 records of a default 3v3 run (fused launch, closed loop, closed loop with the "
                          "five-strategy attacker ensemble = BASELINE config 5's per-GPU shape)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL on ROCm)")
+    ap.add_argument("--two-stream-tail", action="store_true",
+                    help="experiment: put the advantage statistics, the exchange and the normalisation of a rollout on a second "
+                         "stream, under the next rollout (measured: 0.186 vs 0.188 ms per step on one rank, 0.218 vs 0.203 with the "
+                         "forced one-rank collective -- the cross-stream event waits cost what the overlap gains; default off)")
     ap.add_argument("--force-collective", action="store_true",
                     help="with --gpus 1: open a process group of ONE rank and take the several-rank path anyway (the "
                          "all-gather, the merge kernel, the second-stream exchange run on one rank and must change nothing): how "
@@ -368,62 +372,43 @@ def main():
         else:
             eng.collect_rollout(0, T)
 
-    # Several ranks: the exchange of rollout k -- all-gather of the N x 3 moments, exact merge, normalisation -- runs on a
-    # SECOND stream under rollout k + 1 (nothing in a rollout depends on the statistics of the previous one; only the next
-    # GAE pass, which rewrites `returns`, has to wait for the normalisation that reads them).  One rank: one stream.
+    # The collector tail of rollout k: the GAE scan, the one-pass advantage moments, (several ranks: the all-gather of the
+    # N x 3 moments and the exact merge,) the normalisation -- all on the launch stream.  --two-stream-tail (experiment) moves
+    # everything behind the GAE scan to a second stream, under rollout k + 1: those kernels read returns / value_preds only,
+    # which no rollout touches, and the next GAE pass, which rewrites `returns`, waits for them.
     main_stream = torch.cuda.current_stream()
-    xchg_stream = torch.cuda.Stream() if exchanging else None
-    pending = {"norm_done": None}
+    tail_stream = torch.cuda.Stream() if args.two_stream_tail else None
+    pending = {"tail_done": None}
     gather_buf = torch.zeros((world, N, 3), dtype=torch.float64, device=dev) if exchanging else None
 
-    local_graph = {"g": None}   # several ranks: GAE + local moments replayed as ONE graph (the host has the exchange to enqueue
-                                # as well, and must stay ahead of a 0.19 ms step)
-
-    def collector_tail():
-        if not exchanging:
-            mean, std = gae_adv_mean_std(eng, 0.99, 0.95)          # GAE + one-pass fp64 advantage moments
-            eng.adv_normalize(mean, std, out=adv)
-            return
-        if pending["norm_done"] is not None:
-            main_stream.wait_event(pending["norm_done"])           # the previous normalisation has read returns / the moments
-        mom, _, _ = eng.gae_moments(0.99, 0.95)                    # this rank's (n, mean, M2) per agent
-        exchange(mom)
-
-    def drain():
-        if xchg_stream is not None:
-            main_stream.wait_stream(xchg_stream)
-
-    def exchange(mom):
-        ready = torch.cuda.Event()
-        ready.record(main_stream)
-        with torch.cuda.stream(xchg_stream):
-            xchg_stream.wait_event(ready)
+    def statistics_and_normalise():
+        mom, mean, std = eng.adv_moments_onepass()                 # this rank's (n, mean, M2), mean, std per agent
+        if exchanging:
             dist.all_gather_into_tensor(gather_buf.view(-1), mom.view(-1))   # the path's one collective (RCCL / xGMI)
             mean, std = eng.adv_merge(gather_buf)                  # Chan-Golub-LeVeque in rank order: same bits on every rank
-            eng.adv_normalize(mean, std, out=adv)
+        eng.adv_normalize(mean, std, out=adv)
+
+    def collector_tail():
+        if pending["tail_done"] is not None:
+            main_stream.wait_event(pending["tail_done"])           # the previous statistics / normalisation have read `returns`
+        eng.gae(0.99, 0.95)
+        if tail_stream is None:
+            statistics_and_normalise()
+            return
+        ready = torch.cuda.Event()
+        ready.record(main_stream)
+        with torch.cuda.stream(tail_stream):
+            tail_stream.wait_event(ready)
+            statistics_and_normalise()
             done = torch.cuda.Event()
-            done.record(xchg_stream)
-        pending["norm_done"] = done
+            done.record(tail_stream)
+        pending["tail_done"] = done
+
+    def drain():
+        if tail_stream is not None:
+            main_stream.wait_stream(tail_stream)
 
     def hot_path():
-        if exchanging and not args.no_collector and graph is None:
-            if local_graph["g"] is None:                           # capture GAE + local moments (three launches) once
-                cap = torch.cuda.Stream()
-                cap.wait_stream(main_stream)
-                with torch.cuda.stream(cap):
-                    local_graph["mom"] = eng.gae_moments(0.99, 0.95)[0]
-                main_stream.wait_stream(cap)
-                torch.cuda.synchronize()
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                    eng.gae_moments(0.99, 0.95)
-                local_graph["g"] = g
-            env_rollout()
-            if pending["norm_done"] is not None:
-                main_stream.wait_event(pending["norm_done"])       # the previous normalisation has read returns / the moments
-            local_graph["g"].replay()
-            exchange(local_graph["mom"])
-            return
         env_rollout()
         if not args.no_collector:
             collector_tail()
@@ -462,13 +447,7 @@ def main():
         env_rollout()
         ev[k][1].record()
         if not args.no_collector:
-            if exchanging and graph is None and local_graph["g"] is not None:
-                if pending["norm_done"] is not None:
-                    main_stream.wait_event(pending["norm_done"])
-                local_graph["g"].replay()
-                exchange(local_graph["mom"])
-            else:
-                collector_tail()
+            collector_tail()
     host_enqueue = time.perf_counter() - t0       # the host's share: everything above only ENQUEUES work
     drain()
     torch.cuda.synchronize()
@@ -481,7 +460,7 @@ def main():
 
     # the second-stream exchange must leave what the one-stream form leaves (same launches, same order per buffer)
     pipelined_ok = None
-    if exchanging and not args.no_collector:
+    if tail_stream is not None and not args.no_collector:
         mean, std = gae_adv_mean_std(eng, 0.99, 0.95)
         pipelined_ok = bool(torch.equal(eng.adv_normalize(mean, std), adv))
     env_steps = world * E * T * steps
@@ -540,7 +519,9 @@ def main():
                                 "one fa_step launch per env-step replayed from a hipGraph",
                                 "step kernel only" if args.no_collector else
                                 "+ fused RolloutStorage write, GAE scan, one-pass fp64 advantage moments "
-                                "(all-gather of N x 3 f64 when n_gpus > 1) and normalisation"),
+                                "(all-gather of N x 3 f64 when n_gpus > 1) and normalisation" + (
+                                    "" if tail_stream is None else "; --two-stream-tail: the moments / exchange / normalisation of a rollout run "
+                                    "on a second stream under the next rollout (the next GAE pass waits for them)")),
                 "envs_per_gpu": E, "rollout_steps": T, "num_guards": G, "num_attackers": A,
                 "max_time_steps": 100, "rng": "mt19937 (reference-parity reset stream)",
                 "agent_counters": "off" if args.no_counters else "on (numHit / numWasHit / evaluation counters)",
@@ -568,8 +549,8 @@ def main():
                              "backend": dist.get_backend() if exchanging else None,
                              "rccl_ranks": (dist.get_world_size() if (exchanging and dist.get_backend() == "nccl") else 0),
                              "rank_binding": binding,
-                             "per_rollout": "one all_gather_into_tensor of N x 3 f64 (advantage moments) + exact merge + normalisation, "
-                                            "on a second stream under the next rollout",
+                             "per_rollout": "one all_gather_into_tensor of N x 3 f64 (advantage moments) + exact merge, between the "
+                                            "moments sweep and the normalisation",
                              "forced_on_one_rank": bool(args.force_collective),
                              "second_stream_exchange_equals_one_stream": pipelined_ok,
                              "per_optimizer_step": "one all_reduce of the flat f32 gradient buffer (149 908 floats) per team"}

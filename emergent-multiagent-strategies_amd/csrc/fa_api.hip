@@ -440,6 +440,19 @@ int fa_gae_moments(fa_env *env, double gamma, double tau, double *moments_out, d
     return FA_OK;
 }
 
+int fa_adv_moments_onepass(fa_env *env, double *moments_out, double *mean_out, double *std_out, void *stream) {
+    if (!env) return fail(FA_ERR_INVALID, "fa_adv_moments_onepass: null env");
+    if (!env->bound) return fail(FA_ERR_STATE, "fa_adv_moments_onepass: no storage bound");
+    DeviceGuard guard(env->cfg.device_id);
+    const fa_storage &st = env->st;
+    const long long rows = (long long)st.num_steps * env->cfg.num_envs;
+    long long want = (rows + 2047) / 2048;   // as fa_gae_moments: a lane takes 2 rows x 4 per trip, at most two workgroups per CU
+    const int nblocks = (int)(want < 512 ? (want < 1 ? 1 : want) : 512);
+    FA_HIP(fa_launch_adv_onepass(st.returns, st.value_preds, rows, env->N, env->adv_partial, nblocks, moments_out, mean_out,
+                                 std_out, static_cast<hipStream_t>(stream)));
+    return FA_OK;
+}
+
 int fa_adv_stats(fa_env *env, int32_t pass, const double *mean, double *stats, void *stream) {
     if (!env || !stats) return fail(FA_ERR_INVALID, "fa_adv_stats: null argument");
     if (!env->bound) return fail(FA_ERR_STATE, "fa_adv_stats: no storage bound");

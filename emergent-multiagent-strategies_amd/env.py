@@ -179,6 +179,16 @@ class BatchedFortAttack(object):
                                             _ptr(self._adv_ms[0]), _ptr(self._adv_ms[1]), _stream()), "fa_gae_moments")
         return self._gae_mom, self._adv_ms[0], self._adv_ms[1]
 
+    def adv_moments_onepass(self):
+        """fa_adv_moments_onepass: the statistics half of gae_moments alone (same buffers, same values), on the current stream."""
+        if not hasattr(self, "_gae_mom"):
+            self._gae_mom = torch.zeros((self.N, 3), dtype=torch.float64, device=self.device)
+        if not hasattr(self, "_adv_ms"):
+            self._adv_ms = torch.zeros((2, self.N), dtype=torch.float64, device=self.device)
+        _lib.check(self._lib.fa_adv_moments_onepass(self._h, _ptr(self._gae_mom), _ptr(self._adv_ms[0]), _ptr(self._adv_ms[1]),
+                                                    _stream()), "fa_adv_moments_onepass")
+        return self._gae_mom, self._adv_ms[0], self._adv_ms[1]
+
     def adv_stats(self, pass_, mean=None, out=None):
         """fa_adv_stats.  pass 0 fills out[i] = {n, sum(A), 0}; pass 1 (needs `mean`) writes only
         out[i][2] = sum((A-mean)^2) -- hand it pass 0's buffer to get the full triple."""

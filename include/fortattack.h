@@ -211,6 +211,10 @@ int fa_gae(fa_env *env, double gamma, double tau, void *stream);
  * moments[i] = {n, mean, M2} (the fa_adv_moments / fa_adv_merge format), mean[i] and the unbiased
  * std[i] of THIS handle's samples; any of the three may be null.  Device pointers. */
 int fa_gae_moments(fa_env *env, double gamma, double tau, double *moments, double *mean, double *std_, void *stream);
+/* The second half of fa_gae_moments alone -- the one-pass per-agent advantage moments (n, mean, M2), mean and unbiased
+ * std of ppo.py:121-123 from the bound storage's returns / value_preds -- for a caller that puts the statistics on
+ * another stream than the GAE scan (they read returns / value_preds only; the next rollout does not touch those). */
+int fa_adv_moments_onepass(fa_env *env, double *moments, double *mean, double *std_, void *stream);
 /* Advantage statistics of JointPPO.update (rlcore/algo/ppo.py:121-123), per agent, in
  * fp64: pass 0 writes stats[i] = {n, sum(A), 0}; pass 1 reads mean[i] and writes
  * only stats[i][2] = sum((A-mean)^2) (stats[i][0..1] are left as they are).  A = returns[:-1] - value_preds[:-1].

@@ -142,16 +142,17 @@ def test_one_rank_through_rccl_changes_nothing(route):
     assert worst < 4e-4, worst
 
 
-def test_bench_second_stream_exchange_on_rccl_with_one_rank():
-    """bench.py's several-rank hot path -- GAE + local moments on the launch stream, all-gather + merge + normalisation on a
-    second stream under the next rollout -- executed on RCCL in a world of ONE rank (`--force-collective`): the line must
-    report one RCCL rank, and the second-stream form must have left exactly the advantages of the one-stream form."""
+def test_bench_exchange_on_rccl_with_one_rank():
+    """bench.py's several-rank hot path -- GAE, local moments, all-gather, merge, normalisation -- executed on RCCL in a world of
+    ONE rank (`--force-collective`), here in its two-stream form (`--two-stream-tail`: everything behind the GAE scan on a
+    second stream under the next rollout): the line must report one RCCL rank, and the two-stream form must have left exactly
+    the advantages of the one-stream form."""
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--force-collective", "--backend", "nccl",
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--force-collective", "--two-stream-tail", "--backend", "nccl",
                           "--envs", "1024", "--rollout", "32", "--steps", "10", "--warmup", "2", "--no-cpu-baseline", "--no-5v5",
                           "--no-esweep", "--closed-loop-rollouts", "2", "--closed-loop-updates", "1"],
                          cwd=root, env=env, capture_output=True, text=True, timeout=900)
