@@ -190,7 +190,9 @@ __device__ __forceinline__ void fa_train_body(const FaTrainArgs &a) {
 #pragma unroll
         for (int k = tid; k < TR * 32; k += NTH) {
             const int r = k >> 5, c4 = k & 31;
-            reinterpret_cast<float4 *>(dst)[k] = *reinterpret_cast<const float4 *>(src + r * LDA + c4 * 4);
+            // (non-temporal: a record is read once, by another kernel -- it need not displace the weights in L2)
+            typedef float v4f __attribute__((ext_vector_type(4)));
+            __builtin_nontemporal_store(*reinterpret_cast<const v4f *>(src + r * LDA + c4 * 4), reinterpret_cast<v4f *>(dst) + k);
         }
     };
     auto save_tile64 = [&](const float *src, float *dst) { // 32 x 64 LDS (at src, row stride LDA) -> global
@@ -330,7 +332,6 @@ __device__ __forceinline__ void fa_train_body(const FaTrainArgs &a) {
         FA_TR_TICK(11 + 5 * round)
         {   // team attention, self excluded (mpnn.py:250-332); rows beyond the tile's envs: hmix = 0
             float ov[2][8];
-#ifndef FA_TRAIN_RECOMPUTE_G
             // g is saved for the backward (a GEMM and a barrier less per round there) by the sub-group that is about to
             // overwrite the row with the mix -- no other wave touches it in this phase
 #pragma unroll
@@ -340,7 +341,6 @@ __device__ __forceinline__ void fa_train_body(const FaTrainArgs &a) {
                 dst[0] = *reinterpret_cast<const float4 *>(B1 + r * LDA + q16 * 8);
                 dst[1] = *reinterpret_cast<const float4 *>(B1 + r * LDA + q16 * 8 + 4);
             }
-#endif
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
                 const int r = wave * 4 + (lane >> 4) + k * NWV * 4, rr = r < RU ? r : RU - 1, el = rr / n;
@@ -580,11 +580,9 @@ __device__ __forceinline__ void fa_train_body(const FaTrainArgs &a) {
         float4 hin[TR * 32 / NTH];
 #pragma unroll
         for (int j = 0; j < TR * 32 / NTH; ++j) hin[j] = reinterpret_cast<const float4 *>(rec + FA_RECA_HIN)[tid + j * NTH];
-#ifndef FA_TRAIN_RECOMPUTE_G
         float4 gin[TR * 32 / NTH];
 #pragma unroll
         for (int j = 0; j < TR * 32 / NTH; ++j) gin[j] = reinterpret_cast<const float4 *>(recG + round * FA_REC_PLANE)[tid + j * NTH];
-#endif
         __builtin_amdgcn_sched_barrier(0);
         FA_TR_TICK(30 + 8 * (2 - round))
         {   // [dh_a | dhmix] = dZ W7^T (K = 128 -> 256 columns)
@@ -601,21 +599,6 @@ __device__ __forceinline__ void fa_train_body(const FaTrainArgs &a) {
             const int k = tid + j * NTH;
             *reinterpret_cast<float4 *>(B0 + (k >> 5) * LDA + (k & 31) * 4) = hin[j];
         }
-#ifdef FA_TRAIN_RECOMPUTE_G
-        BHead<128> hd_g;
-        prefetch_b<128>(wp_am, lane, hd_g);
-        __syncthreads();
-        FA_TR_TICK(32 + 8 * (2 - round))
-        if (tid < 128) dbu += sO2[tid] + sO2[128 + tid];
-        project_team(B2, hd_g); // g = h_in A_m -> B2, recomputed
-        BHead<128> hd;
-        const float4 *wp = Tq + FA_TOFF_AMT / 4 + cbw * 16 * 64;
-        prefetch_b<128>(wp, lane, hd);
-        __syncthreads();
-        FA_TR_TICK(33 + 8 * (2 - round))
-        if (wave == 0 && lane < 32)
-            for (int r = RU; r < TR; ++r) *reinterpret_cast<float4 *>(B2 + r * LDA + lane * 4) = float4{0, 0, 0, 0};
-#else
         // g -> B2 (rows beyond the tile's envs hold the g of padding rows: their dg is zero)
 #pragma unroll
         for (int j = 0; j < TR * 32 / NTH; ++j) {
@@ -624,17 +607,16 @@ __device__ __forceinline__ void fa_train_body(const FaTrainArgs &a) {
         }
         BHead<128> hd;
         const float4 *wp = Tq + FA_TOFF_AMT / 4 + cbw * 16 * 64;
-        prefetch_b<128>(wp, lane, hd);
         __syncthreads();
         FA_TR_TICK(33 + 8 * (2 - round))
         if (tid < 128) dbu += sO2[tid] + sO2[128 + tid];
-#endif
         // attention backward per env: dhmix (B1), g (B2) -> dg (B2 in place), dkeys added into B3
         for (int el = wave * 4 + (lane >> 4); el < ET; el += NWV * 4)
             attend_env_bwd<128, true, MT>(B1 + (el * n) * LDA, B2 + (el * n) * LDA, B0 + (el * n) * LDA, B3 + (el * n) * LDA,
                                           sAttn[1 + round] + (el * n) * 8, n, n, q16);
         __syncthreads();
         FA_TR_TICK(34 + 8 * (2 - round))
+        prefetch_b<128>(wp, lane, hd); // (requested here, not ahead of the attention: 16 registers less across it, 1-2 % faster)
         save_tile(B2, rec + FA_RECA_DG);
         {   // dh += dg A_m^T, and -- rounds 2, 1 -- through the relu of the round below (its output is this round's h_in)
             f32x16 acc[1] = {};

@@ -84,7 +84,7 @@ __device__ __forceinline__ void dw_range(const float *__restrict__ rec, int q0, 
         const int cur = ((q - q0) & 1) * FA_RECB_FLOATS, nxt = FA_RECB_FLOATS - cur; // float offsets of the two images
         src = reinterpret_cast<const f32x4 *>(rec + (size_t)(q + 1 < q1 ? q + 1 : q) * RF);
 #pragma unroll
-        for (int j = 0; j < NS; ++j) stage[j] = src[tid + j * DW_NT];
+        for (int j = 0; j < NS; ++j) stage[j] = __builtin_nontemporal_load(src + tid + j * DW_NT); // (read once)
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int t = 0; t < FA_TR_ROWS / 2; ++t) {
