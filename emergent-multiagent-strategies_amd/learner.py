@@ -320,7 +320,7 @@ class BatchedLearner(object):
     def __init__(self, eng, num_steps=128, hidden_dim=128, lr=1e-4, clip_param=0.2, ppo_epoch=4,
                  num_mini_batch=32, value_loss_coef=0.5, entropy_coef=0.01, max_grad_norm=0.5,
                  gamma=0.99, tau=0.95, clipped_value_loss=True, use_graph=False, group=None, policy_backend="auto",
-                 sample_seed=None, update_backend="auto", exchange="torch"):
+                 sample_seed=None, update_backend="auto", exchange="torch", reference_sampling=False):
         # defaults: arguments.py:22-45
         # policy_backend: "hip" = the fused fa_policy kernel runs the rollout's forwards (hidden_dim 128),
         # "torch" = the PyTorch modules do, "auto" = hip whenever it supports the configuration
@@ -331,6 +331,13 @@ class BatchedLearner(object):
         self.value_loss_coef, self.entropy_coef = value_loss_coef, entropy_coef
         self.max_grad_norm, self.clipped_value_loss = max_grad_norm, clipped_value_loss
         self.group = group
+        # reference_sampling: the minibatch index sets are drawn as the reference draws them -- one torch.randperm(T * E) on the
+        # CPU's default generator per epoch and team (BatchSampler(SubsetRandomSampler(range(batch)), mb), ppo.py:213), the
+        # guards' epochs first, then the attackers' (learner.py:175-188) -- so that torch.manual_seed(s) gives the reference's
+        # minibatches.  Default: permutations drawn on the device (same distribution, no host round trip).  (The ACTION
+        # sampling stream cannot be the reference's: FixedCategorical.sample is torch.multinomial on the CPU generator, the
+        # engine samples inside the policy kernel from Philox keyed by (seed; rollout, step, env, agent).)
+        self.reference_sampling = bool(reference_sampling)
         # exchange: "torch" = torch.distributed collectives on `group` (backend "nccl" is RCCL); "rccl" = the library's own
         # RCCL communicators (dist.LibraryExchange -> fa_adv_allreduce / fa_grad_allreduce), also with ONE rank.
         # Each team's update chain gets its own communicator / process group: the two chains run concurrently on two
@@ -647,6 +654,9 @@ class BatchedLearner(object):
     def update(self, train_guards_only=False, sampler=None):
         """-> float tensor (n_trained_teams, 3) = mean (value_loss, action_loss, entropy)."""
         st, T, E = self.storage, self.T, self.E
+        graphs_with_sampler = False
+        if sampler is None and self.reference_sampling:
+            sampler, graphs_with_sampler = self._reference_sampler(), True
         mean, std = self._adv_mean_std                           # ppo.py:121-123, from collect()
         # The fused optimizer steps normalise the advantages inside the kernel from (mean, std): the (T, E, N) advantage
         # tensor is only materialised for the paths that read it (PyTorch autograd, a caller's sampler, a ragged last
@@ -654,8 +664,8 @@ class BatchedLearner(object):
         batch = T * E
         mb = int(batch / self.num_mini_batch) if batch >= self.num_mini_batch else 0
         g = self._update_graphs
-        in_kernel = (g is not None and g.get("fused", False) and sampler is None and mb > 0 and batch % mb == 0
-                     and all(mpnn_pack.supported(p) for p in self.policies))
+        in_kernel = (g is not None and g.get("fused", False) and (sampler is None or graphs_with_sampler) and mb > 0
+                     and batch % mb == 0 and all(mpnn_pack.supported(p) for p in self.policies))
         adv_stats = (self._adv_mean, self._adv_std) if in_kernel else None
         if not in_kernel:
             self.eng.adv_normalize(mean, std, out=self.adv)      # ppo.py:123
@@ -671,8 +681,21 @@ class BatchedLearner(object):
                 self.policies[ti], self.optimizers[ti], self.team_slices[ti], self.team_slices[1 - ti], rows,
                 self.clip_param, self.ppo_epoch, self.num_mini_batch, self.value_loss_coef, self.entropy_coef,
                 self.max_grad_norm, self.clipped_value_loss, self._team_groups[ti], sampler,
-                graphs=None if sampler is not None else self._update_graphs, exchange=self._team_exch[ti], adv_stats=adv_stats))
+                graphs=self._update_graphs if (sampler is None or graphs_with_sampler) else None,
+                exchange=self._team_exch[ti], adv_stats=adv_stats))
         return torch.stack(out)
+
+    def _reference_sampler(self):
+        """magent_feed_forward_generator's index sets (ppo.py:207-213): BatchSampler(SubsetRandomSampler(range(batch)), mb,
+        drop_last=False) iterates ONE torch.randperm(batch) of the CPU's default generator in chunks of mb."""
+        batch = self.T * self.E
+        mb = int(batch / self.num_mini_batch)
+        dev = self.device
+
+        def sampler(epoch):
+            perm = torch.randperm(batch)
+            return [perm[k:k + mb].to(dev) for k in range(0, batch, mb)]
+        return sampler
 
     def _teams_step_ok(self, rows):
         g = self._update_graphs

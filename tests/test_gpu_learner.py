@@ -412,3 +412,33 @@ def test_detached_parameters_are_refused(fa):
     p.data = p.data.clone()                                 # re-pointed
     with pytest.raises(RuntimeError, match="flat buffer"):
         L.collect()
+
+
+def test_reference_sampling_mode_replays_the_cpu_generator(fa):
+    """BatchedLearner(reference_sampling=True): the minibatch index sets come from torch.randperm on the CPU's default
+    generator in the reference's order (ppo.py:213; guards' epochs, then attackers'), the optimizer steps still replay from the
+    fused graphs.  Same seed -> same update, bit for bit; the update consumes the CPU generator; and it equals the update
+    driven through the `sampler` hook with the very same index sets (PyTorch-autograd path) to the fused-vs-torch tolerance."""
+    res = []
+    for mode in ("reference", "reference", "hook"):
+        torch.manual_seed(4)
+        eng = fa.BatchedFortAttack(256, 3, 3, 12, base_seed=6)
+        L = fa.BatchedLearner(eng, num_steps=16, num_mini_batch=4, ppo_epoch=2, use_graph=True, update_backend="fused",
+                              reference_sampling=(mode == "reference"), lr=1e-4)
+        L.reset()
+        L.collect()
+        torch.manual_seed(99)
+        before = torch.get_rng_state().clone()
+        if mode == "reference":
+            losses = L.update()
+            assert any(isinstance(k, tuple) for k in L._update_graphs)      # the captured fused steps ran
+        else:
+            hook = L._reference_sampler()                                    # the same draws, through the eager autograd path
+            losses = L.update(sampler=hook)
+        torch.cuda.synchronize()
+        assert not torch.equal(before, torch.get_rng_state())               # 2 teams x 2 epochs of randperm on the CPU generator
+        res.append((losses.cpu(), [p.detach().cpu().clone() for pol in L.policies for p in pol.parameters()]))
+    (l0, p0), (l1, p1), (l2, p2) = res
+    assert torch.equal(l0, l1) and all(torch.equal(a, b) for a, b in zip(p0, p1))
+    assert (l0 - l2).abs().max() < 2e-4 * max(1.0, float(l0.abs().max()))
+    assert max(float((x - y).abs().max()) for x, y in zip(p0, p2)) < 4e-4   # 8 Adam steps of 1e-4

@@ -83,3 +83,28 @@ def test_all_dead_minibatch_gives_zero_losses():
     z = torch.zeros(5, 2, 1)
     vl, al, ent = ppo_losses(pol, own, torch.randn(5, 2, 6), z.long(), z, z, z, z, 0.2)
     assert float(vl) == 0 and float(al) == 0 and float(ent) == 0 and torch.isfinite(vl)
+
+
+def test_reference_sampling_draws_the_reference_minibatches():
+    """BatchedLearner(reference_sampling=True)'s index sets == the ones magent_feed_forward_generator (ppo.py:207-246) draws
+    from the same torch seed: rollouts whose observation column 0 holds the flat sample index t * P + p make the reference's
+    generator reveal its indices."""
+    rh.import_reference()
+    from rlcore.algo.ppo import magent_feed_forward_generator
+    from rlcore.storage import RolloutStorage as RefStorage
+    from emergent_multiagent_strategies_amd.learner import BatchedLearner
+    T, P, nmb = 6, 5, 4                                      # batch 30, minibatches of 7, 7, 7, 7, 2 (drop_last=False)
+    st = RefStorage(T, P, (6,), None, 1)
+    st.obs[:-1, :, 0] = torch.arange(T * P, dtype=torch.float32).view(T, P)
+    adv = [torch.zeros(T, P, 1)]
+    torch.manual_seed(123)
+    want = [[b[0][:, 0].long() for b in magent_feed_forward_generator([st], [st], adv, nmb)] for _ in range(3)]
+    L = BatchedLearner.__new__(BatchedLearner)               # the sampler needs T, E, num_mini_batch and a device only
+    L.T, L.E, L.num_mini_batch, L.device = T, P, nmb, torch.device("cpu")
+    torch.manual_seed(123)
+    sampler = L._reference_sampler()
+    got = [sampler(ep) for ep in range(3)]
+    assert [len(e) for e in got] == [len(e) for e in want] == [5, 5, 5]
+    for ge, we in zip(got, want):
+        for g, w in zip(ge, we):
+            assert torch.equal(g, w)

@@ -41,6 +41,9 @@ def get_args():
     p.add_argument("--clip-param", type=float, default=0.2)
     p.add_argument("--no-clipped-value-loss", action="store_true")
     p.add_argument("--save-dir", default="tmp")
+    p.add_argument("--reference-sampling", action="store_true",
+                   help="draw the PPO minibatches as the reference does (torch.randperm on the CPU generator per epoch and team, "
+                        "rlcore/algo/ppo.py:213) instead of on the device")
     p.add_argument("--save-interval", type=int, default=10)
     p.add_argument("--log-interval", type=int, default=1)
     p.add_argument("--continue-training", action="store_true")
@@ -73,7 +76,7 @@ def main():
                           value_loss_coef=args.value_loss_coef, entropy_coef=args.entropy_coef,
                           max_grad_norm=args.max_grad_norm, gamma=args.gamma, tau=args.tau,
                           clipped_value_loss=not args.no_clipped_value_loss, use_graph=not args.no_graph,
-                          sample_seed=args.seed + 1)
+                          sample_seed=args.seed + 1, reference_sampling=args.reference_sampling)
     # Action sampling (fused policy kernel): Philox keyed by (sample_seed; rollout counter, step, GLOBAL env index,
     # agent) -- the same seed on every rank, the env index makes the shards differ.  torch's generator only draws
     # the minibatch permutations (and the samples of the PyTorch policy fallback): different per rank.
