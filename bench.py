@@ -497,6 +497,7 @@ def main():
     # a default 3v3 run on one GPU also carries the 5v5 shapes one GPU can run (BASELINE config 5's per-GPU shape)
     extra = {}
     if world == 1 and (G, A) == (3, 3) and not args.no_5v5:
+        extra["single_env_facade"] = facade_record(fa, G, A, dev)
         extra["fused_5v5"] = fused_record(fa, 5, 5, E, T, dev)
         if not args.no_closed_loop:
             extra["closed_loop_5v5"] = closed_loop(fa, args, rank, local_rank, world, dev, barrier, G=5, A=5, rollouts=10, updates=2)
@@ -710,6 +711,29 @@ def closed_loop(fa, args, rank, local_rank, world, dev, barrier, G=None, A=None,
     del L, eng
     torch.cuda.empty_cache()
     return rec
+
+
+def facade_record(fa, G, A, dev, steps=400):
+    """The single-env façade (make_fortattack_env: the reference's surface over the same GPU engine with E = 1, one launch and
+    one host synchronisation per env.step) -- what a reference script gets when it runs unmodified: env-steps/s."""
+    import numpy as np
+    env = fa.make_fortattack_env(100, num_guards=G, num_attackers=A, seed=0, device=dev.index)
+    env.reset()
+    rng = np.random.RandomState(0)
+    acts = rng.randint(0, 8, size=(steps + 20, G + A))
+    for k in range(20):
+        if env.step(acts[k])[2]:
+            env.reset()
+    t0 = time.perf_counter()
+    for k in range(20, steps + 20):
+        if env.step(acts[k])[2]:
+            env.reset()
+    sec = time.perf_counter() - t0
+    env.close()
+    return {"workload": "make_fortattack_env(...).step on one env (%dv%d), E = 1 on the GPU, numpy in / numpy out, %d steps incl. the "
+                        "resets they trigger" % (G, A, steps), "env_steps_per_s": steps / sec, "us_per_step": sec / steps * 1e6,
+            "reference_python_env_steps_per_s": 2580, "note": "latency-bound by design (a launch + a sync + four small copies per "
+            "step); the batched engine is the product path"}
 
 
 def fused_record(fa, G, A, E, T, dev, iters=200):
