@@ -19,11 +19,14 @@ def fa():
 # largest deviations of the policy-side rows (fused kernel vs the PyTorch module) seen by _check_rollout_against_oracle in this
 # process: value rows relative to max(1, max |V|), log-prob rows absolute.  tools/soak_closed_loop.py reports them.
 POLICY_ROW_DEVIATION = {"value_rel": 0.0, "logp_abs": 0.0}
-# Bounds = 10 x the largest deviation recorded over the training soaks (profiles/r04_soak_closed_loop.jsonl, 80 iterations at
-# 3v3 and 20 at 5v5 with tools/soak_closed_loop.py ... measure): values 1.6e-5 relative while the critic grows to |V| ~ 100,
-# log-probs 2.3e-5 absolute -- float32 with the folded algebra (A = norm W_q W_k^T etc. multiplied out once per update) against
-# the module's unfolded float32.  (Round 3 allowed 1e-4 relative / 1e-4 without a record of what was observed.)
-VALUE_REL_TOL, LOGP_ABS_TOL = 1.6e-4, 2.3e-4
+# Bounds from the training soaks of profiles/r04_soak_closed_loop.jsonl (tools/soak_closed_loop.py: 80 iterations at 3v3 and
+# 20 at 5v5, twice -- with round 3's update kernels in `measure` mode, and with round 4's with these bounds asserted).  Largest
+# deviations seen: values 3.9e-5 relative (5v5; 1.5e-5 at 3v3 while the critic grows to |V| ~ 100), log-probs 1.4e-4 absolute
+# (3v3 at entropy 0.7, where the logits have grown; 2.3e-5 / 2.9e-5 in the other three runs) -- float32 with the folded
+# algebra (A = norm W_q W_k^T etc. multiplied out once per update) against the module's unfolded float32; they depend on
+# the trajectory the training takes.  Bounds = 5 x / 4 x the largest.  (Round 3 allowed 1e-4 relative / 1e-4 absolute
+# without a record of what was observed.)
+VALUE_REL_TOL, LOGP_ABS_TOL = 2e-4, 6e-4
 
 
 def _check_rollout_against_oracle(fa, learner, orc, first):
