@@ -372,17 +372,17 @@ def main():
         else:
             eng.collect_rollout(0, T)
 
-    # The collector tail of rollout k: the GAE scan, the one-pass advantage moments, (several ranks: the all-gather of the
-    # N x 3 moments and the exact merge,) the normalisation -- all on the launch stream.  --two-stream-tail (experiment) moves
-    # everything behind the GAE scan to a second stream, under rollout k + 1: those kernels read returns / value_preds only,
-    # which no rollout touches, and the next GAE pass, which rewrites `returns`, waits for them.
+    # The collector tail of rollout k on the launch stream.  One rank: fa_gae_normalize -- the GAE scan that also leaves the
+    # one-pass advantage moments, then the fold + normalisation (two launches).  Several ranks: fa_gae_moments (scan + fold),
+    # the all-gather of the N x 3 moments, the exact merge, the normalisation.  --two-stream-tail (experiment) moves everything
+    # behind the scan + fold to a second stream, under rollout k + 1: those kernels read returns / value_preds only, which no
+    # rollout touches, and the next scan, which rewrites `returns`, waits for them.
     main_stream = torch.cuda.current_stream()
     tail_stream = torch.cuda.Stream() if args.two_stream_tail else None
     pending = {"tail_done": None}
     gather_buf = torch.zeros((world, N, 3), dtype=torch.float64, device=dev) if exchanging else None
 
-    def statistics_and_normalise():
-        mom, mean, std = eng.adv_moments_onepass()                 # this rank's (n, mean, M2), mean, std per agent
+    def exchange_and_normalise(mom, mean, std):
         if exchanging:
             dist.all_gather_into_tensor(gather_buf.view(-1), mom.view(-1))   # the path's one collective (RCCL / xGMI)
             mean, std = eng.adv_merge(gather_buf)                  # Chan-Golub-LeVeque in rank order: same bits on every rank
@@ -391,15 +391,18 @@ def main():
     def collector_tail():
         if pending["tail_done"] is not None:
             main_stream.wait_event(pending["tail_done"])           # the previous statistics / normalisation have read `returns`
-        eng.gae(0.99, 0.95)
+        if not exchanging and tail_stream is None:
+            eng.gae_normalize(0.99, 0.95, out=adv)                 # one rank: scan + moment partials, fold + normalisation
+            return
+        mom, mean, std = eng.gae_moments(0.99, 0.95)               # scan + moment partials, fold: this rank's (n, mean, M2)
         if tail_stream is None:
-            statistics_and_normalise()
+            exchange_and_normalise(mom, mean, std)
             return
         ready = torch.cuda.Event()
         ready.record(main_stream)
         with torch.cuda.stream(tail_stream):
             tail_stream.wait_event(ready)
-            statistics_and_normalise()
+            exchange_and_normalise(mom, mean, std)
             done = torch.cuda.Event()
             done.record(tail_stream)
         pending["tail_done"] = done
@@ -519,8 +522,8 @@ def main():
                                 "fa_step fused over the rollout in one launch" if graph is None else
                                 "one fa_step launch per env-step replayed from a hipGraph",
                                 "step kernel only" if args.no_collector else
-                                "+ fused RolloutStorage write, GAE scan, one-pass fp64 advantage moments "
-                                "(all-gather of N x 3 f64 when n_gpus > 1) and normalisation" + (
+                                "+ fused RolloutStorage write, GAE scan with the one-pass fp64 advantage moments, fold "
+                                "(all-gather of N x 3 f64 + merge when n_gpus > 1) and normalisation" + (
                                     "" if tail_stream is None else "; --two-stream-tail: the moments / exchange / normalisation of a rollout run "
                                     "on a second stream under the next rollout (the next GAE pass waits for them)")),
                 "envs_per_gpu": E, "rollout_steps": T, "num_guards": G, "num_attackers": A,
@@ -737,9 +740,9 @@ def facade_record(fa, G, A, dev, steps=400):
 
 
 def fused_record(fa, G, A, E, T, dev, iters=200):
-    """The headline workload (fused rollout launch + GAE + one-pass moments + normalisation) at another team size, one GPU."""
+    """The headline workload (fused rollout launch + GAE with the one-pass moments + fold and normalisation) at another team
+    size, one GPU."""
     import torch
-    from emergent_multiagent_strategies_amd.dist import gae_adv_mean_std
     N = G + A
     eng = fa.BatchedFortAttack(E, G, A, 100, base_seed=0, device=dev.index, track_counters=True)
     st = fa.JointRolloutStorage(T, E, N, device=dev)
@@ -752,8 +755,7 @@ def fused_record(fa, G, A, E, T, dev, iters=200):
 
     def hot():
         eng.collect_rollout(0, T)
-        mean, std = gae_adv_mean_std(eng, 0.99, 0.95)
-        eng.adv_normalize(mean, std, out=adv)
+        eng.gae_normalize(0.99, 0.95, out=adv)
 
     for _ in range(5):
         hot()
@@ -764,14 +766,13 @@ def fused_record(fa, G, A, E, T, dev, iters=200):
         ev[k][0].record()
         eng.collect_rollout(0, T)
         ev[k][1].record()
-        mean, std = gae_adv_mean_std(eng, 0.99, 0.95)
-        eng.adv_normalize(mean, std, out=adv)
+        eng.gae_normalize(0.99, 0.95, out=adv)
     torch.cuda.synchronize()
     sec = (time.perf_counter() - t0) / iters
     launch_s = sum(a.elapsed_time(b) for a, b in ev) / iters * 1e-3
     gbps = algorithmic_bytes_per_env_step(N) * E * T / launch_s / 1e9
-    rec = {"workload": "FortAttack %dv%d, %d envs, %d-step rollout, open-loop uniform-random actions: fused launch + GAE + "
-                       "one-pass moments + normalisation" % (G, A, E, T),
+    rec = {"workload": "FortAttack %dv%d, %d envs, %d-step rollout, open-loop uniform-random actions: fused launch + GAE with the "
+                       "one-pass moments + fold and normalisation" % (G, A, E, T),
            "value": E * T / sec, "unit": "env-steps/s", "ms_per_step": sec * 1e3, "steps": iters,
            "roofline": {"bound": "hbm", "kernel": eng.step_variant(T) + "<%d,%d>" % (G, A), "achieved": gbps, "peak": HBM_PEAK_GBPS,
                         "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS, "avg_launch_us": launch_s * 1e6,

@@ -89,6 +89,7 @@ EXPORTS = {
     "fa_collect_reset": (C.c_int, [c_p, c_p]),
     "fa_gae": (C.c_int, [c_p, C.c_double, C.c_double, c_p]),
     "fa_gae_moments": (C.c_int, [c_p, C.c_double, C.c_double, c_p, c_p, c_p, c_p]),
+    "fa_gae_normalize": (C.c_int, [c_p, C.c_double, C.c_double, c_p, c_p, c_p, c_p, c_p]),
     "fa_adv_moments_onepass": (C.c_int, [c_p, c_p, c_p, c_p, c_p]),
     "fa_adv_stats": (C.c_int, [c_p, C.c_int32, c_p, c_p, c_p]),
     "fa_adv_mean_std": (C.c_int, [c_p, c_p, c_p, c_p]),

@@ -2,6 +2,7 @@
 // Owns the fp64 SoA world state + RNG state in HBM; everything else belongs to the caller.
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -20,6 +21,17 @@ hipError_t fa_launch_selftest(unsigned long long n_per_thread, unsigned long lon
                               hipStream_t st);
 hipError_t fa_launch_gae(const float *rewards, const float *value_preds, const float *masks, float *returns,
                          const uint8_t *done, int T, int E, int N, double gamma, double tau, hipStream_t st);
+int fa_gae_mom_blocks(const float *rewards, const float *value_preds, const float *masks, const float *returns, int T, int E,
+                      int N, long long partial_cap);
+hipError_t fa_launch_gae_mom(const float *rewards, const float *value_preds, const float *masks, float *returns,
+                             const uint8_t *done, int T, int E, int N, double gamma, double tau, double *partial, int nblocks,
+                             hipStream_t st);
+hipError_t fa_launch_gae_mom_final(const double *partial, int nblocks, const float *rewards, const float *value_preds,
+                                   const float *masks, int T, int E, int N, double gamma, double *moments_out, double *mean_out,
+                                   double *std_out, hipStream_t st);
+hipError_t fa_launch_gae_mom_norm(const double *partial, int nblocks, const float *rewards, const float *value_preds,
+                                  const float *masks, const float *returns, int T, int E, int N, double gamma, float *out,
+                                  double *moments_out, double *mean_out, double *std_out, int grid, hipStream_t st);
 hipError_t fa_launch_adv_onepass(const float *returns, const float *value_preds, long long rows, int N, double *partial,
                                  int nblocks, double *moments_out, double *mean_out, double *std_out, hipStream_t st);
 hipError_t fa_launch_adv_stats(int pass, const float *returns, const float *value_preds, const double *mean,
@@ -248,7 +260,7 @@ int fa_create(const fa_config *cfg, fa_env **out) {
     const size_t o_epr = carve(2 * EN * sizeof(double));
     const size_t o_ale = carve(EN * sizeof(uint32_t));
     const size_t o_adv = carve((size_t)env->adv_blocks * FA_MAX_AGENTS * 2 * sizeof(double));
-    const size_t o_advs = carve((size_t)FA_MAX_AGENTS * 4 * sizeof(double));
+    const size_t o_advs = carve((size_t)FA_MAX_AGENTS * 5 * sizeof(double)); // stats (3) + mean + std scratch
     const bool fused_ok = cfg->num_guards <= FA_POLICY_MAX_TEAM && cfg->num_attackers <= FA_POLICY_MAX_TEAM;
     // sized for the smallest tile the policy kernel may choose (64 rows), slots counted at the largest (96)
     const int n_max = cfg->num_guards > cfg->num_attackers ? cfg->num_guards : cfg->num_attackers;
@@ -422,6 +434,16 @@ int fa_gae(fa_env *env, double gamma, double tau, void *stream) {
     return FA_OK;
 }
 
+// the fused scan's workgroup count for this handle's storage, 0 where the separate kernels serve (see fa_gae_mom_blocks;
+// FA_GAE_MOMENTS_SEPARATE=1 in the environment forces them: the A/B switch of tools/ab_tail.py)
+static int gae_mom_blocks(const fa_env *env) {
+    static const bool separate = [] { const char *v = getenv("FA_GAE_MOMENTS_SEPARATE"); return v && v[0] == '1'; }();
+    if (separate) return 0;
+    const fa_storage &st = env->st;
+    return fa_gae_mom_blocks(st.rewards, st.value_preds, st.masks, st.returns, st.num_steps, env->cfg.num_envs, env->N,
+                             (long long)env->adv_blocks * FA_MAX_AGENTS * 2);
+}
+
 int fa_gae_moments(fa_env *env, double gamma, double tau, double *moments_out, double *mean_out, double *std_out,
                    void *stream) {
     if (!env) return fail(FA_ERR_INVALID, "fa_gae_moments: null env");
@@ -429,6 +451,14 @@ int fa_gae_moments(fa_env *env, double gamma, double tau, double *moments_out, d
     DeviceGuard guard(env->cfg.device_id);
     const fa_storage &st = env->st;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (const int nb = gae_mom_blocks(env)) {
+        // two launches: the scan leaves the workgroups' moment partials, one workgroup folds them
+        FA_HIP(fa_launch_gae_mom(st.rewards, st.value_preds, st.masks, st.returns, st.done, st.num_steps, env->cfg.num_envs,
+                                 env->N, gamma, tau, env->adv_partial, nb, s));
+        FA_HIP(fa_launch_gae_mom_final(env->adv_partial, nb, st.rewards, st.value_preds, st.masks, st.num_steps,
+                                       env->cfg.num_envs, env->N, gamma, moments_out, mean_out, std_out, s));
+        return FA_OK;
+    }
     FA_HIP(fa_launch_gae(st.rewards, st.value_preds, st.masks, st.returns, st.done, st.num_steps,
                          env->cfg.num_envs, env->N, gamma, tau, s));
     const long long rows = (long long)st.num_steps * env->cfg.num_envs;
@@ -438,6 +468,30 @@ int fa_gae_moments(fa_env *env, double gamma, double tau, double *moments_out, d
     FA_HIP(fa_launch_adv_onepass(st.returns, st.value_preds, rows, env->N, env->adv_partial, nblocks, moments_out,
                                  mean_out, std_out, s));
     return FA_OK;
+}
+
+int fa_gae_normalize(fa_env *env, double gamma, double tau, float *adv_out, double *moments_out, double *mean_out,
+                     double *std_out, void *stream) {
+    if (!env || !adv_out) return fail(FA_ERR_INVALID, "fa_gae_normalize: null argument");
+    if (!env->bound) return fail(FA_ERR_STATE, "fa_gae_normalize: no storage bound");
+    DeviceGuard guard(env->cfg.device_id);
+    const fa_storage &st = env->st;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (const int nb = gae_mom_blocks(env)) {
+        // two launches: scan + moment partials; fold + normalisation by every workgroup
+        FA_HIP(fa_launch_gae_mom(st.rewards, st.value_preds, st.masks, st.returns, st.done, st.num_steps, env->cfg.num_envs,
+                                 env->N, gamma, tau, env->adv_partial, nb, s));
+        FA_HIP(fa_launch_gae_mom_norm(env->adv_partial, nb, st.rewards, st.value_preds, st.masks, st.returns, st.num_steps,
+                                      env->cfg.num_envs, env->N, gamma, adv_out, moments_out, mean_out, std_out, 0, s));
+        return FA_OK;
+    }
+    // the separate kernels: the normalisation needs mean / std on the device, in the handle's scratch when the caller
+    // asked for neither
+    double *mean = mean_out ? mean_out : env->adv_stats + 3 * FA_MAX_AGENTS;
+    double *sd = std_out ? std_out : env->adv_stats + 4 * FA_MAX_AGENTS;
+    const int rc = fa_gae_moments(env, gamma, tau, moments_out, mean, sd, stream);
+    if (rc != FA_OK) return rc;
+    return fa_adv_normalize(env, mean, sd, adv_out, stream);
 }
 
 int fa_adv_moments_onepass(fa_env *env, double *moments_out, double *mean_out, double *std_out, void *stream) {

@@ -79,7 +79,10 @@ __global__ __launch_bounds__(64) void fa_gae_kernel(const float *__restrict__ re
 // it at ~3 TB/s.  Here a workgroup of four waves shares 64 columns: waves 1..3 stream rewards /
 // value_preds / masks + done flags a 32-step chunk ahead into LDS (each with its own queue), wave 0
 // scans the previous chunk out of LDS and stores the returns.  Same arithmetic, same order.
-// (Keeping two chunks in flight per loader -- two register sets -- measured 3x slower.)
+// (Two chunks in flight per loader: 3x slower through __syncthreads() in round 2 -- its fence drains
+// vmcnt -- and still 18.8 us against 16.0 with raw barriers and statically named register sets in
+// round 4: at 3.5 TB/s this access pattern -- 256-byte pieces of 32 rows 96 KB apart per wave -- has
+// the memory system saturated, more requests in flight only queue longer.)
 #define FA_GAEC_CHUNK 32
 __global__ __launch_bounds__(256) void fa_gae_coop_kernel(const float *__restrict__ rewards,
                                                           const float *__restrict__ value_preds,
@@ -162,6 +165,318 @@ __global__ __launch_bounds__(256) void fa_gae_coop_kernel(const float *__restric
             }
         }
         __syncthreads();
+    }
+}
+
+
+// ---- the collector tail in two launches: GAE + advantage moments, fold + normalisation --------------
+// fa_gae_mom_kernel = the cooperative scan whose scanning wave also leaves the workgroup's one-pass
+// advantage moments (ppo.py:121-123): S = sum(A - P), Q = sum((A - P)^2) per agent in fp64, with
+// A = returns[t] - value_preds[t] taken in float32 from the value the scan is about to store -- the
+// returns / value_preds re-read of fa_adv_onepass_vec_kernel and its launch disappear.  The entries at
+// the episode ends are left stale by the scan (storage.py:59-66 never visits them) but belong to the
+// statistics: their OLD returns (and value_preds) are gathered sparsely by the scanning wave behind the
+// chunk's scan, FA_GAEC_GATHER per lane and trip -- the wave is ahead of the loaders, the round trip hides
+// behind the next barrier.  (A dense prefetch of the old returns costs the 12.6 MB it reads: 21 us against
+// 15.4 for the plain scan; round 4's first attempt, a fifth wave + the sums inside the scan loop, 29 us;
+// the done flags requested by the scanning wave itself instead of a loader: 19.5 us -- a wave that stores
+// should not also wait for loads, the counter is one.)  The workgroup barrier is a raw s_barrier behind an
+// LDS wait, not __syncthreads(): the scanning wave's stores and gathers stay in flight across it.  Rows are
+// addressed through buffer descriptors (scalar row offset + the lane's 32-bit byte offset).
+// Pivot P_i: agent i's first GAE term of env 0, from the inputs alone, so that every workgroup and the
+// fold agree on it without a grid-wide exchange (any sample-sized value does: it only keeps S*S/n from
+// cancelling against Q).
+#define FA_GAEC_GATHER 4
+// the workgroup barrier between chunks: LDS traffic complete, then s_barrier.  NOT __syncthreads(): its fence also
+// waits for every global load and store in flight (vmcnt(0)) -- the loaders' next chunks and the scanning wave's
+// stores -- which is what pinned the first form of this kernel to one chunk in flight and a store drain per chunk.
+#define FA_GAEC_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+__device__ __forceinline__ float fa_gae_pivot(const float *__restrict__ rewards, const float *__restrict__ value_preds,
+                                              const float *__restrict__ masks, int T, long long EN, int i, float g32) {
+    const long long o = (long long)(T - 1) * EN + i, o1 = (long long)T * EN + i;
+    const float vp = value_preds[o];
+    const float delta = rewards[o] + g32 * value_preds[o1] * masks[o1] - vp;
+    return (delta + vp) - vp;
+}
+
+__global__ __launch_bounds__(256, 2) void fa_gae_mom_kernel(const float *__restrict__ rewards,
+                                                             const float *__restrict__ value_preds,
+                                                             const float *__restrict__ masks, float *__restrict__ returns,
+                                                             const uint8_t *__restrict__ done, int T, int E, int N, float g32,
+                                                             float gt32, double *__restrict__ partial) {
+    __shared__ float s_x[3][2][FA_GAEC_CHUNK][64]; // [rewards, value_preds, masks][chunk parity][step][column]
+    __shared__ uint8_t s_d[2][FA_GAEC_CHUNK][64];
+    __shared__ double s_sq[2][64];
+    const long long EN = (long long)E * N;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // wave: in a scalar register
+    const long long colv = (long long)blockIdx.x * 64 + lane;
+    const bool valid = colv < EN;
+    const long long col = valid ? colv : EN - 1; // idle lanes shadow the last column, store nothing
+    const int e = (int)(col / N);
+    const int nc = (T + FA_GAEC_CHUNK - 1) / FA_GAEC_CHUNK;
+    // chunk c holds steps t = T-1 - c*CHUNK - k, k = 0..CHUNK-1 (clamped loads below t = 0)
+    // Rows are addressed through buffer descriptors: a wave-uniform row offset in a scalar register + the lane's
+    // 32-bit byte offset.  (As 64-bit vector addresses the loads a loader keeps in flight cost it two registers each.)
+    // Offsets fit 32 bits: (T + 1) * EN * 4 < 2^31 on this path.
+    const unsigned rowb = (unsigned)EN * 4u;                                    // bytes per step of a (T, E, N) tensor
+    const unsigned coff = (unsigned)col * 4u;
+    const float *src = wave == 1 ? rewards : (wave == 2 ? value_preds : masks);
+    const __amdgpu_buffer_rsrc_t rs_src =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(src), 0, (int)((unsigned)(T + 1) * rowb), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_ret = __builtin_amdgcn_make_buffer_rsrc(returns, 0, (int)((unsigned)(T + 1) * rowb), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_val =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(value_preds), 0, (int)((unsigned)(T + 1) * rowb), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_done =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(done), 0, (int)((unsigned)T * (unsigned)E), 0x00020000);
+    auto ldf = [&](const __amdgpu_buffer_rsrc_t &rs, unsigned voff, unsigned soff) -> float {
+        // (readfirstlane: the row offset IS uniform, but computed with a vector clamp it gets a waterfall loop per load)
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)voff, __builtin_amdgcn_readfirstlane((int)soff), 0));
+    };
+    // a loader's chunk: 32 floats of its tensor; wave 3 also the 32 done flags of the lane's env
+    struct Chunk { float x[FA_GAEC_CHUNK]; uint8_t d[FA_GAEC_CHUNK]; };
+    auto issue = [&](Chunk &q, int c) {
+        const int t0 = T - 1 - c * FA_GAEC_CHUNK;
+#pragma unroll
+        for (int k = 0; k < FA_GAEC_CHUNK; ++k) {
+            const int t = t0 - k;
+            q.x[k] = ldf(rs_src, coff, (unsigned)(t >= 0 ? t : 0) * rowb);
+        }
+        if (wave == 3) {
+#pragma unroll
+            for (int k = 0; k < FA_GAEC_CHUNK; ++k) {
+                const int t = t0 - k;
+                q.d[k] = __builtin_amdgcn_raw_buffer_load_b8(rs_done, e, __builtin_amdgcn_readfirstlane((int)((unsigned)(t > 0 ? t - 1 : 0) * (unsigned)E)), 0);
+            }
+        }
+    };
+    auto stash = [&](const Chunk &q, int c) {
+        float(*dst)[64] = s_x[wave - 1][c & 1];
+#pragma unroll
+        for (int k = 0; k < FA_GAEC_CHUNK; ++k) dst[k][lane] = q.x[k];
+        if (wave == 3) {
+#pragma unroll
+            for (int k = 0; k < FA_GAEC_CHUNK; ++k) s_d[c & 1][k][lane] = q.d[k];
+        }
+    };
+    if (wave != 0) {
+        // ---- loaders (the two roles run their own copies of the chunk loop, each with its own barrier instructions:
+        // the counts match)
+        Chunk q;
+        issue(q, 0);
+        stash(q, 0);
+        FA_GAEC_BARRIER(); // chunk 0 is in LDS
+        for (int c = 0; c < nc; ++c) {
+            if (c + 1 < nc) {
+                issue(q, c + 1);
+                stash(q, c + 1);
+            }
+            FA_GAEC_BARRIER();
+        }
+    } else {
+        // ---- the scanning wave
+        float gae = 0.0f;
+        float v_next = value_preds[(long long)T * EN + col];
+        float m_next = masks[(long long)T * EN + col];
+        double accS[2] = {0.0, 0.0}, accQ[2] = {0.0, 0.0};
+        const double piv = (double)fa_gae_pivot(rewards, value_preds, masks, T, EN, (int)(col % N), g32);
+        auto add_stale = [&](float o, float v) {
+            const double dd = (double)(o - v) - piv;
+            accS[0] += dd;
+            accQ[0] = __fma_rn(dd, dd, accQ[0]);
+        };
+        FA_GAEC_BARRIER(); // chunk 0 is in LDS
+        auto scan_chunk = [&](int c) {
+            const int t0 = T - 1 - c * FA_GAEC_CHUNK, b = c & 1;
+            // the chunk comes out of LDS in one batch (a read per scan step would put an LDS round
+            // trip on every step of the chain)
+            float r[FA_GAEC_CHUNK], v[FA_GAEC_CHUNK], m[FA_GAEC_CHUNK];
+            uint8_t d[FA_GAEC_CHUNK];
+#pragma unroll
+            for (int k = 0; k < FA_GAEC_CHUNK; ++k) {
+                r[k] = s_x[0][b][k][lane]; v[k] = s_x[1][b][k][lane]; m[k] = s_x[2][b][k][lane]; d[k] = s_d[b][k][lane];
+            }
+            unsigned stale = 0u;
+#pragma unroll
+            for (int k = 0; k < FA_GAEC_CHUNK; ++k) {
+                const int t = t0 - k;
+                if (t >= 0) {
+                    const float delta = r[k] + g32 * v_next * m_next - v[k];
+                    const float g = delta + gt32 * m_next * gae;
+                    if ((t > 0) & (d[k] != 0)) {
+                        gae = 0.0f;
+                        stale |= 1u << k;
+                    } else {
+                        gae = g;
+                        const float ret = g + v[k];
+                        if (valid) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, ret), rs_ret, (int)coff, __builtin_amdgcn_readfirstlane((int)((unsigned)t * rowb)), 0);
+                        const double dd = (double)(ret - v[k]) - piv;
+                        accS[k & 1] += dd;
+                        accQ[k & 1] = __fma_rn(dd, dd, accQ[k & 1]);
+                    }
+                    v_next = v[k];
+                    m_next = m[k];
+                }
+            }
+            {
+                // the chunk's stale entries (a few per cent of all): old returns and value_preds straight from memory,
+                // FA_GAEC_GATHER per lane and trip -- the wave is ahead of the loaders, the round trip hides behind the
+                // next barrier
+                unsigned rem = stale;
+                while (__builtin_amdgcn_ballot_w64(rem != 0u) != 0ull) {
+                    float go[FA_GAEC_GATHER], gv[FA_GAEC_GATHER];
+                    unsigned gmask = 0u;
+#pragma unroll
+                    for (int j = 0; j < FA_GAEC_GATHER; ++j) {
+                        const int k = rem ? __builtin_ctz(rem) : 0;
+                        gmask |= (rem ? 1u : 0u) << j;
+                        rem &= rem - 1u;
+                        const unsigned o = (unsigned)(t0 - k) * rowb + coff; // t0 - k >= 1 for a stale k, t0 >= 0 otherwise
+                        go[j] = ldf(rs_ret, o, 0u);
+                        gv[j] = ldf(rs_val, o, 0u);
+                    }
+#pragma unroll
+                    for (int j = 0; j < FA_GAEC_GATHER; ++j)
+                        if ((gmask >> j) & 1u) add_stale(go[j], gv[j]);
+                }
+            }
+        };
+        for (int c = 0; c < nc; ++c) {
+            scan_chunk(c);
+            FA_GAEC_BARRIER();
+        }
+        s_sq[0][lane] = valid ? accS[0] + accS[1] : 0.0;
+        s_sq[1][lane] = valid ? accQ[0] + accQ[1] : 0.0;
+    }
+    {
+        __syncthreads();
+        // partial[block][agent] = {S, Q}: the lanes of an agent in ascending order
+        if ((int)threadIdx.x < 2 * N) {
+            const int i = threadIdx.x >> 1, cmp = threadIdx.x & 1;
+            const int first = (int)(((long long)blockIdx.x * 64) % N); // agent of lane 0
+            double acc = 0.0;
+            for (int l = (i - first + N) % N; l < 64; l += N) acc += s_sq[cmp][l];
+            partial[((long long)blockIdx.x * N + i) * 2 + cmp] = acc;
+        }
+    }
+}
+
+// One wave folds agent i's partials: lane l takes workgroups l, l + 64, ... in order (16-byte loads,
+// issued together), then a fixed shuffle tree; every lane returns the same (mean, M2).  Used by the
+// one-workgroup fold AND by every workgroup of the fused normalisation, so both produce the same bits.
+#define FA_GAEM_FOLD 8 // partial workgroups per lane: nblocks <= 64 * FA_GAEM_FOLD
+__device__ __forceinline__ void fa_gae_mom_fold(const double *__restrict__ partial, int nblocks, int N, int i, int lane,
+                                                double n_rows, double piv, double &mean, double &m2) {
+    const double2 *p2 = reinterpret_cast<const double2 *>(partial);
+    double2 p[FA_GAEM_FOLD];
+#pragma unroll
+    for (int k = 0; k < FA_GAEM_FOLD; ++k) {
+        const int b = lane + 64 * k;
+        p[k] = p2[(long long)(b < nblocks ? b : 0) * N + i];
+    }
+    double s = 0.0, q = 0.0;
+#pragma unroll
+    for (int k = 0; k < FA_GAEM_FOLD; ++k) {
+        const bool in = lane + 64 * k < nblocks;
+        s += in ? p[k].x : 0.0;
+        q += in ? p[k].y : 0.0;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { s += __shfl_down(s, off, 64); q += __shfl_down(q, off, 64); }
+    s = __shfl(s, 0, 64);
+    q = __shfl(q, 0, 64);
+    mean = piv + s / n_rows;
+    m2 = q - s * (s / n_rows);
+}
+
+__global__ void fa_gae_mom_final_kernel(const double *__restrict__ partial, int nblocks, int N,
+                                        const float *__restrict__ rewards, const float *__restrict__ value_preds,
+                                        const float *__restrict__ masks, int T, long long EN, float g32, double n_rows,
+                                        double *__restrict__ moments_out, double *__restrict__ mean_out,
+                                        double *__restrict__ std_out) {
+    const int i = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (i >= N) return;
+    const double piv = (double)fa_gae_pivot(rewards, value_preds, masks, T, EN, i, g32);
+    double mean, m2;
+    fa_gae_mom_fold(partial, nblocks, N, i, lane, n_rows, piv, mean, m2);
+    if (lane == 0) {
+        if (moments_out) { moments_out[i * 3 + 0] = n_rows; moments_out[i * 3 + 1] = mean; moments_out[i * 3 + 2] = m2; }
+        if (mean_out) mean_out[i] = mean;
+        if (std_out) std_out[i] = sqrt(m2 / (n_rows - 1.0));
+    }
+}
+
+// The fold and ppo.py:123 in one launch (one rank: nothing is exchanged between them): every workgroup
+// folds the partials itself -- one wave per agent, 6 KB per agent out of L2 at config 2 -- and normalises its
+// share of the advantages, 16 bytes per lane and trip, the first trip requested ahead of the fold.  (A - (float)mean) / ((float)std + 1e-5f) as fa_adv_norm_kernel; workgroup 0
+// also leaves moments / mean / std.  `total` = T*E*N.
+__global__ __launch_bounds__(512) void fa_gae_mom_norm_kernel(const double *__restrict__ partial, int nblocks, int N,
+                                                              const float *__restrict__ rewards,
+                                                              const float *__restrict__ value_preds,
+                                                              const float *__restrict__ masks,
+                                                              const float *__restrict__ returns, int T, long long EN, float g32,
+                                                              double n_rows, long long total, float *__restrict__ out,
+                                                              double *__restrict__ moments_out, double *__restrict__ mean_out,
+                                                              double *__restrict__ std_out) {
+    __shared__ float s_mean[FA_MAX_AGENTS_DEV], s_den[FA_MAX_AGENTS_DEV];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long quads = total / 4;
+    const bool vec = (((uintptr_t)returns | (uintptr_t)value_preds | (uintptr_t)out) & 15) == 0;
+    const float4 *r4 = reinterpret_cast<const float4 *>(returns), *v4 = reinterpret_cast<const float4 *>(value_preds);
+    // the lane's first trip is requested before the fold: its round trip and the fold's run side by side
+    float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), va = ra, rb = ra, vb = ra;
+    if (vec && gid < quads) {
+        const long long q1 = gid + stride;
+        ra = r4[gid]; va = v4[gid];
+        rb = r4[q1 < quads ? q1 : gid]; vb = v4[q1 < quads ? q1 : gid];
+    }
+    for (int i = wave; i < N; i += 8) { // eight waves: one agent each up to 4v4, one round trip
+        const double piv = (double)fa_gae_pivot(rewards, value_preds, masks, T, EN, i, g32);
+        double mean, m2;
+        fa_gae_mom_fold(partial, nblocks, N, i, lane, n_rows, piv, mean, m2);
+        const double sd = sqrt(m2 / (n_rows - 1.0));
+        if (lane == 0) {
+            s_mean[i] = (float)mean;
+            s_den[i] = (float)sd + 1e-5f;
+            if (blockIdx.x == 0) {
+                if (moments_out) { moments_out[i * 3 + 0] = n_rows; moments_out[i * 3 + 1] = mean; moments_out[i * 3 + 2] = m2; }
+                if (mean_out) mean_out[i] = mean;
+                if (std_out) std_out[i] = sd;
+            }
+        }
+    }
+    __syncthreads();
+    if (vec) {
+        float4 *o4 = reinterpret_cast<float4 *>(out);
+        for (long long q0 = gid; q0 < quads; q0 += 2 * stride) {
+            const long long q1 = q0 + stride;
+            const bool two = q1 < quads;
+            if (q0 != gid) {
+                ra = r4[q0]; va = v4[q0];
+                rb = r4[two ? q1 : q0]; vb = v4[two ? q1 : q0];
+            }
+            auto norm4 = [&](const float4 &r, const float4 &v, long long q) {
+                int i = (int)((4 * q) % N);
+                float4 o;
+                o.x = (r.x - v.x - s_mean[i]) / s_den[i]; i = i + 1 == N ? 0 : i + 1;
+                o.y = (r.y - v.y - s_mean[i]) / s_den[i]; i = i + 1 == N ? 0 : i + 1;
+                o.z = (r.z - v.z - s_mean[i]) / s_den[i]; i = i + 1 == N ? 0 : i + 1;
+                o.w = (r.w - v.w - s_mean[i]) / s_den[i];
+                return o;
+            };
+            o4[q0] = norm4(ra, va, q0);
+            if (two) o4[q1] = norm4(rb, vb, q1);
+        }
+        for (long long k = quads * 4 + gid; k < total; k += stride) {
+            const int i = (int)(k % N);
+            out[k] = (returns[k] - value_preds[k] - s_mean[i]) / s_den[i];
+        }
+    } else {
+        for (long long k = gid; k < total; k += stride) {
+            const int i = (int)(k % N);
+            out[k] = (returns[k] - value_preds[k] - s_mean[i]) / s_den[i];
+        }
     }
 }
 
@@ -552,6 +867,51 @@ hipError_t fa_launch_gae(const float *rewards, const float *value_preds, const f
         hipLaunchKernelGGL(fa_gae_kernel, dim3(grid), dim3(64), 0, st, rewards, value_preds, masks, returns,
                            done, T, E, N, (float)gamma, (float)(gamma * tau));
     }
+    return hipGetLastError();
+}
+
+// ---- GAE + moments (fa_gae_mom_kernel) and its two possible second launches ---------------------------
+// Eligible up to 512 workgroups = 32 768 (env, agent) columns -- two workgroups per CU.  (Beyond that a CU hosts three and
+// the scanning wave, which carries the fp64 sums and the gathers, falls behind its loaders: 41 us against 34 for the
+// separate kernels at 5v5 x 4096 and 3v3 x 8192; at 3v3 x 4096 / x 1024: 23.7 against 26.0 / 19.0 against 22.1.)  `partial`
+// (partial_cap doubles) holds a {S, Q} pair per (workgroup, agent).  Returns the number of workgroups or 0.
+int fa_gae_mom_blocks(const float *rewards, const float *value_preds, const float *masks, const float *returns, int T, int E,
+                      int N, long long partial_cap) {
+    const long long EN = (long long)E * N;
+    if (EN > 64LL * 512 || T < 1 || (long long)(T + 1) * EN * 4 >= (1LL << 31)) return 0;
+    const long long nb = (EN + 63) / 64;
+    if (nb > 64 * FA_GAEM_FOLD || nb * N * 2 > partial_cap) return 0;
+    return (int)nb;
+}
+hipError_t fa_launch_gae_mom(const float *rewards, const float *value_preds, const float *masks, float *returns,
+                             const uint8_t *done, int T, int E, int N, double gamma, double tau, double *partial, int nblocks,
+                             hipStream_t st) {
+    hipLaunchKernelGGL(fa_gae_mom_kernel, dim3(nblocks), dim3(256), 0, st, rewards, value_preds, masks, returns, done, T, E, N,
+                       (float)gamma, (float)(gamma * tau), partial);
+    return hipGetLastError();
+}
+hipError_t fa_launch_gae_mom_final(const double *partial, int nblocks, const float *rewards, const float *value_preds,
+                                   const float *masks, int T, int E, int N, double gamma, double *moments_out, double *mean_out,
+                                   double *std_out, hipStream_t st) {
+    const long long EN = (long long)E * N;
+    const double n_rows = (double)T * (double)E;
+    hipLaunchKernelGGL(fa_gae_mom_final_kernel, dim3(1), dim3(64 * N), 0, st, partial, nblocks, N, rewards, value_preds, masks, T,
+                       EN, (float)gamma, n_rows, moments_out, mean_out, std_out);
+    return hipGetLastError();
+}
+hipError_t fa_launch_gae_mom_norm(const double *partial, int nblocks, const float *rewards, const float *value_preds,
+                                  const float *masks, const float *returns, int T, int E, int N, double gamma, float *out,
+                                  double *moments_out, double *mean_out, double *std_out, int grid, hipStream_t st) {
+    const long long EN = (long long)E * N, total = (long long)T * EN;
+    const double n_rows = (double)T * (double)E;
+    if (grid <= 0) {
+        // a lane takes two 16-byte quads per trip; two workgroups of eight waves per CU (measured at config 2's 38 MB:
+        // 128 / 256 / 512 / 1024 workgroups -> 31.6 / 29.7 / 30.0 / 31.6 us for the two launches, 512 the best behind the rollout)
+        long long want = (total / 4 + 1023) / 1024;
+        grid = (int)(want < 512 ? (want < 1 ? 1 : want) : 512);
+    }
+    hipLaunchKernelGGL(fa_gae_mom_norm_kernel, dim3(grid), dim3(512), 0, st, partial, nblocks, N, rewards, value_preds, masks,
+                       returns, T, EN, (float)gamma, n_rows, total, out, moments_out, mean_out, std_out);
     return hipGetLastError();
 }
 

@@ -131,7 +131,7 @@ def adv_mean_std(eng, group=None):
 
 def gae_adv_mean_std(eng, gamma=0.99, tau=0.95, group=None, exchange=None):
     """compute_returns (GAE) + the global per-agent advantage mean / unbiased std in one pass over
-    the rollout buffers (fa_gae_moments: three launches); with several ranks additionally ONE all-gather
+    the rollout buffers (fa_gae_moments: two launches up to 32 768 columns); with several ranks additionally ONE all-gather
     of the local (N,3) moments and the exact merge kernel -- through torch.distributed, or inside the library
     when `exchange` is a LibraryExchange."""
     mom, mean, std = eng.gae_moments(gamma, tau)

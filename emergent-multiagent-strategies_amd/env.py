@@ -179,6 +179,20 @@ class BatchedFortAttack(object):
                                             _ptr(self._adv_ms[0]), _ptr(self._adv_ms[1]), _stream()), "fa_gae_moments")
         return self._gae_mom, self._adv_ms[0], self._adv_ms[1]
 
+    def gae_normalize(self, gamma=0.99, tau=0.95, out=None):
+        """fa_gae_normalize: the collector tail of one rank in two launches -- GAE + moment partials, fold + normalisation
+        (ppo.py:121-124).  Returns (adv (T, E, N, 1) float32, moments (N,3), mean (N,), std (N,)); == gae_moments() +
+        adv_normalize() bit for bit."""
+        if not hasattr(self, "_gae_mom"):
+            self._gae_mom = torch.zeros((self.N, 3), dtype=torch.float64, device=self.device)
+        if not hasattr(self, "_adv_ms"):
+            self._adv_ms = torch.zeros((2, self.N), dtype=torch.float64, device=self.device)
+        if out is None:
+            out = self._new((self.storage.num_steps, self.E, self.N, 1), torch.float32)
+        _lib.check(self._lib.fa_gae_normalize(self._h, float(gamma), float(tau), _ptr(out), _ptr(self._gae_mom),
+                                              _ptr(self._adv_ms[0]), _ptr(self._adv_ms[1]), _stream()), "fa_gae_normalize")
+        return out, self._gae_mom, self._adv_ms[0], self._adv_ms[1]
+
     def adv_moments_onepass(self):
         """fa_adv_moments_onepass: the statistics half of gae_moments alone (same buffers, same values), on the current stream."""
         if not hasattr(self, "_gae_mom"):

@@ -204,13 +204,23 @@ int fa_collect_reset(fa_env *env, void *stream);
  * value_preds[T] must hold V(obs[T]).  Reproduces quirk Q7 (returns[end_pt] not
  * recomputed) exactly. */
 int fa_gae(fa_env *env, double gamma, double tau, void *stream);
-/* fa_gae followed by the advantage statistics of ppo.py:121-123 in ONE pass over the buffers
- * (instead of the two passes + two folds of fa_adv_stats): per agent, fp64 sums of (A - P) and
- * (A - P)^2 around a pivot P that is an actual sample (no cancellation), folded over the
- * workgroups in a fixed order -- bitwise reproducible.  Three launches.  Writes
- * moments[i] = {n, mean, M2} (the fa_adv_moments / fa_adv_merge format), mean[i] and the unbiased
+/* fa_gae + the advantage statistics of ppo.py:121-123 (instead of the two passes + two folds of fa_adv_stats): per
+ * agent, fp64 sums of (A - P) and (A - P)^2 around a pivot P that is an actual sample (no cancellation), folded over the
+ * workgroups in a fixed order -- bitwise reproducible.  Up to 32 768 (env, agent) columns the scan itself leaves the
+ * sums (A = returns[t] - value_preds[t] in float32 from the value it is about to store; the stale entries at the
+ * episode ends from the old returns) and one workgroup folds them: two launches; beyond that fa_gae, a one-pass sweep
+ * and its fold.  Writes moments[i] = {n, mean, M2} (the fa_adv_moments / fa_adv_merge format), mean[i] and the unbiased
  * std[i] of THIS handle's samples; any of the three may be null.  Device pointers. */
 int fa_gae_moments(fa_env *env, double gamma, double tau, double *moments, double *mean, double *std_, void *stream);
+/* The whole collector tail of one rank -- Learner.wrap_horizon + compute_returns (learner.py:191-211, storage.py:59-66),
+ * the advantage statistics and the normalisation (A - mean) / (std + 1e-5) of rlcore/algo/ppo.py:121-124 -- in two
+ * launches: the scan of fa_gae_moments, then ONE kernel in which every workgroup folds the moment partials (same order,
+ * same bits everywhere) and normalises its share into adv_out, (T, E, N) float32; returns / value_preds are read once
+ * more, nothing else.  Equals fa_gae_moments + fa_adv_normalize bit for bit; moments / mean / std_ (may be null) as
+ * there.  With several ranks the statistics are exchanged between the two halves: fa_gae_moments, the all-gather,
+ * fa_adv_merge, fa_adv_normalize. */
+int fa_gae_normalize(fa_env *env, double gamma, double tau, float *adv_out, double *moments, double *mean, double *std_,
+                     void *stream);
 /* The second half of fa_gae_moments alone -- the one-pass per-agent advantage moments (n, mean, M2), mean and unbiased
  * std of ppo.py:121-123 from the bound storage's returns / value_preds -- for a caller that puts the statistics on
  * another stream than the GAE scan (they read returns / value_preds only; the next rollout does not touch those). */

@@ -256,3 +256,56 @@ def test_moments_and_merge_equal_global_two_pass(fa):
         assert abs(float(std[i]) - allp[:, :, i].std(ddof=1)) < 1e-12
     hm, hs = merge_moments(gathered)
     assert torch.allclose(hm, mean.cpu(), rtol=0, atol=1e-15) and torch.allclose(hs, std.cpu(), rtol=1e-15, atol=0)
+
+
+@pytest.mark.parametrize("E,G,A,T", [(4096, 3, 3, 128),          # the headline shape: fa_gae_mom_kernel, 384 workgroups, fold of 8
+                                     (300, 3, 3, 64), (64, 5, 5, 128),
+                                     (37, 2, 5, 33),             # ragged last workgroup, T*E*N not a multiple of 4
+                                     (5461, 3, 3, 24),           # 32 766 columns: the largest fused shape (512 workgroups, ragged)
+                                     (4096, 5, 5, 40),           # 40 960 columns: beyond the fused scan, the separate kernels
+                                     (32768, 3, 3, 24)])         # ... and fa_gae_kernel behind the same call
+def test_gae_normalize_equals_gae_moments_plus_normalize(fa, E, G, A, T):
+    """fa_gae_normalize (scan + moment partials, then fold + normalisation in every workgroup) == fa_gae_moments +
+    fa_adv_normalize bit for bit -- returns, moments, mean, std, normalised advantages -- and the numpy oracle's
+    normalised advantages (ppo.py:121-124) to 2e-6; the stale episode-end entries belong to the statistics."""
+    import collector_oracle as co
+    N = G + A
+    rng = np.random.RandomState(7 * E + T)
+    eng = fa.BatchedFortAttack(E, G, A, 50)
+    st = fa.JointRolloutStorage(T, E, N, device="cuda")
+    eng.bind_storage(st)
+    data = dict(rewards=rng.randn(T, E, N, 1).astype(np.float32),
+                value_preds=rng.randn(T + 1, E, N, 1).astype(np.float32),
+                masks=(rng.rand(T + 1, E, N, 1) > 0.2).astype(np.float32),
+                returns=(3.0 * rng.randn(T + 1, E, N, 1)).astype(np.float32),   # stale entries of the previous update (Q7)
+                done=(rng.rand(T, E) < 0.05).astype(np.uint8))
+
+    def load():
+        for k, v in data.items():
+            getattr(st, k).copy_(_t(v))
+
+    load()
+    mom_ref, mean_ref, std_ref = [x.clone() for x in eng.gae_moments(0.99, 0.95)]
+    ret_ref = st.returns.clone()
+    adv_ref = eng.adv_normalize(mean_ref, std_ref).clone()
+    load()
+    out = torch.full((T, E, N, 1), float("nan"), device="cuda")
+    adv, mom, mean, std = eng.gae_normalize(0.99, 0.95, out=out)
+    assert adv.data_ptr() == out.data_ptr()
+    assert torch.equal(st.returns, ret_ref)
+    assert torch.equal(mom, mom_ref) and torch.equal(mean, mean_ref) and torch.equal(std, std_ref)
+    assert torch.equal(adv, adv_ref)
+    # the oracle: GAE with the stale entries kept, then (A - mean) / (std + 1e-5) per agent
+    ep_start = np.zeros((T, E), bool)
+    ep_start[1:] = data["done"][:-1] != 0
+    want = data["returns"].copy()
+    a = adv.cpu().numpy()
+    for i in range(N):
+        co.gae_single_pass(data["rewards"][:, :, i], data["value_preds"][:, :, i], data["masks"][:, :, i], want[:, :, i],
+                           ep_start, 0.99, 0.95)
+        assert np.abs(a[:, :, i] - co.normalized_advantages(want[:, :, i], data["value_preds"][:, :, i])).max() < 2e-6
+    assert np.array_equal(ret_ref.cpu().numpy(), want)
+    assert int(ep_start.sum()) > 0
+    load()
+    adv2, _, _, _ = eng.gae_normalize(0.99, 0.95)
+    assert torch.equal(adv2, adv)                                              # run-to-run identical
