@@ -70,7 +70,7 @@ class StateHost(C.Structure):
 
 FA_RNG_MT19937, FA_RNG_PHILOX = 0, 1
 # fa_config.step_kernel (include/fortattack.h FA_KERNEL_*)
-STEP_KERNELS = {"auto": 0, "pipe": 1, "pipe3": 2, "waves1": 3, "waves2": 4, "waves3": 5, "pairs": 6}
+STEP_KERNELS = {"auto": 0, "pipe": 1, "pipe3": 2, "waves1": 3, "waves2": 4, "waves3": 5, "pairs": 6, "chain": 7}
 
 # every symbol include/fortattack.h declares
 EXPORTS = {

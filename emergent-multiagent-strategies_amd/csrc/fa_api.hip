@@ -223,7 +223,7 @@ int fa_create(const fa_config *cfg, fa_env **out) {
     if (cfg->max_time_steps < 1) return fail(FA_ERR_INVALID, "fa_create: max_time_steps must be >= 1");
     if (cfg->rng_mode != FA_RNG_MT19937 && cfg->rng_mode != FA_RNG_PHILOX)
         return fail(FA_ERR_INVALID, "fa_create: unknown rng_mode");
-    if (cfg->step_kernel < FA_KERNEL_AUTO || cfg->step_kernel > FA_KERNEL_PAIRS)
+    if (cfg->step_kernel < FA_KERNEL_AUTO || cfg->step_kernel > FA_KERNEL_CHAIN)
         return fail(FA_ERR_INVALID, "fa_create: unknown step_kernel");
     if (cfg->step_kernel != FA_KERNEL_AUTO && cfg->step_kernel != FA_KERNEL_WAVES1 &&
         !((cfg->num_guards == 3 && cfg->num_attackers == 3) || (cfg->num_guards == 5 && cfg->num_attackers == 5)))

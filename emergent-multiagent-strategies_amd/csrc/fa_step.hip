@@ -234,6 +234,9 @@ __device__ __forceinline__ void sincos_heading(double x, double &sn, double &cs)
 // only the band in between needs libm.
 // the libm band, kept out of line: it runs for ~1e-5 of contacts but would otherwise be
 // inlined (exp + log1p, twice) at every one of the ~10 call sites
+// (Taking exp(t) alone below t = -40 -- log1p of an x < 2^-57 is x itself -- is bit-identical on the device down to
+// exp(t) = 2^-1021 and to the reference's libm everywhere (tools/probes/band_probe.hip), and measured SLOWER: 150.9 against
+// 147.5 us per 128-step launch; the select keeps both results live across the call.)
 __device__ __attribute__((noinline)) double softplus_band(double t) {
     if (t == 0.0) return 0.0 + 0.693147180559945309417232121458176568; // NPY_LOGE2
     if (t < 0.0) return 0.0 + log1p(exp(t));
@@ -1734,6 +1737,608 @@ __global__ __launch_bounds__((NPW + 2) * FA_WAVE, MINW) void fa_step_pipe_kernel
     FA_PROBE_WAVE0_END(lane)
 }
 
+// ---- experiment (round 4, second structural one): ONE workgroup barrier per step ---------------------------------
+// The pipelined kernel's step is two phases closed by two barriers: [laser | pair forces | walls] -> B2 -> [force sum,
+// integrate, publish | rows] -> P, each phase headed by an LDS round trip and ended by ~250 cycles of barrier.  Here the
+// wave that owns the state ("chain wave") computes the first DF partner offsets of the soft contacts ITSELF, from
+// partner positions it read back from its own publish before the barrier (no LDS wait at the top of a step), and the
+// three helpers deliver what else the force sum needs -- wave 1 the laser masks, wave 2 decoded action + wall forces,
+// wave 3 the remaining partner offset(s) -- through LDS hand-offs closed by a tag word instead of a barrier: a helper
+// writes its data, then tag = step; the chain wave reads the tags FIRST and the data behind them in one burst (DS
+// operations of a wave execute in order, so a tag that reads `step` proves the data behind it is the step's) and
+// repeats the burst while a tag is stale.  The helpers then do what no next state waits for (next heading's sin/cos,
+// rewards + reset stream, observation / done / mask rows) and everybody meets at the one barrier P.  Same arithmetic in
+// the same order as the pipelined kernel: same bits.  Compile-time team sizes; the ensemble path's choice is not
+// interleaved (as in the pipelined kernel).
+// MEASURED (profiles/r04_experiments/step_one_barrier_chain.md): bit-exact on the first run, 151.5-153.0 us per 128-step
+// launch at 3v3 x 4096 against the pipelined kernel's 147.5 in the same run -- no gain: the step is still the chain
+// P -> [helper: LDS read + laser 1 000-1 160 cycles] -> hand-off -> [force sum, integrate, done, publish: 800] -> barrier
+// (366 with the LDS drain), the chain wave's own pair offsets (628) sit in the shadow of the laser.  FA_KERNEL_CHAIN,
+// never picked by AUTO.
+#ifndef FA_CHAIN_DF
+#define FA_CHAIN_DF 2        // partner offsets the chain wave computes itself (1: 157.9 us against 153.7)
+#endif
+#ifndef FA_CHAIN_TRIG_WAVE
+#define FA_CHAIN_TRIG_WAVE 1 // which helper makes the next heading's sin/cos: 1 (laser wave) or 3 (pair / rows wave: 163.0 us)
+#endif
+#ifndef FA_CHAIN_SLEEP
+#define FA_CHAIN_SLEEP 0     // s_sleep between two polls of the hand-off tags (0: none; 1 / 4: 153.7 / 157.0 us against 151.5)
+#endif
+template <int TG, int TA, bool COLLECT>
+__global__ __launch_bounds__(4 * FA_WAVE, 2) void fa_step_chain_kernel(FaStepArgs a) {
+    constexpr int G = TG, A = TA, N = TG + TA;
+    constexpr int NOFF = N / 2;                 // partner offsets that cover every unordered pair once
+    constexpr int DF = NOFF > FA_CHAIN_DF ? FA_CHAIN_DF : NOFF - 1; // offsets 1..DF: the chain wave; DF+1..NOFF: wave 3
+    constexpr int EPW = FA_WAVE / N;
+    const int lane = threadIdx.x & (FA_WAVE - 1);
+    const int wave_id = threadIdx.x / FA_WAVE;
+    const int slot = lane / N;
+    const int i = lane - slot * N;
+    const int gbase = slot * N;
+    const int e = blockIdx.x * EPW + slot;
+    if (!((slot < EPW) && (e < a.E))) return;
+    const bool is_att = i >= G;
+    const size_t idx = (size_t)e * N + i;
+    const size_t EN = (size_t)a.E * N;
+    constexpr unsigned long long grp_mask = (1ull << N) - 1ull;
+    const FaDerived &c = a.c;
+    const int ns = a.nsteps;
+
+    // buffer s & 1: state at the start of step s and the by-products of step s-1, published by the chain wave before P(s-1)
+    __shared__ double s_px[2][FA_WAVE], s_py[2][FA_WAVE], s_ang[2][FA_WAVE];
+    __shared__ double s_vx[2][FA_WAVE], s_vy[2][FA_WAVE], s_dd[2][FA_WAVE];
+    __shared__ unsigned long long s_mask[2][2];          // [0] alive at the step's start, [1] done of the step before
+    __shared__ double s_trig[2][2][FA_WAVE];             // [step parity][cos, sin][lane]: wave 1 writes and reads it
+    __shared__ int s_act[FA_ACT_BATCH][FA_WAVE];
+    // the hand-offs to the chain wave: written and re-read without a barrier in between.  NOT volatile -- the backend
+    // waits for every volatile LDS access on its own (lgkmcnt(0) each: 250 us) -- but fenced for the COMPILER by
+    // FA_ORDER(): data before tag on the writing side, tags before data on the reading side; the hardware keeps a wave's
+    // DS operations in order.
+    __shared__ unsigned long long s_las[2][4];  // [step parity][alive after the laser, hit, was hit]  (wave 1)
+    __shared__ double s_W[2][FA_WAVE], s_U[3][FA_WAVE];       // wall force, decoded action            (wave 2)
+    __shared__ double s_rp[2][FA_WAVE];                        // positions of the lane's next reset   (wave 2)
+    __shared__ double s_fmx[N][FA_WAVE], s_fmy[N][FA_WAVE];   // [partner j][lane]: pair force on the lane's agent
+    __shared__ int s_tag[4];                                   // [wave]: the step its hand-off is complete for
+#define FA_ORDER() asm volatile("" ::: "memory")
+
+    if (wave_id == 1) {
+        // ---- wave 1: the laser (core.py:254-302) of step s -> chain wave; then sin/cos of the heading of step s+1 ----
+        constexpr int KT = TG > TA ? TG : TA;
+        const int n_opp = is_att ? G : A, opp0 = is_att ? 0 : G;
+        const int team_idx = is_att ? i - G : i;
+        const unsigned opp_bits = is_att ? ((1u << G) - 1u) : (((1u << A) - 1u) << G);
+        int nh = 0, nwh = 0;
+        if (a.track_counters) { nh = a.s.num_hit[idx]; nwh = a.s.num_was_hit[idx]; }
+        double sn, cs, sn_g = 0.0, cs_g = 0.0, sn_a = 0.0, cs_a = 0.0;
+        sincos_heading(a.s.ang[idx], sn, cs);
+        if (ns > 1) { // headings after a reset (fortattack_env_v1.py:59)
+            sincos_heading(c.ang_guard, sn_g, cs_g);
+            sincos_heading(c.ang_attacker, sn_a, cs_a);
+        }
+        const double cs_ro = is_att ? cs_g : cs_a, sn_ro = is_att ? sn_g : sn_a;   // the opponents after a reset
+        s_trig[0][0][lane] = cs;
+        s_trig[0][1][lane] = sn;
+        double k_size = c.agent_size, k_far = c.shoot_far, k_chw = c.cos_hw, k_shw = c.sin_hw;
+        asm volatile("" : "+v"(k_size), "+v"(k_far), "+v"(k_chw), "+v"(k_shw));
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(nh), "+v"(nwh));
+        const unsigned long long lane0_m = FA_M_EQ_U(lane, 0);
+        FA_TICK_INIT
+        FA_WG_BARRIER(); // P(-1)
+        for (int s = 0; s < ns; ++s) {
+            const int b = s & 1;
+            FA_TICK(12)
+            const int act = s_act[s & (FA_ACT_BATCH - 1)][lane];
+            const unsigned long long alive0_m = s_mask[b][0];
+            const unsigned long long reset_prev_m = (s > 0 && a.auto_reset != 0) ? s_mask[b][1] : 0ull;
+            const double px = s_px[b][lane], py = s_py[b][lane], ang = s_ang[b][lane];
+            double oqx[KT], oqy[KT], ocs[KT], osn[KT];
+#pragma unroll
+            for (int k = 0; k < KT; ++k) {
+                const int j = gbase + opp0 + (k < n_opp ? k : 0);
+                oqx[k] = s_px[b][j]; oqy[k] = s_py[b][j];
+                ocs[k] = s_trig[b][0][j]; osn[k] = s_trig[b][1][j];
+            }
+            if (__builtin_expect(reset_prev_m != 0ull, 0)) { // the env was reset at the end of the step before
+                const bool rp = fa_lanes(reset_prev_m);
+#pragma unroll
+                for (int k = 0; k < KT; ++k) {
+                    ocs[k] = rp ? cs_ro : ocs[k];
+                    osn[k] = rp ? sn_ro : osn[k];
+                }
+                if (rp) { nh = 0; nwh = 0; }
+            }
+            const unsigned long long shooters_m = FA_M_EQ_U(act, 7) & alive0_m;
+            unsigned long long hb[KT];
+#pragma unroll
+            for (int k = 0; k < KT; ++k) hb[k] = 0ull;
+            int hit_cnt = 0, was_hit_cnt = 0;
+            if (shooters_m != 0ull) {
+                const unsigned gw_sh = (unsigned)(shooters_m >> gbase);
+#pragma unroll
+                for (int k = 0; k < KT; ++k) {
+                    const unsigned long long cand_m = (k < n_opp ? FA_M_NE_U(gw_sh & (1u << (opp0 + k)), 0) : 0ull) & alive0_m;
+                    double u, lhs, rhs;
+                    fa_wedge(k_size, k_chw, k_shw, px, py, oqx[k], oqy[k], ocs[k], osn[k], u, lhs, rhs);
+                    hb[k] = cand_m & FA_M_LE_D(u, k_far) & FA_M_LE_D(lhs, rhs);
+                }
+                int tix = team_idx;
+                asm volatile("" : "+v"(tix));
+                unsigned sel = (unsigned)(hb[0] >> gbase);
+#pragma unroll
+                for (int k = 1; k < KT; ++k) sel = (k == tix) ? (unsigned)(hb[k] >> gbase) : sel;
+                hit_cnt = __popc(sel & opp_bits);
+#pragma unroll
+                for (int k = 0; k < KT; ++k) was_hit_cnt += fa_lanes(hb[k]) ? 1 : 0;
+            }
+            unsigned long long was_hit_m = hb[0];
+#pragma unroll
+            for (int k = 1; k < KT; ++k) was_hit_m |= hb[k];
+            const unsigned long long hit_m = FA_M_NE_U(hit_cnt, 0) & shooters_m;
+            const unsigned long long alive1_m = alive0_m & ~was_hit_m;        // :293-302 one shot kills
+            if (fa_lanes(lane0_m)) {
+                s_las[b][0] = alive1_m;
+                s_las[b][1] = hit_m;
+                s_las[b][2] = was_hit_m;
+            }
+            FA_ORDER();
+            if (fa_lanes(lane0_m)) s_tag[1] = s;   // behind the data: in order
+            nh += hit_cnt;
+            nwh += was_hit_cnt; // one per shooter that hit (core.py:283)
+            FA_TICK(10)
+            // the heading of step s+1: it only changes by the action's rotation (core.py:336) or by a reset to a
+            // constant (handled above); a dead agent's value is never used
+            if (FA_CHAIN_TRIG_WAVE == 1 && s + 1 < ns) {
+                double rot = 0.0;
+                if (act == 5) rot = c.rot_pos;
+                if (act == 6) rot = c.rot_neg;
+                sincos_heading(ang + rot, sn, cs);
+                s_trig[(s + 1) & 1][0][lane] = cs;
+                s_trig[(s + 1) & 1][1][lane] = sn;
+            }
+            FA_TICK(11)
+            FA_WG_BARRIER(); // P(s)
+        }
+        FA_WG_BARRIER(); // (epilogues of the emitting waves)
+        FA_TICK_FLUSH(10, 13, 29)
+        if (a.track_counters) {
+            if (a.auto_reset != 0 && ((s_mask[ns & 1][1] >> lane) & 1ull)) { nh = 0; nwh = 0; }
+            a.s.num_hit[idx] = nh;
+            a.s.num_was_hit[idx] = nwh;
+        }
+        return;
+    }
+    if (wave_id == 2) {
+        // ---- wave 2: decoded action + wall forces of step s -> chain wave; owns the reset stream; then the rewards
+        // of step s-1 -----------------------------------------------------------------------------------------------
+        double prev = a.s.prev[idx], ep_rew = 0.0;
+        if (a.track_counters) ep_rew = a.s.ep_rew[idx];
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(prev), "+v"(ep_rew));
+        int act_prev = 0;
+        bool alive0_prev = false;
+        float *p_rew = a.rew32 ? a.rew32 + idx : nullptr;
+        long long row = (long long)idx;
+        double k_fort = c.fort_dim, k_03 = 0.3, k_10 = 10.0, k_3 = 3.0, k_01 = 0.1;
+        asm volatile("" : "+v"(p_rew), "+v"(row));
+        asm volatile("" : "+v"(k_fort), "+v"(k_03), "+v"(k_10), "+v"(k_3), "+v"(k_01));
+        // rewards of step se (called once per step, in order): laser masks in s_las[se & 1], done / door distance in
+        // buffer (se + 1) & 1
+        auto emit_rew = [&](int se) {
+            const int pl = se & 1, pb = (se + 1) & 1;
+            const unsigned long long m1 = s_las[pl][0];
+            const bool alive1 = (m1 >> lane) & 1ull;
+            const bool hit = (s_las[pl][1] >> lane) & 1ull;
+            const bool was_hit = (s_las[pl][2] >> lane) & 1ull;
+            const bool done = (s_mask[pb][1] >> lane) & 1ull;
+            const double dist_door = sqrt_rn(s_dd[pb][lane]);
+            const bool alive0 = alive0_prev;
+            const bool shoot = act_prev == 7;
+            const int n_alive_att = __popcll(((m1 >> gbase) & grp_mask) >> G);
+            const unsigned long long in_fort_b = fa_ballot(is_att && alive1 && dist_door < k_fort);
+            const bool any_in_fort = ((in_fort_b >> gbase) & grp_mask) != 0ull;
+            const bool just_died = alive0 && was_hit;
+            const bool rewarded = (alive1 || just_died);
+            const double rew = fa_reward(is_att, rewarded, prev, dist_door, shoot, hit, was_hit, n_alive_att, any_in_fort,
+                                         k_fort, k_03, k_10, k_3, k_01);
+            prev = rewarded ? dist_door : prev;
+            if (a.track_counters) {
+                ep_rew += alive0 ? rew : 0.0;
+                if (done) {
+                    a.s.ep_rew_sum[idx] += ep_rew;
+                    if (alive1) a.s.alive_end[idx] += 1u;
+                    ep_rew = 0.0;
+                }
+            }
+            if (COLLECT) {
+                *p_rew = (float)rew;
+            } else {
+                if (a.rew32) *p_rew = (float)rew;
+                if (a.rew64) a.rew64[row] = rew;
+                if (a.hit) a.hit[row] = hit ? 1 : 0;
+                if (a.was_hit) a.was_hit[row] = was_hit ? 1 : 0;
+            }
+            p_rew += EN; row += (long long)EN;
+        };
+        ResetDraw rdA = {}, rdB = {};
+        MtWords mw = {};
+        bool need_b = false;
+        auto wait_words = [&]() { if (a.rng_mode == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
+        {
+            rdA.base = a.rng_mode == 0 ? a.s.mt_pos[e] + 4 * i : (int)a.s.reset_count[e];
+            rdB.base = draw_next_base(a, rdA.base, i, N);
+            MtWords mwa = {}, mwb = {};
+            draw_load(a, e, rdA.base, mwa);
+            draw_load(a, e, rdB.base, mwb);
+            draw_load(a, e, draw_next_base(a, rdB.base, i, N), mw);
+            wait_words();
+            draw_eval(a, e, i, is_att, mwa, rdA);
+            draw_eval(a, e, i, is_att, mwb, rdB);
+            s_rp[0][lane] = rdA.px;
+            s_rp[1][lane] = rdA.py;
+        }
+        const unsigned long long lane0_m = FA_M_EQ_U(lane, 0);
+        FA_TICK_INIT
+        FA_WG_BARRIER(); // P(-1)
+        for (int s = 0; s < ns; ++s) {
+            const int b = s & 1;
+            FA_TICK(18)
+            if (s > 0 && a.auto_reset != 0) {
+                // envs that were reset at the end of step s-1 used draw A: commit it, promote B (ahead of this step's
+                // tag: the chain wave reads s_rp behind it); the new B is drawn after the hand-off
+                need_b = (s_mask[b][1] >> lane) & 1ull;
+                if (need_b) {
+                    draw_commit(a, e, i, N, rdA);
+                    rdA = rdB;
+                    s_rp[0][lane] = rdA.px;
+                    s_rp[1][lane] = rdA.py;
+                }
+            }
+            const int act = s_act[s & (FA_ACT_BATCH - 1)][lane];
+            const bool alive0 = (s_mask[b][0] >> lane) & 1ull;
+            double px = s_px[b][lane], py = s_py[b][lane];
+            asm volatile("" : "+v"(px), "+v"(py));
+            // fortattack.py:253-263,:289 _set_action (F starts as u + 0.0, core.py:221-228)
+            double u0 = 0.0, u1 = 0.0, rot = 0.0;
+            if (act == 1) u0 = +1.0;
+            if (act == 2) u0 = -1.0;
+            if (act == 3) u1 = +1.0;
+            if (act == 4) u1 = -1.0;
+            if (act == 5) rot = c.rot_pos;
+            if (act == 6) rot = c.rot_neg;
+            s_U[0][lane] = u0 * c.accel + 0.0;
+            s_U[1][lane] = u1 * c.accel + 0.0;
+            s_U[2][lane] = rot;
+            double wx = 0.0, wy = 0.0;
+            fa_wall_force_flat(c, px, py, wx, wy); // core.py:246-252 + :459-472
+            s_W[0][lane] = alive0 ? wx : 0.0;
+            s_W[1][lane] = alive0 ? wy : 0.0;
+            FA_ORDER();
+            if (fa_lanes(lane0_m)) s_tag[2] = s;   // behind the wave's data writes: in order
+            FA_ORDER();
+            FA_TICK(16)
+            if (need_b) {
+                wait_words();
+                rdB.base = draw_next_base(a, rdA.base, i, N);
+                draw_eval(a, e, i, is_att, mw, rdB);
+                draw_load(a, e, draw_next_base(a, rdB.base, i, N), mw);
+            }
+            need_b = false;
+            if (s > 0) emit_rew(s - 1);
+            act_prev = act;
+            alive0_prev = alive0;
+            FA_TICK(17)
+            FA_WG_BARRIER(); // P(s)
+        }
+        FA_WG_BARRIER(); // the chain wave has published the last step's by-products
+        FA_TICK_FLUSH(16, 19, 30)
+        if (a.auto_reset != 0 && ((s_mask[ns & 1][1] >> lane) & 1ull)) draw_commit(a, e, i, N, rdA);
+        emit_rew(ns - 1);
+        a.s.prev[idx] = prev;
+        if (a.track_counters) a.s.ep_rew[idx] = ep_rew;
+        return;
+    }
+    if (wave_id == 3) {
+        // ---- wave 3: the partner offsets DF+1..NOFF of the soft contacts of step s -> chain wave; then the observation,
+        // done and mask rows + episode bookkeeping of step s-1 ----------------------------------------------------
+        uint8_t *p_done = a.done ? a.done + e : nullptr;
+        float *p_mask = a.mask32 ? a.mask32 + idx : nullptr;
+        float *p_obs = a.obs32 ? a.obs32 + idx * 6 : nullptr;
+        long long row6 = (long long)idx * 6;
+        asm volatile("" : "+v"(p_done), "+v"(p_mask), "+v"(p_obs), "+v"(row6));
+        bool alive0_prev = false;
+        auto emit_obs = [&](int bo) { // the state after the step / reset (fortattack_env_v1.py:238)
+            const bool alive_new = (s_mask[bo][0] >> lane) & 1ull;
+            const double px = s_px[bo][lane], py = s_py[bo][lane], ang = s_ang[bo][lane];
+            const double vx = s_vx[bo][lane], vy = s_vy[bo][lane];
+            fa_store_obs((COLLECT || a.obs32) ? p_obs : nullptr, (!COLLECT && a.obs64) ? a.obs64 + row6 : nullptr, alive_new,
+                         px, py, ang, vx, vy);
+            p_obs += EN * 6; row6 += (long long)EN * 6;
+        };
+        auto emit_flags = [&](int se) { // done / mask rows and _get_done bookkeeping of step se (fortattack.py:202-225)
+            const int pl = se & 1, pb = (se + 1) & 1;
+            const unsigned long long m1 = s_las[pl][0];
+            const bool alive1 = (m1 >> lane) & 1ull;
+            const bool done = (s_mask[pb][1] >> lane) & 1ull;
+            const int n_alive_att = __popcll(((m1 >> gbase) & grp_mask) >> G);
+            const unsigned long long in_fort_b = fa_ballot(is_att && alive1 && s_dd[pb][lane] <= c.fort2_max);
+            const bool any_in_fort = ((in_fort_b >> gbase) & grp_mask) != 0ull;
+            if (i == 0) {
+                if (done) {
+                    const int which = any_in_fort ? 2 : (n_alive_att == 0 ? 0 : 1);
+                    uint8_t *gr = a.s.game_result + (size_t)e * 3;
+                    gr[0] = which == 0; gr[1] = which == 1; gr[2] = which == 2;
+                    atomicAdd(a.s.result_count + (size_t)e * 3 + which, 1u);
+                }
+                if (COLLECT || a.done) *p_done = done ? 1 : 0;
+            }
+            const float mk = (alive0_prev || (done && a.auto_reset != 0)) ? 1.0f : 0.0f;
+            if (COLLECT || a.mask32) *p_mask = mk;
+            p_mask += EN; p_done += a.E;
+        };
+        const unsigned long long lane0_m = FA_M_EQ_U(lane, 0);
+        FA_TICK_INIT
+        FA_WG_BARRIER(); // P(-1)
+        for (int s = 0; s < ns; ++s) {
+            const int b = s & 1;
+            FA_TICK(14)
+            const unsigned long long grp_alive0 = (s_mask[b][0] >> gbase) & grp_mask;
+            const bool alive0 = (grp_alive0 >> i) & 1ull;
+            const double px = s_px[b][lane], py = s_py[b][lane];
+            double qx[NOFF], qy[NOFF];
+#pragma unroll
+            for (int d = DF + 1; d <= NOFF; ++d) {
+                int j = i + d;
+                j = j >= N ? j - N : j;
+                qx[d - 1] = s_px[b][gbase + j];
+                qy[d - 1] = s_py[b][gbase + j];
+            }
+#pragma unroll
+            for (int d = DF + 1; d <= NOFF; ++d) {
+                int j = i + d;
+                j = j >= N ? j - N : j;
+                const bool mine = (2 * d != N) || (i < N / 2); // the half offset: one side only
+                const double dx = px - qx[d - 1], dy = py - qy[d - 1];
+                const double d2 = dx * dx + dy * dy;
+                double fxv = 0.0, fyv = 0.0;
+                bool near = false;
+                if (mine && alive0 && ((grp_alive0 >> j) & 1ull) && !(d2 > c.contact_skip_d2)) {
+                    fa_contact_force(c, dx, dy, d2, fxv, fyv);
+                    near = true;
+                }
+                if (mine) {
+                    s_fmx[j][lane] = fxv;               // on agent i from partner j
+                    s_fmy[j][lane] = fyv;
+                    s_fmx[i][gbase + j] = near ? -fxv : 0.0; // on agent j from partner i: the exact negative
+                    s_fmy[i][gbase + j] = near ? -fyv : 0.0;
+                }
+            }
+            FA_ORDER();
+            if (fa_lanes(lane0_m)) s_tag[3] = s;   // behind the wave's data writes: in order
+            FA_ORDER();
+            FA_TICK(8)
+            if (FA_CHAIN_TRIG_WAVE == 3 && s + 1 < ns) { // the heading of step s+1 (see wave 1)
+                const int act = s_act[s & (FA_ACT_BATCH - 1)][lane];
+                double rot = 0.0, sn, cs;
+                if (act == 5) rot = c.rot_pos;
+                if (act == 6) rot = c.rot_neg;
+                sincos_heading(s_ang[b][lane] + rot, sn, cs);
+                s_trig[(s + 1) & 1][0][lane] = cs;
+                s_trig[(s + 1) & 1][1][lane] = sn;
+            }
+            if (s > 0) {
+                emit_obs(b);
+                emit_flags(s - 1);
+            }
+            alive0_prev = alive0;
+            FA_TICK(9)
+            FA_WG_BARRIER(); // P(s)
+        }
+        FA_WG_BARRIER(); // the chain wave has published the last step's by-products
+        FA_TICK_FLUSH(8, 10, 31)
+        FA_TICK_FLUSH(14, 15, 27)
+        emit_obs(ns & 1);
+        emit_flags(ns - 1);
+        return;
+    }
+
+    // ---- wave 0: the chain ---------------------------------------------------------------------------------------
+    __builtin_amdgcn_s_setprio(3);
+    double px = a.s.px[idx], py = a.s.py[idx], vx = a.s.vx[idx], vy = a.s.vy[idx];
+    double ang = a.s.ang[idx];
+    unsigned long long alive_m = FA_M_NE_U(a.s.alive[idx], 0);
+    int t = a.s.tstep[e];
+    unsigned long long dirty_m = 0ull;
+    const unsigned long long is_att_m = FA_M_NE_U(is_att ? 1u : 0u, 0), lane0_m = FA_M_EQ_U(lane, 0);
+    const int64_t *act_ptr = a.actions + (int64_t)e * a.as_e + (int64_t)i * a.as_i;
+    int av[FA_ACT_BATCH];
+#pragma unroll
+    for (int k = 0; k < FA_ACT_BATCH; ++k) av[k] = (k < ns) ? (int)act_ptr[(int64_t)k * a.as_t] : 0;
+    constexpr unsigned grp_bits = (1u << N) - 1u;
+#pragma unroll
+    for (int k = 0; k < FA_ACT_BATCH; ++k) s_act[k][lane] = av[k];
+#pragma unroll
+    for (int k = 0; k < FA_ACT_BATCH; ++k)
+        av[k] = (FA_ACT_BATCH + k < ns) ? (int)act_ptr[(int64_t)(FA_ACT_BATCH + k) * a.as_t] : 0;
+    s_px[0][lane] = px;
+    s_py[0][lane] = py;
+    s_ang[0][lane] = ang;
+    if (fa_lanes(lane0_m)) {
+        s_mask[0][0] = alive_m;
+        s_mask[0][1] = 0ull;
+        s_tag[1] = -1; s_tag[2] = -1; s_tag[3] = -1;
+    }
+    s_fmx[i][lane] = 0.0; // an agent exerts no force on itself: nobody writes the diagonal
+    s_fmy[i][lane] = 0.0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    double qx[DF], qy[DF]; // the partners i+1 .. i+DF at the step's start: read back from this wave's own publish
+#pragma unroll
+    for (int d = 1; d <= DF; ++d) {
+        int j = i + d;
+        j = j >= N ? j - N : j;
+        qx[d - 1] = s_px[0][gbase + j];
+        qy[d - 1] = s_py[0][gbase + j];
+    }
+    FA_WG_BARRIER(); // P(-1)
+
+    double k_damp = c.one_minus_damping, k_dt = c.dt, k_sp2 = c.speed2_max, k_vmax = c.max_speed;
+    double k_doorx = c.door_x, k_doory = c.door_y, k_fort2 = c.fort2_max;
+    double k_ang_r = is_att ? c.ang_attacker : c.ang_guard;
+    asm volatile("" : "+v"(k_damp), "+v"(k_dt), "+v"(k_sp2), "+v"(k_vmax));
+    asm volatile("" : "+v"(k_doorx), "+v"(k_doory), "+v"(k_fort2), "+v"(k_ang_r));
+    FA_TICK_INIT
+    for (int s = 0; s < ns; ++s) {
+        const int b = s & 1, nb = (s + 1) & 1;
+        FA_TICK(4)
+        const unsigned long long alive0_m = alive_m;
+        const unsigned grp_alive0 = (unsigned)(alive0_m >> gbase) & grp_bits;
+        const bool alive0 = fa_lanes(alive0_m);
+        // ---- core.py:231-243, :440-456: this wave's partner offsets, once per unordered pair ----------------------
+#pragma unroll
+        for (int d = 1; d <= DF; ++d) {
+            int j = i + d;
+            j = j >= N ? j - N : j;
+            const bool mine = (2 * d != N) || (i < N / 2);
+            const double dx = px - qx[d - 1], dy = py - qy[d - 1];
+            const double d2 = dx * dx + dy * dy;
+            double fxv = 0.0, fyv = 0.0;
+            bool near = false;
+            if (mine && alive0 && ((grp_alive0 >> j) & 1u) && !(d2 > c.contact_skip_d2)) {
+                fa_contact_force(c, dx, dy, d2, fxv, fyv);
+                near = true;
+            }
+            if (mine) {
+                s_fmx[j][lane] = fxv;
+                s_fmy[j][lane] = fyv;
+                s_fmx[i][gbase + j] = near ? -fxv : 0.0;
+                s_fmy[i][gbase + j] = near ? -fyv : 0.0;
+            }
+        }
+        FA_TICK(0)
+        // ---- the helpers' hand-offs of step s: tags first, data behind them, one burst; again while a tag is stale ----
+        unsigned long long alive1_m;
+        double fmx[N], fmy[N], wx, wy, u0, u1, rot;
+        for (;;) {
+            FA_ORDER();
+            const int t1 = s_tag[1], t2 = s_tag[2], t3 = s_tag[3];
+            FA_ORDER();
+            alive1_m = s_las[b][0];
+            wx = s_W[0][lane]; wy = s_W[1][lane];
+            u0 = s_U[0][lane]; u1 = s_U[1][lane]; rot = s_U[2][lane];
+#pragma unroll
+            for (int j = 0; j < N; ++j) { fmx[j] = s_fmx[j][lane]; fmy[j] = s_fmy[j][lane]; }
+            FA_ORDER();
+            const bool ok = (t1 == s) & (t2 == s) & (t3 == s);
+            if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
+            if (FA_CHAIN_SLEEP > 0) __builtin_amdgcn_s_sleep(FA_CHAIN_SLEEP);
+        }
+        FA_TICK(1)
+        const unsigned ga1 = (unsigned)(alive1_m >> gbase) & grp_bits;     // survivors of the lane's env
+        const int n_alive_att = __popc(ga1 >> G);
+        const bool restage = ((s + 1) & (FA_ACT_BATCH - 1)) == 0;
+        // ---- core.py:221-252: F = u + 0, the pairs in the reference's order (partner j ascending), then the walls ----
+        if (fa_lanes(alive1_m)) {
+            double Fx = u0, Fy = u1;
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                const double m = (double)((ga1 >> j) & 1u);
+                Fx = __fma_rn(fmx[j], m, Fx);
+                Fy = __fma_rn(fmy[j], m, Fy);
+            }
+            Fx = wx + Fx;
+            Fy = wy + Fy;
+            // core.py:324-338 integrate_state (mass == 1.0: F/1.0 is exact)
+            const double vdx = vx * k_damp, vdy = vy * k_damp;
+            vx = vdx + Fx * k_dt;
+            vy = vdy + Fy * k_dt;
+            double speed2 = vx * vx + vy * vy;
+            if (__builtin_expect(!(speed2 <= k_sp2), 0)) {
+                if (speed2 != speed2) { // coincident agents: see fa_step_pipe_kernel
+                    double Gx = u0, Gy = u1;
+#pragma unroll
+                    for (int j = 0; j < N; ++j)
+                        if ((ga1 >> j) & 1u) { Gx = s_fmx[j][lane] + Gx; Gy = s_fmy[j][lane] + Gy; }
+                    Gx = wx + Gx;
+                    Gy = wy + Gy;
+                    vx = vdx + Gx * k_dt;
+                    vy = vdy + Gy * k_dt;
+                    speed2 = vx * vx + vy * vy;
+                }
+                if (speed2 > k_sp2) {
+                    const double speed = sqrt_rn(speed2);
+                    vx = div_rn(vx, speed) * k_vmax;
+                    vy = div_rn(vy, speed) * k_vmax;
+                }
+            }
+            ang += rot;
+            px += vx * k_dt;
+            py += vy * k_dt;
+        }
+        FA_TICK(2)
+        // ---- what the next state needs of the reward / done logic (see fa_step_pipe_kernel) ------------------------
+        const double ddx = px - k_doorx, ddy = py - k_doory;
+        const double dd2 = ddx * ddx + ddy * ddy;
+        const unsigned long long in_fort_m = FA_M_LE_D(dd2, k_fort2) & is_att_m & alive1_m;
+        const unsigned gw_fort = (unsigned)(in_fort_m >> gbase) & grp_bits;
+        const unsigned long long done_m = FA_M_NE_U(gw_fort, 0) | FA_M_EQ_U(n_alive_att, 0) | FA_M_EQ_U(t, a.max_t - 1);
+        const unsigned long long reset_m = a.auto_reset != 0 ? done_m : 0ull;
+        t += 1;                                                        // fortattack.py:171
+        alive_m = alive1_m;
+        dirty_m |= alive0_m;
+        // ---- fortattack_env_v1.py:47-75 reset_world (prevDist is NOT reset: quirk Q1) ------------------------------
+        if (__builtin_expect(reset_m != 0ull, 0)) {
+            const double rpx = s_rp[0][lane], rpy = s_rp[1][lane];
+            if (fa_lanes(reset_m)) {
+                px = rpx; py = rpy; vx = 0.0; vy = 0.0;
+                ang = k_ang_r;
+                t = 0;
+            }
+            alive_m |= reset_m;
+            dirty_m |= reset_m;
+        }
+        // ---- publish state(s+1) and the by-products of step s -------------------------------------------------------
+        s_px[nb][lane] = px;
+        s_py[nb][lane] = py;
+        s_ang[nb][lane] = ang;
+        s_vx[nb][lane] = vx;
+        s_vy[nb][lane] = vy;
+        s_dd[nb][lane] = dd2;
+        if (fa_lanes(lane0_m)) {
+            s_mask[nb][0] = alive_m;
+            s_mask[nb][1] = done_m;
+        }
+        if (__builtin_expect(restage, 0)) { // (every helper has read this step's action: their tags said so)
+#pragma unroll
+            for (int k = 0; k < FA_ACT_BATCH; ++k) s_act[k][lane] = av[k];
+        }
+        // the partners' positions of the next step: this wave's own writes, in order -- they land while the barrier's LDS
+        // wait drains, so nothing stands between P(s) and the pair forces of step s+1
+#pragma unroll
+        for (int d = 1; d <= DF; ++d) {
+            int j = i + d;
+            j = j >= N ? j - N : j;
+            qx[d - 1] = s_px[nb][gbase + j];
+            qy[d - 1] = s_py[nb][gbase + j];
+        }
+        FA_TICK(3)
+        FA_WG_BARRIER(); // P(s)
+        if (__builtin_expect(restage, 0)) {
+#pragma unroll
+            for (int k = 0; k < FA_ACT_BATCH; ++k)
+                av[k] = (s + 1 + FA_ACT_BATCH + k < ns) ? (int)act_ptr[(int64_t)(s + 1 + FA_ACT_BATCH + k) * a.as_t] : 0;
+        }
+    }
+    FA_WG_BARRIER(); // (epilogues of the emitting waves)
+    FA_TICK_FLUSH(0, 5, 28)
+    if (fa_lanes(dirty_m)) {
+        a.s.px[idx] = px; a.s.py[idx] = py; a.s.vx[idx] = vx; a.s.vy[idx] = vy;
+        a.s.ang[idx] = ang;
+        a.s.alive[idx] = fa_lanes(alive_m) ? 1 : 0;
+    }
+    if (i == 0) a.s.tstep[e] = t;
+#undef FA_ORDER
+}
+
 // ---- np.random.seed(int): init_genrand, then discard the construction draws ----------
 __global__ void fa_seed_kernel(FaState s, int E, uint64_t base_seed, int64_t env_offset, int skip_words) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1771,6 +2376,7 @@ static int step_variant(int G, int A, int E, int nsteps, bool reset_only, int fo
     case 4: return 2;
     case 5: return 3;
     case 6: if (G == 3 && A == 3) return 6; break;         // FA_KERNEL_PAIRS (experiment): lane = (agent, partner)
+    case 7: if (nsteps >= 2 && !choice) return 7; break;   // FA_KERNEL_CHAIN (experiment): one barrier per step
     default: break;
     }
     if (!choice && nsteps >= FA_PIPE_MIN_STEPS && grid <= FA_PIPE_MAX_GRID) return grid <= 2 * 256 ? 0 : -3;
@@ -1779,6 +2385,7 @@ static int step_variant(int G, int A, int E, int nsteps, bool reset_only, int fo
 const char *fa_step_variant_name(int G, int A, int E, int nsteps, int forced, bool choice) {
     switch (step_variant(G, A, E, nsteps, false, forced, choice)) {
     case 6: return "fa_step_pair_kernel";
+    case 7: return "fa_step_chain_kernel";
     case 0: return "fa_step_pipe_kernel";
     case -3: return "fa_step_pipe_kernel/3 per CU";
     case 3: return "fa_step_kernel/3 waves";
@@ -1808,7 +2415,12 @@ static hipError_t launch_step_t(const FaStepArgs &a, hipStream_t st) {
     } while (0)
 #define FA_LAUNCH_PIPE(TG_, TA_, NPW_, MINW_) \
     hipLaunchKernelGGL((fa_step_pipe_kernel<TG_, TA_, COLLECT, NPW_, MINW_>), dim3(grid), dim3((NPW_ + 2) * FA_WAVE), 0, st, a)
-    if (nw == 6) {
+    if (nw == 7) {
+        if constexpr (!RESET_ONLY) {
+            if (a.G == 3) hipLaunchKernelGGL((fa_step_chain_kernel<3, 3, COLLECT>), dim3(grid), dim3(4 * FA_WAVE), 0, st, a);
+            else hipLaunchKernelGGL((fa_step_chain_kernel<5, 5, COLLECT>), dim3(grid), dim3(4 * FA_WAVE), 0, st, a);
+        }
+    } else if (nw == 6) {
         if constexpr (!RESET_ONLY) {
             const int g2 = (a.E + 1) / 2; // two envs per wave
             if (a.choice_k > 0) hipLaunchKernelGGL((fa_step_pair_kernel<3, 3, COLLECT, true>), dim3(g2), dim3(FA_WAVE), 0, st, a);

@@ -50,8 +50,10 @@ enum { FA_KERNEL_AUTO = 0,
        FA_KERNEL_WAVES1 = 3,  /* fa_step_kernel, one wave per workgroup */
        FA_KERNEL_WAVES2 = 4,  /* ... with the force wave (3v3 / 5v5) */
        FA_KERNEL_WAVES3 = 5,  /* ... with force and wall waves (3v3 / 5v5) */
-       FA_KERNEL_PAIRS = 6 }; /* fa_step_pair_kernel (round-4 experiment, 3v3): lane = (agent, partner), one wave, no
+       FA_KERNEL_PAIRS = 6,   /* fa_step_pair_kernel (round-4 experiment, 3v3): lane = (agent, partner), one wave, no
                                  workgroup barrier; never picked by AUTO */
+       FA_KERNEL_CHAIN = 7 }; /* fa_step_chain_kernel (round-4 experiment, 3v3 / 5v5, num_steps >= 2): one workgroup barrier
+                                 per step, the helpers' results reach the state's wave through tagged LDS hand-offs */
 enum { FA_RNG_MT19937 = 0, /* numpy legacy RandomState stream: parity with the reference */
        FA_RNG_PHILOX = 1 }; /* counter based, stateless: perf mode */
 

@@ -1,6 +1,7 @@
 """Experiment (run ON THE GPU BOX): A/B of step-kernel builds.  For each library (tools/_build/lib_<name>.so,
 or "product") in its own process: the fused COLLECT launch at 3v3 x 4096 x 128 / 5v5 x 4096 x 128 / 3v3 x 7680 x 64
 checked against the oracle (rows, state, counters), then timed with events.
+FA_AB_KERNEL=<pipe|chain|...> pins the step kernel (fa_config.step_kernel) in both parts.
 usage: ab_step.py [--no-parity] [--quick] product name1 name2 ..."""
 import json
 import os
@@ -29,7 +30,7 @@ def one(name, parity, quick):
             from test_gpu_shipped_kernels import _check_rows_vs_oracle, _shooty_actions
             rng = np.random.RandomState(G * 1000 + E)
             orc = OracleEnv(E, G, A, 60, base_seed=4242)
-            eng = fa.BatchedFortAttack(E, G, A, 60, base_seed=4242)
+            eng = fa.BatchedFortAttack(E, G, A, 60, base_seed=4242, step_kernel=os.environ.get('FA_AB_KERNEL', 'auto'))
             st = fa.JointRolloutStorage(T, E, N, device="cuda")
             eng.bind_storage(st)
             eng.collect_reset()
@@ -54,7 +55,7 @@ def one(name, parity, quick):
                 out[tag + "_err"] = "rows differ at step %s" % (ex,)
             out[tag + "_parity"] = ok
             del eng, st, orc
-        eng = fa.BatchedFortAttack(E, G, A, 100, base_seed=0)
+        eng = fa.BatchedFortAttack(E, G, A, 100, base_seed=0, step_kernel=os.environ.get('FA_AB_KERNEL', 'auto'))
         st = fa.JointRolloutStorage(T, E, N, device="cuda")
         eng.bind_storage(st)
         st.actions.copy_(torch.randint(0, 8, st.actions.shape, device="cuda", generator=torch.Generator(device="cuda").manual_seed(0)))

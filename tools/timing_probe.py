@@ -11,7 +11,8 @@ E = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 G = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 A = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 T = 128
-eng = fa.BatchedFortAttack(E, G, A, 100, track_counters=False)
+KERNEL = os.environ.get("FA_PROBE_KERNEL", "auto")     # "chain": the one-barrier experiment kernel's sections
+eng = fa.BatchedFortAttack(E, G, A, 100, track_counters=False, step_kernel=KERNEL)
 st = fa.JointRolloutStorage(T, E, G + A, device="cuda")
 eng.bind_storage(st)
 st.actions.copy_(torch.randint(0, 8, st.actions.shape, device="cuda"))
@@ -30,7 +31,14 @@ names = {0: "w0 decode + triangles", 1: "w0 laser + ballots", 2: "w0 wait B2", 3
          4: "w0 door distance + done", 5: "w0 reset", 6: "w0 publish", 7: "w0 wait P",
          10: "out wait P", 11: "out pair forces", 12: "out wait B2", 13: "out rewards + stores",
          16: "last wait P", 17: "last walls", 18: "last wait B2", 19: "last sin/cos"}
-for lo, hi, cnt in ((0, 8, 28), (10, 14, 29), (16, 20, 30)):
+groups = ((0, 8, 28), (10, 14, 29), (16, 20, 30))
+if KERNEL == "chain":
+    names = {4: "chain wait P", 0: "chain own pair offsets", 1: "chain hand-off burst (+ waiting)", 2: "chain force sum + integrate",
+             3: "chain done + reset + publish", 12: "laser wait P", 10: "laser read + tests + hand-off", 11: "laser next heading",
+             18: "walls wait P", 16: "walls decode + walls + hand-off", 17: "walls rewards + reset stream",
+             14: "pairs wait P", 8: "pairs rest offsets + hand-off", 9: "pairs obs / done / mask rows"}
+    groups = ((0, 5, 28), (10, 13, 29), (16, 19, 30), (8, 10, 31), (14, 15, 27))
+for lo, hi, cnt in groups:
     waves = max(buf[cnt], 1)
     tot = 0.0
     for k in range(lo, hi):
