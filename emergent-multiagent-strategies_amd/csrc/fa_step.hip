@@ -1761,6 +1761,13 @@ __global__ __launch_bounds__((NPW + 2) * FA_WAVE, MINW) void fa_step_pipe_kernel
 #ifndef FA_CHAIN_TRIG_WAVE
 #define FA_CHAIN_TRIG_WAVE 1 // which helper makes the next heading's sin/cos: 1 (laser wave) or 3 (pair / rows wave: 163.0 us)
 #endif
+#ifndef FA_CHAIN_NOBAR
+#define FA_CHAIN_NOBAR 0     // 1: no barrier inside the step loop at all -- the helpers poll the chain wave's publish tag
+                             // (bit-exact; 162.3 / 165.0 / 167.4 us with s_sleep 0 / 1 / 3 between polls against 153.8 with P)
+#endif
+#ifndef FA_CHAIN_HSLEEP
+#define FA_CHAIN_HSLEEP 1    // s_sleep between two polls of the publish tag by a helper
+#endif
 #ifndef FA_CHAIN_SLEEP
 #define FA_CHAIN_SLEEP 0     // s_sleep between two polls of the hand-off tags (0: none; 1 / 4: 153.7 / 157.0 us against 151.5)
 #endif
@@ -1794,12 +1801,29 @@ __global__ __launch_bounds__(4 * FA_WAVE, 2) void fa_step_chain_kernel(FaStepArg
     // waits for every volatile LDS access on its own (lgkmcnt(0) each: 250 us) -- but fenced for the COMPILER by
     // FA_ORDER(): data before tag on the writing side, tags before data on the reading side; the hardware keeps a wave's
     // DS operations in order.
-    __shared__ unsigned long long s_las[2][4];  // [step parity][alive after the laser, hit, was hit]  (wave 1)
+    __shared__ unsigned long long s_las[3][4];  // [step % 3][alive after the laser, hit, was hit]     (wave 1)
     __shared__ double s_W[2][FA_WAVE], s_U[3][FA_WAVE];       // wall force, decoded action            (wave 2)
     __shared__ double s_rp[2][FA_WAVE];                        // positions of the lane's next reset   (wave 2)
     __shared__ double s_fmx[N][FA_WAVE], s_fmy[N][FA_WAVE];   // [partner j][lane]: pair force on the lane's agent
-    __shared__ int s_tag[4];                                   // [wave]: the step its hand-off is complete for
+    __shared__ int s_tag[4];                                   // [wave]: the step its hand-off is complete for; [0]: the chain
+                                                               // wave's -- the step whose start state is published
 #define FA_ORDER() asm volatile("" ::: "memory")
+    // FA_CHAIN_NOBAR: a helper starts step s when the chain wave's tag says state(s) is published (tag first, data behind it);
+    // nothing else orders the waves inside the loop.  What a helper reads one step late (by-products, s_las) survives
+    // because the chain wave publishes state(s+2) only after it has seen every helper's tag of step s+1, i.e. after
+    // every helper finished step s entirely -- except s_las, which wave 1 rewrites two steps later WITHOUT waiting for
+    // the others: three buffers.
+    auto wait_state = [&](int s) {
+        if (FA_CHAIN_NOBAR) {
+            for (;;) {
+                FA_ORDER();
+                const int tf = s_tag[0];
+                FA_ORDER();
+                if (__builtin_amdgcn_readfirstlane(tf) >= s) break;
+                if (FA_CHAIN_HSLEEP > 0) __builtin_amdgcn_s_sleep(FA_CHAIN_HSLEEP);
+            }
+        }
+    };
 
     if (wave_id == 1) {
         // ---- wave 1: the laser (core.py:254-302) of step s -> chain wave; then sin/cos of the heading of step s+1 ----
@@ -1825,7 +1849,8 @@ __global__ __launch_bounds__(4 * FA_WAVE, 2) void fa_step_chain_kernel(FaStepArg
         FA_TICK_INIT
         FA_WG_BARRIER(); // P(-1)
         for (int s = 0; s < ns; ++s) {
-            const int b = s & 1;
+            const int b = s & 1, b3 = s % 3;
+            wait_state(s);
             FA_TICK(12)
             const int act = s_act[s & (FA_ACT_BATCH - 1)][lane];
             const unsigned long long alive0_m = s_mask[b][0];
@@ -1876,9 +1901,9 @@ __global__ __launch_bounds__(4 * FA_WAVE, 2) void fa_step_chain_kernel(FaStepArg
             const unsigned long long hit_m = FA_M_NE_U(hit_cnt, 0) & shooters_m;
             const unsigned long long alive1_m = alive0_m & ~was_hit_m;        // :293-302 one shot kills
             if (fa_lanes(lane0_m)) {
-                s_las[b][0] = alive1_m;
-                s_las[b][1] = hit_m;
-                s_las[b][2] = was_hit_m;
+                s_las[b3][0] = alive1_m;
+                s_las[b3][1] = hit_m;
+                s_las[b3][2] = was_hit_m;
             }
             FA_ORDER();
             if (fa_lanes(lane0_m)) s_tag[1] = s;   // behind the data: in order
@@ -1896,7 +1921,7 @@ __global__ __launch_bounds__(4 * FA_WAVE, 2) void fa_step_chain_kernel(FaStepArg
                 s_trig[(s + 1) & 1][1][lane] = sn;
             }
             FA_TICK(11)
-            FA_WG_BARRIER(); // P(s)
+            if (!FA_CHAIN_NOBAR) FA_WG_BARRIER(); // P(s)
         }
         FA_WG_BARRIER(); // (epilogues of the emitting waves)
         FA_TICK_FLUSH(10, 13, 29)
@@ -1923,7 +1948,7 @@ __global__ __launch_bounds__(4 * FA_WAVE, 2) void fa_step_chain_kernel(FaStepArg
         // rewards of step se (called once per step, in order): laser masks in s_las[se & 1], done / door distance in
         // buffer (se + 1) & 1
         auto emit_rew = [&](int se) {
-            const int pl = se & 1, pb = (se + 1) & 1;
+            const int pl = se % 3, pb = (se + 1) & 1;
             const unsigned long long m1 = s_las[pl][0];
             const bool alive1 = (m1 >> lane) & 1ull;
             const bool hit = (s_las[pl][1] >> lane) & 1ull;
@@ -1980,6 +2005,7 @@ __global__ __launch_bounds__(4 * FA_WAVE, 2) void fa_step_chain_kernel(FaStepArg
         FA_WG_BARRIER(); // P(-1)
         for (int s = 0; s < ns; ++s) {
             const int b = s & 1;
+            wait_state(s);
             FA_TICK(18)
             if (s > 0 && a.auto_reset != 0) {
                 // envs that were reset at the end of step s-1 used draw A: commit it, promote B (ahead of this step's
@@ -2026,7 +2052,7 @@ __global__ __launch_bounds__(4 * FA_WAVE, 2) void fa_step_chain_kernel(FaStepArg
             act_prev = act;
             alive0_prev = alive0;
             FA_TICK(17)
-            FA_WG_BARRIER(); // P(s)
+            if (!FA_CHAIN_NOBAR) FA_WG_BARRIER(); // P(s)
         }
         FA_WG_BARRIER(); // the chain wave has published the last step's by-products
         FA_TICK_FLUSH(16, 19, 30)
@@ -2054,7 +2080,7 @@ __global__ __launch_bounds__(4 * FA_WAVE, 2) void fa_step_chain_kernel(FaStepArg
             p_obs += EN * 6; row6 += (long long)EN * 6;
         };
         auto emit_flags = [&](int se) { // done / mask rows and _get_done bookkeeping of step se (fortattack.py:202-225)
-            const int pl = se & 1, pb = (se + 1) & 1;
+            const int pl = se % 3, pb = (se + 1) & 1;
             const unsigned long long m1 = s_las[pl][0];
             const bool alive1 = (m1 >> lane) & 1ull;
             const bool done = (s_mask[pb][1] >> lane) & 1ull;
@@ -2079,6 +2105,7 @@ __global__ __launch_bounds__(4 * FA_WAVE, 2) void fa_step_chain_kernel(FaStepArg
         FA_WG_BARRIER(); // P(-1)
         for (int s = 0; s < ns; ++s) {
             const int b = s & 1;
+            wait_state(s);
             FA_TICK(14)
             const unsigned long long grp_alive0 = (s_mask[b][0] >> gbase) & grp_mask;
             const bool alive0 = (grp_alive0 >> i) & 1ull;
@@ -2130,7 +2157,7 @@ __global__ __launch_bounds__(4 * FA_WAVE, 2) void fa_step_chain_kernel(FaStepArg
             }
             alive0_prev = alive0;
             FA_TICK(9)
-            FA_WG_BARRIER(); // P(s)
+            if (!FA_CHAIN_NOBAR) FA_WG_BARRIER(); // P(s)
         }
         FA_WG_BARRIER(); // the chain wave has published the last step's by-products
         FA_TICK_FLUSH(8, 10, 31)
@@ -2164,7 +2191,7 @@ __global__ __launch_bounds__(4 * FA_WAVE, 2) void fa_step_chain_kernel(FaStepArg
     if (fa_lanes(lane0_m)) {
         s_mask[0][0] = alive_m;
         s_mask[0][1] = 0ull;
-        s_tag[1] = -1; s_tag[2] = -1; s_tag[3] = -1;
+        s_tag[0] = 0; s_tag[1] = -1; s_tag[2] = -1; s_tag[3] = -1;
     }
     s_fmx[i][lane] = 0.0; // an agent exerts no force on itself: nobody writes the diagonal
     s_fmy[i][lane] = 0.0;
@@ -2222,7 +2249,7 @@ __global__ __launch_bounds__(4 * FA_WAVE, 2) void fa_step_chain_kernel(FaStepArg
             FA_ORDER();
             const int t1 = s_tag[1], t2 = s_tag[2], t3 = s_tag[3];
             FA_ORDER();
-            alive1_m = s_las[b][0];
+            alive1_m = s_las[s % 3][0];
             wx = s_W[0][lane]; wy = s_W[1][lane];
             u0 = s_U[0][lane]; u1 = s_U[1][lane]; rot = s_U[2][lane];
 #pragma unroll
@@ -2320,8 +2347,13 @@ __global__ __launch_bounds__(4 * FA_WAVE, 2) void fa_step_chain_kernel(FaStepArg
             qx[d - 1] = s_px[nb][gbase + j];
             qy[d - 1] = s_py[nb][gbase + j];
         }
+        if (FA_CHAIN_NOBAR) { // state(s+1) is complete: tag behind the data
+            FA_ORDER();
+            if (fa_lanes(lane0_m)) s_tag[0] = s + 1;
+            FA_ORDER();
+        }
         FA_TICK(3)
-        FA_WG_BARRIER(); // P(s)
+        if (!FA_CHAIN_NOBAR) FA_WG_BARRIER(); // P(s)
         if (__builtin_expect(restage, 0)) {
 #pragma unroll
             for (int k = 0; k < FA_ACT_BATCH; ++k)
