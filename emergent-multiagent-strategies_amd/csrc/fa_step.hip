@@ -320,9 +320,31 @@ __device__ __forceinline__ void fa_wall_force_flat(const FaDerived &c, double px
         band = band | ((t[q] < 40.0) & !(t[q] < -746.0));
     }
     if (__builtin_amdgcn_ballot_w64(band) != 0ull) {
+        bool bq[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-            if ((t[q] < 40.0) & !(t[q] < -746.0)) v[q] = softplus_band(t[q]);
+        for (int q = 0; q < 4; ++q) bq[q] = (t[q] < 40.0) & !(t[q] < -746.0);
+#ifndef FA_WALLS_FOUR_CALLS
+        // An agent is in the band of at most ONE wall per axis unless the arena is narrower than two band widths
+        // (the band is 0.786 wide, the reference's arena 1.9 x 1.5 between the agents' surfaces): the axis' one
+        // candidate goes through the libm path -- two calls per step instead of four, the same function on the same
+        // operand, so the same bits.  (A wave with a lane between two bands of one axis takes the general path.)
+        if (__builtin_amdgcn_ballot_w64((bq[0] & bq[1]) | (bq[2] & bq[3])) == 0ull) {
+#pragma unroll
+            for (int ax = 0; ax < 2; ++ax) {
+                const bool any = bq[2 * ax] | bq[2 * ax + 1];
+                if (any) {
+                    const double vb = softplus_band(bq[2 * ax] ? t[2 * ax] : t[2 * ax + 1]);
+                    if (bq[2 * ax]) v[2 * ax] = vb;
+                    else v[2 * ax + 1] = vb;
+                }
+            }
+        } else
+#endif
+        {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (bq[q]) v[q] = softplus_band(t[q]);
+        }
     }
     wx = c.contact_force * (v[0] * k) - c.contact_force * (v[1] * k);
     wy = c.contact_force * (v[2] * k) - c.contact_force * (v[3] * k);
@@ -1188,15 +1210,18 @@ __global__ __launch_bounds__((NPW + 2) * FA_WAVE, MINW) void fa_step_pipe_kernel
     FA_PROBE_HWID(lane, wave_id)
 
     // buffer s & 1: state at the start of step s (+ by-products of step s-1)
-    __shared__ double s_px[2][FA_WAVE], s_py[2][FA_WAVE], s_ang[2][FA_WAVE];
-    __shared__ double s_vx[2][FA_WAVE], s_vy[2][FA_WAVE], s_dd[2][FA_WAVE];
+    // (x, y) pairs live side by side: whoever reads one reads the other, and one 16-byte LDS operation per pair halves the
+    // number of LDS instructions queued behind each barrier (the reads behind P take ~330 cycles: four waves at once)
+    __shared__ double2 s_pos[2][FA_WAVE], s_vel[2][FA_WAVE];
+    __shared__ double s_ang[2][FA_WAVE], s_dd[2][FA_WAVE];
     __shared__ unsigned long long s_mask[2][8]; // ballots: 0 alive, 1 alive after laser, 2 hit, 3 was hit, 4 done
-    __shared__ double s_trig[2][2][FA_WAVE]; // [step parity][cos, sin][lane]: heading of the step's start state
-    __shared__ double s_W[2][FA_WAVE];
-    __shared__ double s_U[3][FA_WAVE]; // decoded action of the step: accel*u + 0.0 (x, y), rotation
-    __shared__ double s_fmx[N][FA_WAVE], s_fmy[N][FA_WAVE]; // [partner j][lane]: pair force on the lane's agent
+    __shared__ double2 s_trig[2][FA_WAVE]; // [step parity][lane] = (cos, sin): heading of the step's start state
+    __shared__ double2 s_W[FA_WAVE];
+    __shared__ double2 s_U[FA_WAVE];       // decoded action of the step: accel*u + 0.0 (x, y)
+    __shared__ double s_rot[FA_WAVE];      // ... and its rotation
+    __shared__ double2 s_fm[N][FA_WAVE];   // [partner j][lane]: pair force on the lane's agent
     __shared__ int s_act[FA_ACT_BATCH][FA_WAVE];
-    __shared__ double s_rp[2][FA_WAVE]; // positions of the lane's next reset (drawn ahead by wave 1)
+    __shared__ double2 s_rp[FA_WAVE]; // position of the lane's next reset (drawn ahead by wave 1)
 
     if (wave_id == NPW + 1) {
         // ---- last wave: walls of step s, sin/cos of the heading of step s+1, and the done / mask rows +
@@ -1238,7 +1263,8 @@ __global__ __launch_bounds__((NPW + 2) * FA_WAVE, MINW) void fa_step_pipe_kernel
             const int act = s_act[s & (FA_ACT_BATCH - 1)][lane];
             const double ang = s_ang[b][lane];
             const bool alive0 = (s_mask[b][0] >> lane) & 1ull;
-            double px = s_px[b][lane], py = s_py[b][lane];
+            const double2 pos_ = s_pos[b][lane];
+            double px = pos_.x, py = pos_.y;
             asm volatile("" : "+v"(px), "+v"(py)); // read with the rest: one LDS round trip, not two
             // fortattack.py:253-263,:289 _set_action, for wave 0 (F starts as u + 0.0, core.py:221-228)
             double u0 = 0.0, u1 = 0.0, rot = 0.0;
@@ -1248,23 +1274,20 @@ __global__ __launch_bounds__((NPW + 2) * FA_WAVE, MINW) void fa_step_pipe_kernel
             if (act == 4) u1 = -1.0;
             if (act == 5) rot = c.rot_pos;
             if (act == 6) rot = c.rot_neg;
-            s_U[0][lane] = u0 * c.accel + 0.0;
-            s_U[1][lane] = u1 * c.accel + 0.0;
-            s_U[2][lane] = rot;
+            s_U[lane] = make_double2(u0 * c.accel + 0.0, u1 * c.accel + 0.0);
+            s_rot[lane] = rot;
             double wx = 0.0, wy = 0.0;
             fa_wall_force_flat(c, px, py, wx, wy); // core.py:246-252 + :459-472
             wx = alive0 ? wx : 0.0;
             wy = alive0 ? wy : 0.0;
-            s_W[0][lane] = wx;
-            s_W[1][lane] = wy;
+            s_W[lane] = make_double2(wx, wy);
             FA_TICK(17)
             FA_WG_BARRIER(); // B2(s)
             FA_TICK(18)
             if (s + 1 < ns) {
                 double sn, cs;
                 sincos_heading(ang + rot, sn, cs); // == wave 0's `ang += rot` for a survivor
-                s_trig[(s + 1) & 1][0][lane] = cs;
-                s_trig[(s + 1) & 1][1][lane] = sn;
+                s_trig[(s + 1) & 1][lane] = make_double2(cs, sn);
             }
             if (s > 0) emit_flags(b);
             alive0_prev = alive0;
@@ -1345,8 +1368,9 @@ __global__ __launch_bounds__((NPW + 2) * FA_WAVE, MINW) void fa_step_pipe_kernel
         auto emit_obs = [&](int bo) {
             // observation row (fortattack_env_v1.py:238): the state after the step / reset
             const bool alive_new = (s_mask[bo][0] >> lane) & 1ull;
-            const double px = s_px[bo][lane], py = s_py[bo][lane], ang = s_ang[bo][lane];
-            const double vx = s_vx[bo][lane], vy = s_vy[bo][lane];
+            const double2 pos_ = s_pos[bo][lane], vel_ = s_vel[bo][lane];
+            const double px = pos_.x, py = pos_.y, ang = s_ang[bo][lane];
+            const double vx = vel_.x, vy = vel_.y;
             fa_store_obs((COLLECT || a.obs32) ? p_obs : nullptr, (!COLLECT && a.obs64) ? a.obs64 + row6 : nullptr, alive_new,
                          px, py, ang, vx, vy);
             p_obs += EN * 6; row6 += (long long)EN * 6;
@@ -1368,8 +1392,7 @@ __global__ __launch_bounds__((NPW + 2) * FA_WAVE, MINW) void fa_step_pipe_kernel
             wait_words();
             draw_eval(a, e, i, is_att, mwa, rdA);
             draw_eval(a, e, i, is_att, mwb, rdB);
-            s_rp[0][lane] = rdA.px;
-            s_rp[1][lane] = rdA.py;
+            s_rp[lane] = make_double2(rdA.px, rdA.py);
         }
         FA_TICK_INIT
         FA_WG_BARRIER(); // P(-1)
@@ -1383,13 +1406,13 @@ __global__ __launch_bounds__((NPW + 2) * FA_WAVE, MINW) void fa_step_pipe_kernel
                 if (need_b) {
                     draw_commit(a, e, i, N, rdA);
                     rdA = rdB;
-                    s_rp[0][lane] = rdA.px;
-                    s_rp[1][lane] = rdA.py;
+                    s_rp[lane] = make_double2(rdA.px, rdA.py);
                 }
             }
             const unsigned long long grp_alive0 = (s_mask[b][0] >> gbase) & grp_mask;
             const bool alive0 = (grp_alive0 >> i) & 1ull;
-            const double px = s_px[b][lane], py = s_py[b][lane];
+            const double2 pos_ = s_pos[b][lane];
+            const double px = pos_.x, py = pos_.y;
             const int act_cur = s_act[s & (FA_ACT_BATCH - 1)][lane];
             // the partners' positions of all this wave's offsets in one LDS round trip (small teams:
             // at N = 10 the extra live registers push the 168-VGPR build into scratch)
@@ -1401,8 +1424,9 @@ __global__ __launch_bounds__((NPW + 2) * FA_WAVE, MINW) void fa_step_pipe_kernel
                     if (fa_pair_wave<N, NPW>(d) != wave_id) continue; // uniform per wave
                     int j = i + d;
                     j = j >= N ? j - N : j;
-                    qx[d - 1] = s_px[b][gbase + j];
-                    qy[d - 1] = s_py[b][gbase + j];
+                    const double2 q_ = s_pos[b][gbase + j];
+                    qx[d - 1] = q_.x;
+                    qy[d - 1] = q_.y;
                 }
             }
 #pragma unroll
@@ -1414,8 +1438,9 @@ __global__ __launch_bounds__((NPW + 2) * FA_WAVE, MINW) void fa_step_pipe_kernel
                 // candidate against a partner alive BEFORE the laser (one the laser kills this step
                 // is masked out in the sum); exactly +0.0 when out of range, so adding it is a no-op
                 if constexpr (!HOISTQ) {
-                    qx[d - 1] = s_px[b][gbase + j];
-                    qy[d - 1] = s_py[b][gbase + j];
+                    const double2 q_ = s_pos[b][gbase + j];
+                    qx[d - 1] = q_.x;
+                    qy[d - 1] = q_.y;
                 }
                 const double dx = px - qx[d - 1], dy = py - qy[d - 1];
                 const double d2 = dx * dx + dy * dy;
@@ -1426,10 +1451,8 @@ __global__ __launch_bounds__((NPW + 2) * FA_WAVE, MINW) void fa_step_pipe_kernel
                     near = true;
                 }
                 if (mine) {
-                    s_fmx[j][lane] = fxv;               // on agent i from partner j
-                    s_fmy[j][lane] = fyv;
-                    s_fmx[i][gbase + j] = near ? -fxv : 0.0; // on agent j from partner i: the exact negative
-                    s_fmy[i][gbase + j] = near ? -fyv : 0.0;
+                    s_fm[j][lane] = make_double2(fxv, fyv);                                       // on agent i from partner j
+                    s_fm[i][gbase + j] = make_double2(near ? -fxv : 0.0, near ? -fyv : 0.0);     // on agent j from partner i: the exact negative
                 }
             }
             FA_TICK(11)
@@ -1493,16 +1516,14 @@ __global__ __launch_bounds__((NPW + 2) * FA_WAVE, MINW) void fa_step_pipe_kernel
     }
     const double cs_ro = is_att ? cs_g : cs_a, sn_ro = is_att ? sn_g : sn_a;   // the opponents
     double oqx[KT], oqy[KT], ocs[KT], osn[KT]; // the opponents' position and heading at the step's start
-    s_trig[0][0][lane] = cs;
-    s_trig[0][1][lane] = sn;
+    s_trig[0][lane] = make_double2(cs, sn);
     int act = av[0];
 #pragma unroll
     for (int k = 0; k < FA_ACT_BATCH; ++k) s_act[k][lane] = av[k];
 #pragma unroll
     for (int k = 0; k < FA_ACT_BATCH; ++k)
         av[k] = (FA_ACT_BATCH + k < ns) ? (int)act_ptr[(int64_t)(FA_ACT_BATCH + k) * a.as_t] : 0;
-    s_px[0][lane] = px;
-    s_py[0][lane] = py;
+    s_pos[0][lane] = make_double2(px, py);
     s_ang[0][lane] = ang;
     if (fa_lanes(lane0_m)) s_mask[0][0] = alive_m;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1511,12 +1532,12 @@ __global__ __launch_bounds__((NPW + 2) * FA_WAVE, MINW) void fa_step_pipe_kernel
 #pragma unroll
     for (int k = 0; k < KT; ++k) {
         const int j = gbase + opp0 + (k < n_opp ? k : 0);
-        oqx[k] = s_px[0][j]; oqy[k] = s_py[0][j];
-        ocs[k] = s_trig[0][0][j]; osn[k] = s_trig[0][1][j];
+        const double2 q_ = s_pos[0][j], tg_ = s_trig[0][j];
+        oqx[k] = q_.x; oqy[k] = q_.y;
+        ocs[k] = tg_.x; osn[k] = tg_.y;
     }
     unsigned long long reset_prev_m = 0ull;
-    s_fmx[i][lane] = 0.0; // an agent exerts no force on itself: the pair waves never write the diagonal
-    s_fmy[i][lane] = 0.0;
+    s_fm[i][lane] = make_double2(0.0, 0.0); // an agent exerts no force on itself: the pair waves never write the diagonal
     FA_WG_BARRIER(); // P(-1)
     FA_PROBE_WAVE0_LOOP_BEGIN(lane)
 
@@ -1539,8 +1560,9 @@ __global__ __launch_bounds__((NPW + 2) * FA_WAVE, MINW) void fa_step_pipe_kernel
 #pragma unroll
             for (int k = 0; k < KT; ++k) {
                 const int j = gbase + opp0 + (k < n_opp ? k : 0);
-                ocs[k] = s_trig[s & 1][0][j];
-                osn[k] = s_trig[s & 1][1][j];
+                const double2 tg_ = s_trig[s & 1][j];
+                ocs[k] = tg_.x;
+                osn[k] = tg_.y;
             }
             if (__builtin_expect(reset_prev_m != 0ull, 0)) { // rare blocks out of line: a taken skip costs ~27 cycles
                 const bool rp = fa_lanes(reset_prev_m);
@@ -1594,9 +1616,10 @@ __global__ __launch_bounds__((NPW + 2) * FA_WAVE, MINW) void fa_step_pipe_kernel
         // partner j ascending), then the walls -------------------------------------------------
         double fmx[N], fmy[N];
 #pragma unroll
-        for (int j = 0; j < N; ++j) { fmx[j] = s_fmx[j][lane]; fmy[j] = s_fmy[j][lane]; }
-        const double wx = s_W[0][lane], wy = s_W[1][lane];
-        const double u0 = s_U[0][lane], u1 = s_U[1][lane], rot = s_U[2][lane];
+        for (int j = 0; j < N; ++j) { const double2 f_ = s_fm[j][lane]; fmx[j] = f_.x; fmy[j] = f_.y; }
+        const double2 w_ = s_W[lane], u_ = s_U[lane];
+        const double wx = w_.x, wy = w_.y;
+        const double u0 = u_.x, u1 = u_.y, rot = s_rot[lane];
         const bool restage = ((s + 1) & (FA_ACT_BATCH - 1)) == 0;
         const int act_lds = s_act[(s + 1) & (FA_ACT_BATCH - 1)][lane];
         int act_next = restage ? av[0] : act_lds;
@@ -1628,7 +1651,7 @@ __global__ __launch_bounds__((NPW + 2) * FA_WAVE, MINW) void fa_step_pipe_kernel
                     double Gx = u0, Gy = u1;
 #pragma unroll
                     for (int j = 0; j < N; ++j)
-                        if ((ga1 >> j) & 1u) { Gx = s_fmx[j][lane] + Gx; Gy = s_fmy[j][lane] + Gy; }
+                        if ((ga1 >> j) & 1u) { const double2 f_ = s_fm[j][lane]; Gx = f_.x + Gx; Gy = f_.y + Gy; }
                     Gx = wx + Gx;
                     Gy = wy + Gy;
                     vx = vdx + Gx * k_dt;
@@ -1668,7 +1691,8 @@ __global__ __launch_bounds__((NPW + 2) * FA_WAVE, MINW) void fa_step_pipe_kernel
         // ---- fortattack_env_v1.py:47-75 reset_world (prevDist is NOT reset: quirk Q1) ----------
         // (the positions were drawn ahead by wave 1, see ResetDraw)
         if (__builtin_expect(reset_m != 0ull, 0)) { // wave-uniform: most steps reset no env of the wave
-            const double rpx = s_rp[0][lane], rpy = s_rp[1][lane];
+            const double2 rp_ = s_rp[lane];
+            const double rpx = rp_.x, rpy = rp_.y;
             if (fa_lanes(reset_m)) {
                 px = rpx; py = rpy; vx = 0.0; vy = 0.0;
                 ang = k_ang_r;
@@ -1681,8 +1705,7 @@ __global__ __launch_bounds__((NPW + 2) * FA_WAVE, MINW) void fa_step_pipe_kernel
         reset_prev_m = reset_m;
         FA_TICK(5)
         // ---- publish state(s+1): what the helper waves need to start on step s+1 ----------------
-        s_px[nb][lane] = px;
-        s_py[nb][lane] = py;
+        s_pos[nb][lane] = make_double2(px, py);
         s_ang[nb][lane] = ang;
         if (fa_lanes(lane0_m)) {
             s_mask[nb][0] = alive_m;
@@ -1696,8 +1719,7 @@ __global__ __launch_bounds__((NPW + 2) * FA_WAVE, MINW) void fa_step_pipe_kernel
         // behind the barrier, while the helpers already work on step s+1 (those of the last step are
         // followed by one more barrier after the loop)
         auto publish_byproducts = [&]() {
-            s_vx[nb][lane] = vx;
-            s_vy[nb][lane] = vy;
+            s_vel[nb][lane] = make_double2(vx, vy);
             s_dd[nb][lane] = dd2;
             if (fa_lanes(lane0_m)) {
                 s_mask[nb][1] = alive1_m;
@@ -1718,8 +1740,9 @@ __global__ __launch_bounds__((NPW + 2) * FA_WAVE, MINW) void fa_step_pipe_kernel
 #pragma unroll
         for (int k = 0; k < KT; ++k) {
             const int j = gbase + opp0 + (k < n_opp ? k : 0);
-            oqx[k] = s_px[nb][j];
-            oqy[k] = s_py[nb][j];
+            const double2 q_ = s_pos[nb][j];
+            oqx[k] = q_.x;
+            oqy[k] = q_.y;
         }
         act = act_next;
     }

@@ -31,7 +31,8 @@ names = {0: "w0 decode + triangles", 1: "w0 laser + ballots", 2: "w0 wait B2", 3
          4: "w0 door distance + done", 5: "w0 reset", 6: "w0 publish", 7: "w0 wait P",
          10: "out wait P", 11: "out pair forces", 12: "out wait B2", 13: "out rewards + stores",
          16: "last wait P", 17: "last walls", 18: "last wait B2", 19: "last sin/cos"}
-groups = ((0, 8, 28), (10, 14, 29), (16, 20, 30))
+groups = ((0, 8, 28), (10, 14, 29), (16, 20, 30), (15, 16, 26))
+names[15] = "last: LDS reads landed (probe build with the extra mark only)"
 if KERNEL == "chain":
     names = {4: "chain wait P", 0: "chain own pair offsets", 1: "chain hand-off burst (+ waiting)", 2: "chain force sum + integrate",
              3: "chain done + reset + publish", 12: "laser wait P", 10: "laser read + tests + hand-off", 11: "laser next heading",
