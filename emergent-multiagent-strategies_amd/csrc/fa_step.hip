@@ -434,10 +434,11 @@ __global__ __launch_bounds__(NW * FA_WAVE) void fa_step_kernel(FaStepArgs a) {
     const unsigned long long grp_mask = (1ull << N) - 1ull;
     const FaDerived &c = a.c;
 
-    __shared__ double s_px[FA_WAVE], s_py[FA_WAVE], s_cs[FA_WAVE], s_sn[FA_WAVE]; // positions, heading of shooters
+    __shared__ double2 s_pos[FA_WAVE], s_trig[FA_WAVE]; // positions; (cos, sin) of the shooters' headings -- (x, y) pairs side by
+                                                         // side: one 16-byte LDS operation per pair (see fa_step_pipe_kernel)
     __shared__ int s_act[FA_ACT_BATCH][FA_WAVE];
-    __shared__ double s_F[2][TWO ? FA_WAVE : 1];  // TWO: total force per lane, from the force wave
-    __shared__ double s_W[2][THREE ? FA_WAVE : 1]; // THREE: wall force per lane, from the wall wave
+    __shared__ double2 s_F[TWO ? FA_WAVE : 1];   // TWO: total force per lane, from the force wave
+    __shared__ double2 s_W[THREE ? FA_WAVE : 1]; // THREE: wall force per lane, from the wall wave
     __shared__ unsigned long long s_mask[2];        // TWO: ballots of alive-before / alive-after-laser
 
     if constexpr (TWO) {
@@ -455,9 +456,9 @@ __global__ __launch_bounds__(NW * FA_WAVE) void fa_step_kernel(FaStepArgs a) {
                     FA_WG_BARRIER(); // (1)
                     const bool alive0 = (s_mask[0] >> lane) & 1ull;
                     double wx, wy;
-                    wall_force(alive0, s_px[lane], s_py[lane], wx, wy);
-                    s_W[0][lane] = wx;
-                    s_W[1][lane] = wy;
+                    const double2 pos_ = s_pos[lane];
+                    wall_force(alive0, pos_.x, pos_.y, wx, wy);
+                    s_W[lane] = make_double2(wx, wy);
                     FA_WG_BARRIER(); // (2)
                     FA_WG_BARRIER(); // (3)
                 }
@@ -476,14 +477,16 @@ __global__ __launch_bounds__(NW * FA_WAVE) void fa_step_kernel(FaStepArgs a) {
                 u1 *= c.accel;
                 const unsigned long long grp_alive0 = (s_mask[0] >> gbase) & grp_mask;
                 const bool alive0 = (grp_alive0 >> i) & 1ull;
-                const double px = s_px[lane], py = s_py[lane];
+                const double2 pos_ = s_pos[lane];
+                const double px = pos_.x, py = pos_.y;
                 // candidate pair force against every partner alive BEFORE the laser (a partner the
                 // laser kills this step is masked out below); exactly +0.0 when out of range, so
                 // that adding it is a no-op (F is never -0.0)
                 double fxj[NT], fyj[NT];
 #pragma unroll
                 for (int j = 0; j < NT; ++j) {
-                    const double dx = px - s_px[gbase + j], dy = py - s_py[gbase + j];
+                    const double2 q_ = s_pos[gbase + j];
+                    const double dx = px - q_.x, dy = py - q_.y;
                     const double d2 = dx * dx + dy * dy;
                     fxj[j] = 0.0;
                     fyj[j] = 0.0;
@@ -495,7 +498,7 @@ __global__ __launch_bounds__(NW * FA_WAVE) void fa_step_kernel(FaStepArgs a) {
                 if (!THREE) wall_force(alive0, px, py, wx, wy);
                 FA_WG_BARRIER(); // (2) the alive-after-laser ballot is published
                 const unsigned long long grp_alive1 = (s_mask[1] >> gbase) & grp_mask;
-                if (THREE) { wx = s_W[0][lane]; wy = s_W[1][lane]; }
+                if (THREE) { const double2 w_ = s_W[lane]; wx = w_.x; wy = w_.y; }
                 double Fx = u0 + 0.0, Fy = u1 + 0.0;   // core.py:221-228
 #pragma unroll
                 for (int j = 0; j < NT; ++j)
@@ -505,8 +508,7 @@ __global__ __launch_bounds__(NW * FA_WAVE) void fa_step_kernel(FaStepArgs a) {
                     }
                 Fx = wx + Fx;
                 Fy = wy + Fy;
-                s_F[0][lane] = Fx;
-                s_F[1][lane] = Fy;
+                s_F[lane] = make_double2(Fx, Fy);
                 FA_WG_BARRIER(); // (3) forces are published
             }
             return;
@@ -569,8 +571,7 @@ __global__ __launch_bounds__(NW * FA_WAVE) void fa_step_kernel(FaStepArgs a) {
             u1 *= c.accel;
 
             // ---- stage positions + the shooters' heading sin/cos in LDS (core.py:373-382) ------------
-            s_px[lane] = px;
-            s_py[lane] = py;
+            s_pos[lane] = make_double2(px, py);
             if constexpr (TWO) {
                 const unsigned long long alive0_b = __ballot(alive0);
                 if (lane == 0) s_mask[0] = alive0_b;
@@ -580,8 +581,7 @@ __global__ __launch_bounds__(NW * FA_WAVE) void fa_step_kernel(FaStepArgs a) {
             if (shooter) { // the laser test needs the shooter's position and sin/cos of its heading (fa_wedge)
                 double sn, cs;
                 sincos_heading(ang, sn, cs);
-                s_cs[lane] = cs;
-                s_sn[lane] = sn;
+                s_trig[lane] = make_double2(cs, sn);
             }
             const unsigned long long shooters_b = __ballot(shooter);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -598,8 +598,9 @@ __global__ __launch_bounds__(NW * FA_WAVE) void fa_step_kernel(FaStepArgs a) {
             if constexpr (HOIST) {
 #pragma unroll
                 for (int j = 0; j < NT; ++j) {
-                    dxs[j] = px - s_px[gbase + j];
-                    dys[j] = py - s_py[gbase + j];
+                    const double2 q_ = s_pos[gbase + j];
+                    dxs[j] = px - q_.x;
+                    dys[j] = py - q_.y;
                     d2s[j] = dxs[j] * dxs[j] + dys[j] * dys[j];
                 }
             }
@@ -622,7 +623,8 @@ __global__ __launch_bounds__(NW * FA_WAVE) void fa_step_kernel(FaStepArgs a) {
 #pragma unroll
                     for (int k = 0; k < KT; ++k) {
                         const int j = gbase + opp0 + (k < n_opp ? k : 0);
-                        tr[k][0] = s_px[j]; tr[k][1] = s_py[j]; tr[k][2] = s_cs[j]; tr[k][3] = s_sn[j];
+                        const double2 q_ = s_pos[j], tg_ = s_trig[j];
+                        tr[k][0] = q_.x; tr[k][1] = q_.y; tr[k][2] = tg_.x; tr[k][3] = tg_.y;
                     }
 #pragma unroll
                     for (int k = 0; k < KT; ++k) {
@@ -650,7 +652,8 @@ __global__ __launch_bounds__(NW * FA_WAVE) void fa_step_kernel(FaStepArgs a) {
                         bool h = false;
                         if (alive0 && k < n_opp && ((shooters_b >> j) & 1ull)) {
                             double u, lhs, rhs;
-                            fa_wedge(c.agent_size, c.cos_hw, c.sin_hw, px, py, s_px[j], s_py[j], s_cs[j], s_sn[j], u, lhs, rhs);
+                            const double2 q_ = s_pos[j], tg_ = s_trig[j];
+                            fa_wedge(c.agent_size, c.cos_hw, c.sin_hw, px, py, q_.x, q_.y, tg_.x, tg_.y, u, lhs, rhs);
                             h = (u <= c.shoot_far) & (lhs <= rhs);
                         }
                         const unsigned long long hb = __ballot(h);
@@ -676,8 +679,9 @@ __global__ __launch_bounds__(NW * FA_WAVE) void fa_step_kernel(FaStepArgs a) {
             if (alive1) {
                 double Fx = u0 + 0.0, Fy = u1 + 0.0;      // core.py:221-228
                 if constexpr (TWO) {
-                    Fx = s_F[0][lane];
-                    Fy = s_F[1][lane];
+                    const double2 f_ = s_F[lane];
+                    Fx = f_.x;
+                    Fy = f_.y;
                 } else {
                 // core.py:231-243 + :440-456.  Reference order: pairs (a,b), a<b, lexicographic;
                 // for agent i that is partner j ascending, with f_i = +f for j>i and
@@ -687,8 +691,9 @@ __global__ __launch_bounds__(NW * FA_WAVE) void fa_step_kernel(FaStepArgs a) {
                     if constexpr (!HOIST) {
 #pragma unroll
                         for (int j = 0; j < NT; ++j) {
-                            dxs[j] = px - s_px[gbase + j];
-                            dys[j] = py - s_py[gbase + j];
+                            const double2 q_ = s_pos[gbase + j];
+                            dxs[j] = px - q_.x;
+                            dys[j] = py - q_.y;
                             d2s[j] = dxs[j] * dxs[j] + dys[j] * dys[j];
                         }
                     }
@@ -707,7 +712,8 @@ __global__ __launch_bounds__(NW * FA_WAVE) void fa_step_kernel(FaStepArgs a) {
                 } else {
                     for (int j = 0; j < N; ++j) {
                         if (j == i || !((grp_alive1 >> j) & 1ull)) continue;
-                        const double dx = px - s_px[gbase + j], dy = py - s_py[gbase + j];
+                        const double2 q_ = s_pos[gbase + j];
+                        const double dx = px - q_.x, dy = py - q_.y;
                         const double d2 = dx * dx + dy * dy;
                         if (d2 > c.contact_skip_d2) continue; // exact skip, see above
                         double fx, fy;
