@@ -1821,19 +1821,20 @@ __global__ __launch_bounds__(4 * FA_WAVE, 2) void fa_step_chain_kernel(FaStepArg
     const int ns = a.nsteps;
 
     // buffer s & 1: state at the start of step s and the by-products of step s-1, published by the chain wave before P(s-1)
-    __shared__ double s_px[2][FA_WAVE], s_py[2][FA_WAVE], s_ang[2][FA_WAVE];
-    __shared__ double s_vx[2][FA_WAVE], s_vy[2][FA_WAVE], s_dd[2][FA_WAVE];
+    __shared__ double2 s_pos[2][FA_WAVE], s_vel[2][FA_WAVE]; // ((x, y) pairs side by side, see fa_step_pipe_kernel)
+    __shared__ double s_ang[2][FA_WAVE], s_dd[2][FA_WAVE];
     __shared__ unsigned long long s_mask[2][2];          // [0] alive at the step's start, [1] done of the step before
-    __shared__ double s_trig[2][2][FA_WAVE];             // [step parity][cos, sin][lane]: wave 1 writes and reads it
+    __shared__ double2 s_trig[2][FA_WAVE];               // [step parity][lane] = (cos, sin): wave 1 writes and reads it
     __shared__ int s_act[FA_ACT_BATCH][FA_WAVE];
     // the hand-offs to the chain wave: written and re-read without a barrier in between.  NOT volatile -- the backend
     // waits for every volatile LDS access on its own (lgkmcnt(0) each: 250 us) -- but fenced for the COMPILER by
     // FA_ORDER(): data before tag on the writing side, tags before data on the reading side; the hardware keeps a wave's
     // DS operations in order.
     __shared__ unsigned long long s_las[3][4];  // [step % 3][alive after the laser, hit, was hit]     (wave 1)
-    __shared__ double s_W[2][FA_WAVE], s_U[3][FA_WAVE];       // wall force, decoded action            (wave 2)
-    __shared__ double s_rp[2][FA_WAVE];                        // positions of the lane's next reset   (wave 2)
-    __shared__ double s_fmx[N][FA_WAVE], s_fmy[N][FA_WAVE];   // [partner j][lane]: pair force on the lane's agent
+    __shared__ double2 s_W[FA_WAVE], s_U[FA_WAVE];             // wall force, decoded action (x, y)     (wave 2)
+    __shared__ double s_rot[FA_WAVE];                          // ... and its rotation
+    __shared__ double2 s_rp[FA_WAVE];                          // position of the lane's next reset     (wave 2)
+    __shared__ double2 s_fm[N][FA_WAVE];                       // [partner j][lane]: pair force on the lane's agent
     __shared__ int s_tag[4];                                   // [wave]: the step its hand-off is complete for; [0]: the chain
                                                                // wave's -- the step whose start state is published
 #define FA_ORDER() asm volatile("" ::: "memory")
@@ -1869,8 +1870,7 @@ __global__ __launch_bounds__(4 * FA_WAVE, 2) void fa_step_chain_kernel(FaStepArg
             sincos_heading(c.ang_attacker, sn_a, cs_a);
         }
         const double cs_ro = is_att ? cs_g : cs_a, sn_ro = is_att ? sn_g : sn_a;   // the opponents after a reset
-        s_trig[0][0][lane] = cs;
-        s_trig[0][1][lane] = sn;
+        s_trig[0][lane] = make_double2(cs, sn);
         double k_size = c.agent_size, k_far = c.shoot_far, k_chw = c.cos_hw, k_shw = c.sin_hw;
         asm volatile("" : "+v"(k_size), "+v"(k_far), "+v"(k_chw), "+v"(k_shw));
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(nh), "+v"(nwh));
@@ -1884,13 +1884,15 @@ __global__ __launch_bounds__(4 * FA_WAVE, 2) void fa_step_chain_kernel(FaStepArg
             const int act = s_act[s & (FA_ACT_BATCH - 1)][lane];
             const unsigned long long alive0_m = s_mask[b][0];
             const unsigned long long reset_prev_m = (s > 0 && a.auto_reset != 0) ? s_mask[b][1] : 0ull;
-            const double px = s_px[b][lane], py = s_py[b][lane], ang = s_ang[b][lane];
+            const double2 pos_ = s_pos[b][lane];
+            const double px = pos_.x, py = pos_.y, ang = s_ang[b][lane];
             double oqx[KT], oqy[KT], ocs[KT], osn[KT];
 #pragma unroll
             for (int k = 0; k < KT; ++k) {
                 const int j = gbase + opp0 + (k < n_opp ? k : 0);
-                oqx[k] = s_px[b][j]; oqy[k] = s_py[b][j];
-                ocs[k] = s_trig[b][0][j]; osn[k] = s_trig[b][1][j];
+                const double2 q_ = s_pos[b][j], tg_ = s_trig[b][j];
+                oqx[k] = q_.x; oqy[k] = q_.y;
+                ocs[k] = tg_.x; osn[k] = tg_.y;
             }
             if (__builtin_expect(reset_prev_m != 0ull, 0)) { // the env was reset at the end of the step before
                 const bool rp = fa_lanes(reset_prev_m);
@@ -1946,8 +1948,7 @@ __global__ __launch_bounds__(4 * FA_WAVE, 2) void fa_step_chain_kernel(FaStepArg
                 if (act == 5) rot = c.rot_pos;
                 if (act == 6) rot = c.rot_neg;
                 sincos_heading(ang + rot, sn, cs);
-                s_trig[(s + 1) & 1][0][lane] = cs;
-                s_trig[(s + 1) & 1][1][lane] = sn;
+                s_trig[(s + 1) & 1][lane] = make_double2(cs, sn);
             }
             FA_TICK(11)
             if (!FA_CHAIN_NOBAR) FA_WG_BARRIER(); // P(s)
@@ -2026,8 +2027,7 @@ __global__ __launch_bounds__(4 * FA_WAVE, 2) void fa_step_chain_kernel(FaStepArg
             wait_words();
             draw_eval(a, e, i, is_att, mwa, rdA);
             draw_eval(a, e, i, is_att, mwb, rdB);
-            s_rp[0][lane] = rdA.px;
-            s_rp[1][lane] = rdA.py;
+            s_rp[lane] = make_double2(rdA.px, rdA.py);
         }
         const unsigned long long lane0_m = FA_M_EQ_U(lane, 0);
         FA_TICK_INIT
@@ -2043,13 +2043,13 @@ __global__ __launch_bounds__(4 * FA_WAVE, 2) void fa_step_chain_kernel(FaStepArg
                 if (need_b) {
                     draw_commit(a, e, i, N, rdA);
                     rdA = rdB;
-                    s_rp[0][lane] = rdA.px;
-                    s_rp[1][lane] = rdA.py;
+                    s_rp[lane] = make_double2(rdA.px, rdA.py);
                 }
             }
             const int act = s_act[s & (FA_ACT_BATCH - 1)][lane];
             const bool alive0 = (s_mask[b][0] >> lane) & 1ull;
-            double px = s_px[b][lane], py = s_py[b][lane];
+            const double2 pos_ = s_pos[b][lane];
+            double px = pos_.x, py = pos_.y;
             asm volatile("" : "+v"(px), "+v"(py));
             // fortattack.py:253-263,:289 _set_action (F starts as u + 0.0, core.py:221-228)
             double u0 = 0.0, u1 = 0.0, rot = 0.0;
@@ -2059,13 +2059,11 @@ __global__ __launch_bounds__(4 * FA_WAVE, 2) void fa_step_chain_kernel(FaStepArg
             if (act == 4) u1 = -1.0;
             if (act == 5) rot = c.rot_pos;
             if (act == 6) rot = c.rot_neg;
-            s_U[0][lane] = u0 * c.accel + 0.0;
-            s_U[1][lane] = u1 * c.accel + 0.0;
-            s_U[2][lane] = rot;
+            s_U[lane] = make_double2(u0 * c.accel + 0.0, u1 * c.accel + 0.0);
+            s_rot[lane] = rot;
             double wx = 0.0, wy = 0.0;
             fa_wall_force_flat(c, px, py, wx, wy); // core.py:246-252 + :459-472
-            s_W[0][lane] = alive0 ? wx : 0.0;
-            s_W[1][lane] = alive0 ? wy : 0.0;
+            s_W[lane] = make_double2(alive0 ? wx : 0.0, alive0 ? wy : 0.0);
             FA_ORDER();
             if (fa_lanes(lane0_m)) s_tag[2] = s;   // behind the wave's data writes: in order
             FA_ORDER();
@@ -2102,8 +2100,9 @@ __global__ __launch_bounds__(4 * FA_WAVE, 2) void fa_step_chain_kernel(FaStepArg
         bool alive0_prev = false;
         auto emit_obs = [&](int bo) { // the state after the step / reset (fortattack_env_v1.py:238)
             const bool alive_new = (s_mask[bo][0] >> lane) & 1ull;
-            const double px = s_px[bo][lane], py = s_py[bo][lane], ang = s_ang[bo][lane];
-            const double vx = s_vx[bo][lane], vy = s_vy[bo][lane];
+            const double2 pos_ = s_pos[bo][lane], vel_ = s_vel[bo][lane];
+            const double px = pos_.x, py = pos_.y, ang = s_ang[bo][lane];
+            const double vx = vel_.x, vy = vel_.y;
             fa_store_obs((COLLECT || a.obs32) ? p_obs : nullptr, (!COLLECT && a.obs64) ? a.obs64 + row6 : nullptr, alive_new,
                          px, py, ang, vx, vy);
             p_obs += EN * 6; row6 += (long long)EN * 6;
@@ -2138,14 +2137,16 @@ __global__ __launch_bounds__(4 * FA_WAVE, 2) void fa_step_chain_kernel(FaStepArg
             FA_TICK(14)
             const unsigned long long grp_alive0 = (s_mask[b][0] >> gbase) & grp_mask;
             const bool alive0 = (grp_alive0 >> i) & 1ull;
-            const double px = s_px[b][lane], py = s_py[b][lane];
+            const double2 pos_ = s_pos[b][lane];
+            const double px = pos_.x, py = pos_.y;
             double qx[NOFF], qy[NOFF];
 #pragma unroll
             for (int d = DF + 1; d <= NOFF; ++d) {
                 int j = i + d;
                 j = j >= N ? j - N : j;
-                qx[d - 1] = s_px[b][gbase + j];
-                qy[d - 1] = s_py[b][gbase + j];
+                const double2 q_ = s_pos[b][gbase + j];
+                qx[d - 1] = q_.x;
+                qy[d - 1] = q_.y;
             }
 #pragma unroll
             for (int d = DF + 1; d <= NOFF; ++d) {
@@ -2161,10 +2162,8 @@ __global__ __launch_bounds__(4 * FA_WAVE, 2) void fa_step_chain_kernel(FaStepArg
                     near = true;
                 }
                 if (mine) {
-                    s_fmx[j][lane] = fxv;               // on agent i from partner j
-                    s_fmy[j][lane] = fyv;
-                    s_fmx[i][gbase + j] = near ? -fxv : 0.0; // on agent j from partner i: the exact negative
-                    s_fmy[i][gbase + j] = near ? -fyv : 0.0;
+                    s_fm[j][lane] = make_double2(fxv, fyv);                                   // on agent i from partner j
+                    s_fm[i][gbase + j] = make_double2(near ? -fxv : 0.0, near ? -fyv : 0.0); // on agent j from partner i: the exact negative
                 }
             }
             FA_ORDER();
@@ -2177,8 +2176,7 @@ __global__ __launch_bounds__(4 * FA_WAVE, 2) void fa_step_chain_kernel(FaStepArg
                 if (act == 5) rot = c.rot_pos;
                 if (act == 6) rot = c.rot_neg;
                 sincos_heading(s_ang[b][lane] + rot, sn, cs);
-                s_trig[(s + 1) & 1][0][lane] = cs;
-                s_trig[(s + 1) & 1][1][lane] = sn;
+                s_trig[(s + 1) & 1][lane] = make_double2(cs, sn);
             }
             if (s > 0) {
                 emit_obs(b);
@@ -2214,16 +2212,14 @@ __global__ __launch_bounds__(4 * FA_WAVE, 2) void fa_step_chain_kernel(FaStepArg
 #pragma unroll
     for (int k = 0; k < FA_ACT_BATCH; ++k)
         av[k] = (FA_ACT_BATCH + k < ns) ? (int)act_ptr[(int64_t)(FA_ACT_BATCH + k) * a.as_t] : 0;
-    s_px[0][lane] = px;
-    s_py[0][lane] = py;
+    s_pos[0][lane] = make_double2(px, py);
     s_ang[0][lane] = ang;
     if (fa_lanes(lane0_m)) {
         s_mask[0][0] = alive_m;
         s_mask[0][1] = 0ull;
         s_tag[0] = 0; s_tag[1] = -1; s_tag[2] = -1; s_tag[3] = -1;
     }
-    s_fmx[i][lane] = 0.0; // an agent exerts no force on itself: nobody writes the diagonal
-    s_fmy[i][lane] = 0.0;
+    s_fm[i][lane] = make_double2(0.0, 0.0); // an agent exerts no force on itself: nobody writes the diagonal
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -2232,8 +2228,9 @@ __global__ __launch_bounds__(4 * FA_WAVE, 2) void fa_step_chain_kernel(FaStepArg
     for (int d = 1; d <= DF; ++d) {
         int j = i + d;
         j = j >= N ? j - N : j;
-        qx[d - 1] = s_px[0][gbase + j];
-        qy[d - 1] = s_py[0][gbase + j];
+        const double2 q_ = s_pos[0][gbase + j];
+        qx[d - 1] = q_.x;
+        qy[d - 1] = q_.y;
     }
     FA_WG_BARRIER(); // P(-1)
 
@@ -2264,10 +2261,8 @@ __global__ __launch_bounds__(4 * FA_WAVE, 2) void fa_step_chain_kernel(FaStepArg
                 near = true;
             }
             if (mine) {
-                s_fmx[j][lane] = fxv;
-                s_fmy[j][lane] = fyv;
-                s_fmx[i][gbase + j] = near ? -fxv : 0.0;
-                s_fmy[i][gbase + j] = near ? -fyv : 0.0;
+                s_fm[j][lane] = make_double2(fxv, fyv);
+                s_fm[i][gbase + j] = make_double2(near ? -fxv : 0.0, near ? -fyv : 0.0);
             }
         }
         FA_TICK(0)
@@ -2279,10 +2274,11 @@ __global__ __launch_bounds__(4 * FA_WAVE, 2) void fa_step_chain_kernel(FaStepArg
             const int t1 = s_tag[1], t2 = s_tag[2], t3 = s_tag[3];
             FA_ORDER();
             alive1_m = s_las[s % 3][0];
-            wx = s_W[0][lane]; wy = s_W[1][lane];
-            u0 = s_U[0][lane]; u1 = s_U[1][lane]; rot = s_U[2][lane];
+            const double2 w_ = s_W[lane], u_ = s_U[lane];
+            wx = w_.x; wy = w_.y;
+            u0 = u_.x; u1 = u_.y; rot = s_rot[lane];
 #pragma unroll
-            for (int j = 0; j < N; ++j) { fmx[j] = s_fmx[j][lane]; fmy[j] = s_fmy[j][lane]; }
+            for (int j = 0; j < N; ++j) { const double2 f_ = s_fm[j][lane]; fmx[j] = f_.x; fmy[j] = f_.y; }
             FA_ORDER();
             const bool ok = (t1 == s) & (t2 == s) & (t3 == s);
             if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
@@ -2313,7 +2309,7 @@ __global__ __launch_bounds__(4 * FA_WAVE, 2) void fa_step_chain_kernel(FaStepArg
                     double Gx = u0, Gy = u1;
 #pragma unroll
                     for (int j = 0; j < N; ++j)
-                        if ((ga1 >> j) & 1u) { Gx = s_fmx[j][lane] + Gx; Gy = s_fmy[j][lane] + Gy; }
+                        if ((ga1 >> j) & 1u) { const double2 f_ = s_fm[j][lane]; Gx = f_.x + Gx; Gy = f_.y + Gy; }
                     Gx = wx + Gx;
                     Gy = wy + Gy;
                     vx = vdx + Gx * k_dt;
@@ -2343,7 +2339,8 @@ __global__ __launch_bounds__(4 * FA_WAVE, 2) void fa_step_chain_kernel(FaStepArg
         dirty_m |= alive0_m;
         // ---- fortattack_env_v1.py:47-75 reset_world (prevDist is NOT reset: quirk Q1) ------------------------------
         if (__builtin_expect(reset_m != 0ull, 0)) {
-            const double rpx = s_rp[0][lane], rpy = s_rp[1][lane];
+            const double2 rp_ = s_rp[lane];
+            const double rpx = rp_.x, rpy = rp_.y;
             if (fa_lanes(reset_m)) {
                 px = rpx; py = rpy; vx = 0.0; vy = 0.0;
                 ang = k_ang_r;
@@ -2353,11 +2350,9 @@ __global__ __launch_bounds__(4 * FA_WAVE, 2) void fa_step_chain_kernel(FaStepArg
             dirty_m |= reset_m;
         }
         // ---- publish state(s+1) and the by-products of step s -------------------------------------------------------
-        s_px[nb][lane] = px;
-        s_py[nb][lane] = py;
+        s_pos[nb][lane] = make_double2(px, py);
         s_ang[nb][lane] = ang;
-        s_vx[nb][lane] = vx;
-        s_vy[nb][lane] = vy;
+        s_vel[nb][lane] = make_double2(vx, vy);
         s_dd[nb][lane] = dd2;
         if (fa_lanes(lane0_m)) {
             s_mask[nb][0] = alive_m;
@@ -2373,8 +2368,9 @@ __global__ __launch_bounds__(4 * FA_WAVE, 2) void fa_step_chain_kernel(FaStepArg
         for (int d = 1; d <= DF; ++d) {
             int j = i + d;
             j = j >= N ? j - N : j;
-            qx[d - 1] = s_px[nb][gbase + j];
-            qy[d - 1] = s_py[nb][gbase + j];
+            const double2 q_ = s_pos[nb][gbase + j];
+            qx[d - 1] = q_.x;
+            qy[d - 1] = q_.y;
         }
         if (FA_CHAIN_NOBAR) { // state(s+1) is complete: tag behind the data
             FA_ORDER();
