@@ -16,6 +16,8 @@ def one(E, iters, G=3, A=3):
     sys.path.insert(0, ROOT)
     import torch
     import emergent_multiagent_strategies_amd as fa
+    if os.environ.get("FA_AB_LIB"):   # a tools/build_variant.py library instead of the product
+        fa._lib._build.LIB = os.path.join(ROOT, "tools", "_build", "lib_%s.so" % os.environ["FA_AB_LIB"])
     T = 128
     N = G + A
     eng = fa.BatchedFortAttack(E, G, A, 100, base_seed=0)
@@ -35,7 +37,7 @@ def one(E, iters, G=3, A=3):
 
     forms = {"gae_only": lambda: eng.gae(0.99, 0.95), "old": old, "moments": lambda: eng.gae_moments(0.99, 0.95),
              "fused": lambda: eng.gae_normalize(0.99, 0.95, out=adv)}
-    out = {"separate": os.environ.get("FA_GAE_MOMENTS_SEPARATE", "0"), "E": E, "team": G}
+    out = {"lib": os.environ.get("FA_AB_LIB", "product"), "separate": os.environ.get("FA_GAE_MOMENTS_SEPARATE", "0"), "E": E, "team": G}
     for name, fn in forms.items():
         for with_rollout in (False, True):
             def call():
