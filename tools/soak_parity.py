@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """One-off soak (run on the GPU box): the fused pipelined step kernel against the CPU oracle over many
-rollouts of shoot-heavy random actions -- counts differing flags / fp64 values.  usage: soak_parity.py [rollouts] [E] [G] [A]"""
+rollouts of shoot-heavy random actions -- counts differing flags / fp64 values.  usage: [FA_SOAK_KERNEL=<pipe|chain|...>] soak_parity.py [rollouts] [E] [G] [A]"""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -15,7 +15,7 @@ T, max_t = 128, 60
 N = G + A
 rng = np.random.RandomState(2026)
 orc = OracleEnv(E, G, A, max_t, base_seed=77)
-eng = fa.BatchedFortAttack(E, G, A, max_t, base_seed=77)
+eng = fa.BatchedFortAttack(E, G, A, max_t, base_seed=77, step_kernel=os.environ.get('FA_SOAK_KERNEL', 'auto'))
 o0 = torch.empty((E, N, 6), dtype=torch.float64, device="cuda")
 eng.reset(obs_f64=o0)
 assert np.array_equal(o0.cpu().numpy(), orc.reset())
