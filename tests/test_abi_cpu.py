@@ -113,3 +113,12 @@ def test_product_package_never_touches_the_oracle():
            "print(any('oracle' in k for k in sys.modules))"
     out = subprocess.check_output([sys.executable, "-c", code], cwd=ROOT, text=True)
     assert out.strip() == "False"
+
+
+def test_step_kernel_names_match_the_header_enum(fa):
+    """fa_config.step_kernel: the binding's names are the header's FA_KERNEL_* values (a build pinned by name in the tests and
+    the A/B tools is the one the library dispatches on)."""
+    text = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+    enum = dict((k.lower(), int(v)) for k, v in re.findall(r"FA_KERNEL_([A-Z0-9]+)\s*=\s*(\d+)", text))
+    assert enum and enum == fa._lib.STEP_KERNELS
+    assert sorted(enum.values()) == list(range(len(enum)))            # dense: fa_create range-checks AUTO .. the last one
