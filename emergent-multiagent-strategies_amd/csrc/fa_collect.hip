@@ -449,6 +449,19 @@ __global__ __launch_bounds__(512) void fa_gae_mom_norm_kernel(const double *__re
     __syncthreads();
     if (vec) {
         float4 *o4 = reinterpret_cast<float4 *>(out);
+#ifndef FA_NORM_PLAIN_STORES
+        // write-through (sc1) 16-byte stores: nothing of `out` stays dirty in L2 for the kernel boundary behind this launch to
+        // flush (29.4 against 30.1 us for the two launches, 177.4 against 178.4 behind the rollout; 16-byte sc1 stores cost what
+        // plain ones do -- the 8-byte observation rows of the step kernel as sc1 stores: slower, 180.0 against 177.8)
+        typedef int v4i __attribute__((ext_vector_type(4)));
+        const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(out, 0, (int)(total * 4), 0x00020000);
+        auto st4 = [&](long long q, const float4 &v) {
+            v4i w = {__builtin_bit_cast(int, v.x), __builtin_bit_cast(int, v.y), __builtin_bit_cast(int, v.z), __builtin_bit_cast(int, v.w)};
+            __builtin_amdgcn_raw_buffer_store_b128(w, rs_out, (int)(q * 16), 0, 16);
+        };
+#else
+        auto st4 = [&](long long q, const float4 &v) { o4[q] = v; };
+#endif
         for (long long q0 = gid; q0 < quads; q0 += 2 * stride) {
             const long long q1 = q0 + stride;
             const bool two = q1 < quads;
@@ -465,8 +478,8 @@ __global__ __launch_bounds__(512) void fa_gae_mom_norm_kernel(const double *__re
                 o.w = (r.w - v.w - s_mean[i]) / s_den[i];
                 return o;
             };
-            o4[q0] = norm4(ra, va, q0);
-            if (two) o4[q1] = norm4(rb, vb, q1);
+            st4(q0, norm4(ra, va, q0));
+            if (two) st4(q1, norm4(rb, vb, q1));
         }
         for (long long k = quads * 4 + gid; k < total; k += stride) {
             const int i = (int)(k % N);
