@@ -31,9 +31,11 @@ hipError_t fa_launch_gae_mom_final(const double *partial, int nblocks, const flo
                                    double *std_out, hipStream_t st);
 hipError_t fa_launch_gae_mom_norm(const double *partial, int nblocks, const float *rewards, const float *value_preds,
                                   const float *masks, const float *returns, int T, int E, int N, double gamma, float *out,
-                                  double *moments_out, double *mean_out, double *std_out, int grid, hipStream_t st);
+                                  double *moments_out, double *mean_out, double *std_out, int grid, int piv_from_returns,
+                                  hipStream_t st);
 hipError_t fa_launch_adv_onepass(const float *returns, const float *value_preds, long long rows, int N, double *partial,
-                                 int nblocks, double *moments_out, double *mean_out, double *std_out, hipStream_t st);
+                                 int nblocks, double *moments_out, double *mean_out, double *std_out, hipStream_t st,
+                                 bool final = true);
 hipError_t fa_launch_adv_stats(int pass, const float *returns, const float *value_preds, const double *mean,
                                long long rows, int N, double *partial, int nblocks, double *stats,
                                double *derived, hipStream_t st);
@@ -482,16 +484,21 @@ int fa_gae_normalize(fa_env *env, double gamma, double tau, float *adv_out, doub
         FA_HIP(fa_launch_gae_mom(st.rewards, st.value_preds, st.masks, st.returns, st.done, st.num_steps, env->cfg.num_envs,
                                  env->N, gamma, tau, env->adv_partial, nb, s));
         FA_HIP(fa_launch_gae_mom_norm(env->adv_partial, nb, st.rewards, st.value_preds, st.masks, st.returns, st.num_steps,
-                                      env->cfg.num_envs, env->N, gamma, adv_out, moments_out, mean_out, std_out, 0, s));
+                                      env->cfg.num_envs, env->N, gamma, adv_out, moments_out, mean_out, std_out, 0, 0, s));
         return FA_OK;
     }
-    // the separate kernels: the normalisation needs mean / std on the device, in the handle's scratch when the caller
-    // asked for neither
-    double *mean = mean_out ? mean_out : env->adv_stats + 3 * FA_MAX_AGENTS;
-    double *sd = std_out ? std_out : env->adv_stats + 4 * FA_MAX_AGENTS;
-    const int rc = fa_gae_moments(env, gamma, tau, moments_out, mean, sd, stream);
-    if (rc != FA_OK) return rc;
-    return fa_adv_normalize(env, mean, sd, adv_out, stream);
+    // beyond the fused scan: fa_gae, the one-pass sweep (at most 512 workgroups of partials), and the same fold +
+    // normalisation launch on its partials -- three launches instead of four, nothing dirty left behind the last one
+    FA_HIP(fa_launch_gae(st.rewards, st.value_preds, st.masks, st.returns, st.done, st.num_steps, env->cfg.num_envs, env->N, gamma,
+                         tau, s));
+    const long long rows = (long long)st.num_steps * env->cfg.num_envs;
+    long long want = (rows + 2047) / 2048;   // as fa_gae_moments
+    const int nblocks = (int)(want < 512 ? (want < 1 ? 1 : want) : 512);
+    FA_HIP(fa_launch_adv_onepass(st.returns, st.value_preds, rows, env->N, env->adv_partial, nblocks, nullptr, nullptr, nullptr, s,
+                                 false));
+    FA_HIP(fa_launch_gae_mom_norm(env->adv_partial, nblocks, st.rewards, st.value_preds, st.masks, st.returns, st.num_steps,
+                                  env->cfg.num_envs, env->N, gamma, adv_out, moments_out, mean_out, std_out, 0, 1, s));
+    return FA_OK;
 }
 
 int fa_adv_moments_onepass(fa_env *env, double *moments_out, double *mean_out, double *std_out, void *stream) {

@@ -416,7 +416,9 @@ __global__ __launch_bounds__(512) void fa_gae_mom_norm_kernel(const double *__re
                                                               const float *__restrict__ returns, int T, long long EN, float g32,
                                                               double n_rows, long long total, float *__restrict__ out,
                                                               double *__restrict__ moments_out, double *__restrict__ mean_out,
-                                                              double *__restrict__ std_out) {
+                                                              double *__restrict__ std_out, int piv_from_returns) {
+    // piv_from_returns: the partials are fa_adv_onepass[_vec]_kernel's (shapes beyond the fused scan), whose pivot is agent i's
+    // advantage in row 0 AFTER the scan; same {S, Q} layout, same fold as fa_adv_onepass_final_kernel: same bits
     __shared__ float s_mean[FA_MAX_AGENTS_DEV], s_den[FA_MAX_AGENTS_DEV];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long long stride = (long long)gridDim.x * blockDim.x;
@@ -432,7 +434,8 @@ __global__ __launch_bounds__(512) void fa_gae_mom_norm_kernel(const double *__re
         rb = r4[q1 < quads ? q1 : gid]; vb = v4[q1 < quads ? q1 : gid];
     }
     for (int i = wave; i < N; i += 8) { // eight waves: one agent each up to 4v4, one round trip
-        const double piv = (double)fa_gae_pivot(rewards, value_preds, masks, T, EN, i, g32);
+        const double piv = piv_from_returns ? (double)(returns[i] - value_preds[i])
+                                            : (double)fa_gae_pivot(rewards, value_preds, masks, T, EN, i, g32);
         double mean, m2;
         fa_gae_mom_fold(partial, nblocks, N, i, lane, n_rows, piv, mean, m2);
         const double sd = sqrt(m2 / (n_rows - 1.0));
@@ -454,10 +457,15 @@ __global__ __launch_bounds__(512) void fa_gae_mom_norm_kernel(const double *__re
         // flush (29.4 against 30.1 us for the two launches, 177.4 against 178.4 behind the rollout; 16-byte sc1 stores cost what
         // plain ones do -- the 8-byte observation rows of the step kernel as sc1 stores: slower, 180.0 against 177.8)
         typedef int v4i __attribute__((ext_vector_type(4)));
-        const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(out, 0, (int)(total * 4), 0x00020000);
+        const bool small = total * 4 < (1LL << 31); // buffer offsets are 32 bits
+        const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(out, 0, small ? (int)(total * 4) : 0, 0x00020000);
         auto st4 = [&](long long q, const float4 &v) {
-            v4i w = {__builtin_bit_cast(int, v.x), __builtin_bit_cast(int, v.y), __builtin_bit_cast(int, v.z), __builtin_bit_cast(int, v.w)};
-            __builtin_amdgcn_raw_buffer_store_b128(w, rs_out, (int)(q * 16), 0, 16);
+            if (small) {
+                v4i w = {__builtin_bit_cast(int, v.x), __builtin_bit_cast(int, v.y), __builtin_bit_cast(int, v.z), __builtin_bit_cast(int, v.w)};
+                __builtin_amdgcn_raw_buffer_store_b128(w, rs_out, (int)(q * 16), 0, 16);
+            } else {
+                o4[q] = v;
+            }
         };
 #else
         auto st4 = [&](long long q, const float4 &v) { o4[q] = v; };
@@ -914,7 +922,8 @@ hipError_t fa_launch_gae_mom_final(const double *partial, int nblocks, const flo
 }
 hipError_t fa_launch_gae_mom_norm(const double *partial, int nblocks, const float *rewards, const float *value_preds,
                                   const float *masks, const float *returns, int T, int E, int N, double gamma, float *out,
-                                  double *moments_out, double *mean_out, double *std_out, int grid, hipStream_t st) {
+                                  double *moments_out, double *mean_out, double *std_out, int grid, int piv_from_returns,
+                                  hipStream_t st) {
     const long long EN = (long long)E * N, total = (long long)T * EN;
     const double n_rows = (double)T * (double)E;
     if (grid <= 0) {
@@ -924,13 +933,16 @@ hipError_t fa_launch_gae_mom_norm(const double *partial, int nblocks, const floa
         grid = (int)(want < 512 ? (want < 1 ? 1 : want) : 512);
     }
     hipLaunchKernelGGL(fa_gae_mom_norm_kernel, dim3(grid), dim3(512), 0, st, partial, nblocks, N, rewards, value_preds, masks,
-                       returns, T, EN, (float)gamma, n_rows, total, out, moments_out, mean_out, std_out);
+                       returns, T, EN, (float)gamma, n_rows, total, out, moments_out, mean_out, std_out, piv_from_returns);
     return hipGetLastError();
 }
 
 // one-pass moments; `partial` must hold nblocks * N * 2 doubles, nblocks <= 64 * FA_ADV_FOLD
+// (final = false: the sweep alone -- its partials then go to fa_launch_gae_mom_norm(..., piv_from_returns = 1); needs nblocks <=
+// 64 * FA_GAEM_FOLD)
 hipError_t fa_launch_adv_onepass(const float *returns, const float *value_preds, long long rows, int N, double *partial,
-                                 int nblocks, double *moments_out, double *mean_out, double *std_out, hipStream_t st) {
+                                 int nblocks, double *moments_out, double *mean_out, double *std_out, hipStream_t st,
+                                 bool final = true) {
     const bool vec = (rows % 2 == 0) && ((((uintptr_t)returns | (uintptr_t)value_preds) & 15) == 0);
     if (nblocks > 64 * FA_ADV_FOLD) nblocks = 64 * FA_ADV_FOLD;
     if (vec && N == 6)
@@ -941,8 +953,9 @@ hipError_t fa_launch_adv_onepass(const float *returns, const float *value_preds,
                            partial);
     else
         hipLaunchKernelGGL(fa_adv_onepass_kernel, dim3(nblocks), dim3(256), 0, st, returns, value_preds, rows, N, partial);
-    hipLaunchKernelGGL(fa_adv_onepass_final_kernel, dim3(1), dim3(64 * N), 0, st, partial, nblocks, N, returns, value_preds,
-                       (double)rows, moments_out, mean_out, std_out);
+    if (final)
+        hipLaunchKernelGGL(fa_adv_onepass_final_kernel, dim3(1), dim3(64 * N), 0, st, partial, nblocks, N, returns, value_preds,
+                           (double)rows, moments_out, mean_out, std_out);
     return hipGetLastError();
 }
 

@@ -218,7 +218,8 @@ int fa_gae_moments(fa_env *env, double gamma, double tau, double *moments, doubl
  * the advantage statistics and the normalisation (A - mean) / (std + 1e-5) of rlcore/algo/ppo.py:121-124 -- in two
  * launches: the scan of fa_gae_moments, then ONE kernel in which every workgroup folds the moment partials (same order,
  * same bits everywhere) and normalises its share into adv_out, (T, E, N) float32; returns / value_preds are read once
- * more, nothing else.  Equals fa_gae_moments + fa_adv_normalize bit for bit; moments / mean / std_ (may be null) as
+ * more, nothing else (beyond 32 768 columns: fa_gae, the one-pass sweep and the same fold + normalisation launch on its
+ * partials -- three launches).  Equals fa_gae_moments + fa_adv_normalize bit for bit; moments / mean / std_ (may be null) as
  * there.  With several ranks the statistics are exchanged between the two halves: fa_gae_moments, the all-gather,
  * fa_adv_merge, fa_adv_normalize. */
 int fa_gae_normalize(fa_env *env, double gamma, double tau, float *adv_out, double *moments, double *mean, double *std_,
