@@ -385,7 +385,8 @@ def main():
     def exchange_and_normalise(mom, mean, std):
         if exchanging:
             dist.all_gather_into_tensor(gather_buf.view(-1), mom.view(-1))   # the path's one collective (RCCL / xGMI)
-            mean, std = eng.adv_merge(gather_buf)                  # Chan-Golub-LeVeque in rank order: same bits on every rank
+            eng.adv_merge_normalize(gather_buf, out=adv)           # Chan-Golub-LeVeque in rank order (same bits on every rank)
+            return                                                 # + the normalisation, one launch
         eng.adv_normalize(mean, std, out=adv)
 
     def collector_tail():

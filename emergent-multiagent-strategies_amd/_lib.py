@@ -96,6 +96,7 @@ EXPORTS = {
     "fa_adv_moments": (C.c_int, [c_p, c_p, c_p]),
     "fa_adv_merge": (C.c_int, [c_p, c_p, C.c_int32, c_p, c_p, c_p]),
     "fa_adv_normalize": (C.c_int, [c_p, c_p, c_p, c_p, c_p]),
+    "fa_adv_merge_normalize": (C.c_int, [c_p, c_p, C.c_int32, c_p, c_p, c_p, c_p]),
     "fa_after_update": (C.c_int, [c_p, c_p]),
     "fa_policy_act": (C.c_int, [c_p, C.POINTER(PolicyIO), c_p]),
     "fa_collect_act": (C.c_int, [c_p, C.c_int32, C.POINTER(PolicyIO), c_p]),

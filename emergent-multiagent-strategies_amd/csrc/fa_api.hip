@@ -33,6 +33,8 @@ hipError_t fa_launch_gae_mom_norm(const double *partial, int nblocks, const floa
                                   const float *masks, const float *returns, int T, int E, int N, double gamma, float *out,
                                   double *moments_out, double *mean_out, double *std_out, int grid, int piv_from_returns,
                                   hipStream_t st);
+hipError_t fa_launch_adv_merge_norm(const double *gathered, int W, int N, const float *returns, const float *value_preds,
+                                    long long total, float *out, double *mean_out, double *std_out, hipStream_t st);
 hipError_t fa_launch_adv_onepass(const float *returns, const float *value_preds, long long rows, int N, double *partial,
                                  int nblocks, double *moments_out, double *mean_out, double *std_out, hipStream_t st,
                                  bool final = true);
@@ -569,6 +571,19 @@ int fa_adv_merge(fa_env *env, const double *gathered, int32_t world, double *mea
     if (world < 1) return fail(FA_ERR_INVALID, "fa_adv_merge: world must be >= 1");
     DeviceGuard guard(env->cfg.device_id);
     FA_HIP(fa_launch_adv_merge(gathered, world, env->N, mean_out, std_out, static_cast<hipStream_t>(stream)));
+    return FA_OK;
+}
+
+int fa_adv_merge_normalize(fa_env *env, const double *gathered, int32_t world, float *adv_out, double *mean_out, double *std_out,
+                           void *stream) {
+    if (!env || !gathered || !adv_out) return fail(FA_ERR_INVALID, "fa_adv_merge_normalize: null argument");
+    if (world < 1) return fail(FA_ERR_INVALID, "fa_adv_merge_normalize: world must be >= 1");
+    if (!env->bound) return fail(FA_ERR_STATE, "fa_adv_merge_normalize: no storage bound");
+    DeviceGuard guard(env->cfg.device_id);
+    const fa_storage &st = env->st;
+    const long long total = (long long)st.num_steps * env->cfg.num_envs * env->N;
+    FA_HIP(fa_launch_adv_merge_norm(gathered, world, env->N, st.returns, st.value_preds, total, adv_out, mean_out, std_out,
+                                    static_cast<hipStream_t>(stream)));
     return FA_OK;
 }
 

@@ -416,7 +416,10 @@ __global__ __launch_bounds__(512) void fa_gae_mom_norm_kernel(const double *__re
                                                               const float *__restrict__ returns, int T, long long EN, float g32,
                                                               double n_rows, long long total, float *__restrict__ out,
                                                               double *__restrict__ moments_out, double *__restrict__ mean_out,
-                                                              double *__restrict__ std_out, int piv_from_returns) {
+                                                              double *__restrict__ std_out, int piv_from_returns,
+                                                              const double *__restrict__ gathered, int W) {
+    // gathered != null (several ranks): no fold -- every workgroup merges the W ranks' (n, mean, M2) triples as fa_adv_merge_kernel
+    // does (one lane per agent, rank order: same bits everywhere) and normalises with the result.
     // piv_from_returns: the partials are fa_adv_onepass[_vec]_kernel's (shapes beyond the fused scan), whose pivot is agent i's
     // advantage in row 0 AFTER the scan; same {S, Q} layout, same fold as fa_adv_onepass_final_kernel: same bits
     __shared__ float s_mean[FA_MAX_AGENTS_DEV], s_den[FA_MAX_AGENTS_DEV];
@@ -433,6 +436,28 @@ __global__ __launch_bounds__(512) void fa_gae_mom_norm_kernel(const double *__re
         ra = r4[gid]; va = v4[gid];
         rb = r4[q1 < quads ? q1 : gid]; vb = v4[q1 < quads ? q1 : gid];
     }
+    if (gathered) {
+        if ((int)threadIdx.x < N) {
+            const int i = threadIdx.x;
+            double n = 0.0, mean = 0.0, m2 = 0.0;
+            for (int r = 0; r < W; ++r) { // Chan-Golub-LeVeque in rank order: fa_adv_merge_kernel's loop
+                const double *g = gathered + ((long long)r * N + i) * 3;
+                const double nr = g[0], mr = g[1], m2r = g[2];
+                if (nr <= 0.0) continue;
+                const double nn = n + nr, delta = mr - mean;
+                mean += delta * (nr / nn);
+                m2 += m2r + delta * delta * (n * nr / nn);
+                n = nn;
+            }
+            const double sd = sqrt(m2 / (n - 1.0));
+            s_mean[i] = (float)mean;
+            s_den[i] = (float)sd + 1e-5f;
+            if (blockIdx.x == 0) {
+                if (mean_out) mean_out[i] = mean;
+                if (std_out) std_out[i] = sd;
+            }
+        }
+    } else
     for (int i = wave; i < N; i += 8) { // eight waves: one agent each up to 4v4, one round trip
         const double piv = piv_from_returns ? (double)(returns[i] - value_preds[i])
                                             : (double)fa_gae_pivot(rewards, value_preds, masks, T, EN, i, g32);
@@ -933,7 +958,18 @@ hipError_t fa_launch_gae_mom_norm(const double *partial, int nblocks, const floa
         grid = (int)(want < 512 ? (want < 1 ? 1 : want) : 512);
     }
     hipLaunchKernelGGL(fa_gae_mom_norm_kernel, dim3(grid), dim3(512), 0, st, partial, nblocks, N, rewards, value_preds, masks,
-                       returns, T, EN, (float)gamma, n_rows, total, out, moments_out, mean_out, std_out, piv_from_returns);
+                       returns, T, EN, (float)gamma, n_rows, total, out, moments_out, mean_out, std_out, piv_from_returns,
+                       (const double *)nullptr, 0);
+    return hipGetLastError();
+}
+// several ranks: fa_adv_merge + fa_adv_normalize as ONE launch (every workgroup merges the gathered triples itself)
+hipError_t fa_launch_adv_merge_norm(const double *gathered, int W, int N, const float *returns, const float *value_preds,
+                                    long long total, float *out, double *mean_out, double *std_out, hipStream_t st) {
+    long long want = (total / 4 + 1023) / 1024;
+    const int grid = (int)(want < 512 ? (want < 1 ? 1 : want) : 512);
+    hipLaunchKernelGGL(fa_gae_mom_norm_kernel, dim3(grid), dim3(512), 0, st, (const double *)nullptr, 0, N, (const float *)nullptr,
+                       value_preds, (const float *)nullptr, returns, 0, 0LL, 0.0f, 0.0, total, out, (double *)nullptr, mean_out,
+                       std_out, 0, gathered, W);
     return hipGetLastError();
 }
 

@@ -242,6 +242,17 @@ class BatchedFortAttack(object):
                    "fa_adv_normalize")
         return out
 
+    def adv_merge_normalize(self, gathered, out=None):
+        """fa_adv_merge_normalize: the several-rank tail behind the all-gather in one launch -- merge of the gathered (W, N, 3)
+        moments + normalisation.  Returns (adv, mean, std); == adv_merge() + adv_normalize() bit for bit."""
+        if not hasattr(self, "_adv_ms"):
+            self._adv_ms = torch.zeros((2, self.N), dtype=torch.float64, device=self.device)
+        if out is None:
+            out = self._new((self.storage.num_steps, self.E, self.N, 1), torch.float32)
+        _lib.check(self._lib.fa_adv_merge_normalize(self._h, _ptr(gathered), int(gathered.shape[0]), _ptr(out),
+                                                    _ptr(self._adv_ms[0]), _ptr(self._adv_ms[1]), _stream()), "fa_adv_merge_normalize")
+        return out, self._adv_ms[0], self._adv_ms[1]
+
     def after_update(self):
         _lib.check(self._lib.fa_after_update(self._h, _stream()), "fa_after_update")
 

@@ -248,6 +248,12 @@ int fa_adv_merge(fa_env *env, const double *gathered, int32_t world, double *mea
                  void *stream);
 /* ppo.py:123: adv_out (T,E,N) = (A - mean[i]) / (std[i] + 1e-5), float32. */
 int fa_adv_normalize(fa_env *env, const double *mean, const double *std, float *adv_out, void *stream);
+/* fa_adv_merge + fa_adv_normalize as ONE launch (the several-rank tail behind the all-gather): every workgroup merges the
+ * `world` ranks' gathered (n, mean, M2) triples itself -- fa_adv_merge's loop, rank order, the same bits on every workgroup and
+ * every rank -- and normalises its share of this handle's advantages into adv_out (ppo.py:121-124 over ALL ranks' samples).
+ * mean_out / std_out (device, N doubles, may be null) receive the merged statistics.  Bit for bit the two separate calls. */
+int fa_adv_merge_normalize(fa_env *env, const double *gathered, int32_t world, float *adv_out, double *mean_out,
+                           double *std_out, void *stream);
 /* RolloutStorage.after_update (storage.py:51-56). */
 int fa_after_update(fa_env *env, void *stream);
 

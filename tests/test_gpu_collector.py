@@ -256,6 +256,13 @@ def test_moments_and_merge_equal_global_two_pass(fa):
         assert abs(float(std[i]) - allp[:, :, i].std(ddof=1)) < 1e-12
     hm, hs = merge_moments(gathered)
     assert torch.allclose(hm, mean.cpu(), rtol=0, atol=1e-15) and torch.allclose(hs, std.cpu(), rtol=1e-15, atol=0)
+    # the several-rank tail behind the all-gather as ONE launch: merge + normalisation == the two separate calls, bit for bit
+    mean, std = mean.clone(), std.clone()
+    adv_ref = eng.adv_normalize(mean, std).clone()
+    out = torch.full((T, E, N, 1), float("nan"), device="cuda")
+    adv, m2, s2 = eng.adv_merge_normalize(gathered, out=out)
+    assert adv.data_ptr() == out.data_ptr() and torch.equal(adv, adv_ref)
+    assert torch.equal(m2, mean) and torch.equal(s2, std)
 
 
 @pytest.mark.parametrize("E,G,A,T", [(4096, 3, 3, 128),          # the headline shape: fa_gae_mom_kernel, 384 workgroups, fold of 8
