@@ -81,8 +81,8 @@ __global__ __launch_bounds__(64) void fa_gae_kernel(const float *__restrict__ re
 // scans the previous chunk out of LDS and stores the returns.  Same arithmetic, same order.
 // (Two chunks in flight per loader: 3x slower through __syncthreads() in round 2 -- its fence drains
 // vmcnt -- and still 18.8 us against 16.0 with raw barriers and statically named register sets in
-// round 4: at 3.5 TB/s this access pattern -- 256-byte pieces of 32 rows 96 KB apart per wave -- has
-// the memory system saturated, more requests in flight only queue longer.)
+// round 4 -- in that form the masks + done wave has 128 requests outstanding, twice what a wave can have in
+// flight, and every barrier waits for it.)
 #define FA_GAEC_CHUNK 32
 __global__ __launch_bounds__(256) void fa_gae_coop_kernel(const float *__restrict__ rewards,
                                                           const float *__restrict__ value_preds,
