@@ -136,23 +136,30 @@ def _args(T, device="cpu"):
     return ns
 
 
-def gen_collector_fixture():
+def gen_collector_fixture(name="collector_3v3", G=3, A=3, T=64, max_t=25, n_upd=3, seed=2024, compact=False, load_ckpt=None):
     """Drive the reference's own Learner/Neo/RolloutStorage/JointPPO through the call
     sequence of train_fortattack.py:49-116 for a few updates and record everything the
-    collector, GAE and advantage normalisation produce."""
+    collector, GAE and advantage normalisation produce.  `compact` (the long-horizon capture:
+    the reference's own rollout length, arguments.py:23 / marlsave/tmp_2/params.json): the storage
+    after `after_update` is recorded as its row 0 + the absolute sum of the other rows, and the
+    int64 action tensor is dropped (`actions` int8 holds the same values).  `load_ckpt`: one of
+    the published checkpoints, loaded through the reference's own `Learner.load_models`
+    (learner.py:71-73: `continue_training`) so that episodes end at irregular steps (trained
+    attackers reach the fort, trained guards shoot them) instead of every max_t steps."""
     import torch
     rh.import_reference()
     torch.set_num_threads(1)
     import learner as ref_learner
     import rlcore.algo.ppo as ref_ppo
 
-    G, A, T, max_t, n_upd, seed = 3, 3, 64, 25, 3, 2024
     N = G + A
     torch.manual_seed(seed)
     np.random.seed(seed)
     env, skip = rh.make_reference_env(G, A, max_t)
     args = _args(T)
     master = ref_learner.setup_master(args, env)
+    if load_ckpt is not None:
+        master.load_models(torch.load(load_ckpt, weights_only=False, map_location="cpu")["models"])
 
     captured = {}
     orig_gen = ref_ppo.magent_feed_forward_generator
@@ -164,8 +171,8 @@ def gen_collector_fixture():
     ref_ppo.magent_feed_forward_generator = capturing_gen
 
     rec = dict(actions=np.zeros((n_upd, T, N), np.int8), done=np.zeros((n_upd, T), np.uint8))
-    keys = ["obs", "rewards", "masks", "value_preds", "returns", "action_log_probs", "actions_st"]
-    for k in keys + ["adv", "after_obs", "after_masks"]:
+    keys = ["obs", "rewards", "masks", "value_preds", "returns", "action_log_probs"] + ([] if compact else ["actions_st"])
+    for k in keys + ["adv"] + (["after_obs_row0", "after_masks_row0", "after_rest_abs_sum"] if compact else ["after_obs", "after_masks"]):
         rec[k] = []
     end_pts_all, next_values_all = [], []
     with rh.quiet():
@@ -212,8 +219,16 @@ def gen_collector_fixture():
         adv[G:] = [a.numpy() for a in captured["adv"][1]]
         rec["adv"].append(np.stack(adv))
         master.after_update()
-        rec["after_obs"].append(np.stack([s.obs.numpy().copy() for s in st]))
-        rec["after_masks"].append(np.stack([s.masks.numpy().copy() for s in st]))
+        if compact:
+            assert all(bool(torch.equal(a.actions[:, 0, 0], torch.from_numpy(rec["actions"][j, :, i].astype(np.int64))))
+                       for i, a in enumerate(st))
+            rec["after_obs_row0"].append(np.stack([s.obs[0].numpy().copy() for s in st]))
+            rec["after_masks_row0"].append(np.stack([s.masks[0].numpy().copy() for s in st]))
+            # masks[1:] keep the rollout's values (storage.py:51-56 only moves row T to row 0); obs[1:] are zeroed
+            rec["after_rest_abs_sum"].append(np.array([float(s.obs[1:].abs().sum()) for s in st]))
+        else:
+            rec["after_obs"].append(np.stack([s.obs.numpy().copy() for s in st]))
+            rec["after_masks"].append(np.stack([s.masks.numpy().copy() for s in st]))
     ref_ppo.magent_feed_forward_generator = orig_gen
     for k in list(rec.keys()):
         if isinstance(rec[k], list):
@@ -227,8 +242,8 @@ def gen_collector_fixture():
     rec["end_pts"], rec["next_values"] = ep, nv
     rec["meta"] = np.array([G, A, max_t, T, n_upd, seed, skip], np.int64)
     rec["gamma_tau"] = np.array([args.gamma, args.tau])
-    np.savez_compressed(os.path.join(OUT, "collector_3v3.npz"), **rec)
-    print("collector_3v3  end_pts", end_pts_all)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **rec)
+    print(name, " end_pts", end_pts_all)
 
 
 def gen_mpnn_fixture():
@@ -582,6 +597,10 @@ if __name__ == "__main__":
         gen_env_fixtures()
     if "collector" in which:
         gen_collector_fixture()
+    if "collector1000" in which:
+        # the reference's own rollout length and native team size (arguments.py:23; marlsave/tmp_2/params.json)
+        gen_collector_fixture("collector_5v5_T1000", G=5, A=5, T=1000, max_t=100, n_upd=2, seed=77, compact=True,
+                              load_ckpt="/root/reference/marlsave/tmp_1/ep1240.pt")
     if "mpnn" in which:
         gen_mpnn_fixture()
     if "mpnn128" in which:

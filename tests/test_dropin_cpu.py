@@ -21,7 +21,11 @@ pytestmark = pytest.mark.skipif(not rh.reference_available(), reason="reference 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
-def test_reference_learner_runs_on_repo_rollout_storage():
+@pytest.mark.parametrize("name,ckpt", [("collector_3v3", None),
+                                       # the reference's own rollout length / team size, the published ep1240 policies loaded
+                                       # through the reference's Learner.load_models (as oracle/gen_golden.py collector1000 did)
+                                       ("collector_5v5_T1000", "marlsave/tmp_1/ep1240.pt")])
+def test_reference_learner_runs_on_repo_rollout_storage(name, ckpt):
     import gen_golden as gg
     import emergent_multiagent_strategies_amd as fa
     rh.import_reference()
@@ -30,7 +34,8 @@ def test_reference_learner_runs_on_repo_rollout_storage():
     import rlagent as ref_rlagent
     import rlcore.algo.ppo as ref_ppo
 
-    g = np.load(os.path.join(GOLDEN, "collector_3v3.npz"))
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    compact = "after_obs" not in g.files
     G, A, max_t, T, n_upd, seed, skip = [int(v) for v in g["meta"]]
     N = G + A
     joint = fa.JointRolloutStorage(T, 1, N)
@@ -56,6 +61,8 @@ def test_reference_learner_runs_on_repo_rollout_storage():
         env, skip2 = rh.make_reference_env(G, A, max_t)
         assert skip2 == skip
         master = ref_learner.setup_master(gg._args(T), env)
+        if ckpt is not None:
+            master.load_models(torch.load(os.path.join(rh.REFERENCE_ROOT, ckpt), weights_only=False, map_location="cpu")["models"])
         assert len(made) == N and all(isinstance(a.rollouts, fa.RolloutStorage) for a in master.all_agents)
         with rh.quiet():
             obs = env.reset()
@@ -86,7 +93,8 @@ def test_reference_learner_runs_on_repo_rollout_storage():
                 for k in ("obs", "rewards", "masks", "value_preds", "returns", "action_log_probs"):
                     assert np.array_equal(getattr(made[i], k).numpy(), g[k][j, i]), (k, j, i)
                     assert np.array_equal(getattr(joint, k)[:, :, i].numpy(), g[k][j, i]), (k, j, i)
-                assert np.array_equal(made[i].actions.numpy(), g["actions_st"][j, i])
+                assert np.array_equal(made[i].actions.numpy()[:, 0, 0], g["actions"][j, :, i])
+                assert compact or np.array_equal(made[i].actions.numpy(), g["actions_st"][j, i])
             captured.pop("adv", None)
             with rh.quiet():
                 master.update()                                  # the reference's JointPPO on the windows
@@ -95,8 +103,13 @@ def test_reference_learner_runs_on_repo_rollout_storage():
                 assert np.array_equal(adv[i], g["adv"][j, i]), (j, i)
             master.after_update()
             for i in range(N):
-                assert np.array_equal(made[i].obs.numpy(), g["after_obs"][j, i])
-                assert np.array_equal(made[i].masks.numpy(), g["after_masks"][j, i])
+                if compact:
+                    assert np.array_equal(made[i].obs[0].numpy(), g["after_obs_row0"][j, i])
+                    assert np.array_equal(made[i].masks[0].numpy(), g["after_masks_row0"][j, i])
+                    assert float(made[i].obs[1:].abs().sum()) == 0.0
+                else:
+                    assert np.array_equal(made[i].obs.numpy(), g["after_obs"][j, i])
+                    assert np.array_equal(made[i].masks.numpy(), g["after_masks"][j, i])
     finally:
         ref_rlagent.RolloutStorage = orig_storage
         ref_ppo.magent_feed_forward_generator = orig_gen

@@ -124,8 +124,13 @@ def test_out_files_invariants():
         prev = cur
 
 
-def test_collector_gae_advnorm(golden_dir):
-    g = _load(golden_dir, "collector_3v3")
+@pytest.mark.parametrize("name", ["collector_3v3",
+                                  # the reference's own rollout length and team size (arguments.py:23, marlsave/tmp_2/params.json:
+                                  # num_steps 1000, 5v5, 100-step episodes), the published ep1240 policies acting: 105 episode ends
+                                  "collector_5v5_T1000"])
+def test_collector_gae_advnorm(golden_dir, name):
+    g = _load(golden_dir, name)
+    compact = "after_obs" not in g
     G, A, max_t, T, n_upd, seed, skip = [int(v) for v in g["meta"]]
     N = G + A
     gamma, tau = [float(v) for v in g["gamma_tau"]]
@@ -142,7 +147,8 @@ def test_collector_gae_advnorm(golden_dir):
             out = env.step(g["actions"][j, s][None].astype(np.int64))
             obs = out["obs"][0]
             for i in range(N):
-                st[i].insert(obs[i].astype(np.float32), 0.0, g["actions_st"][j, i, s],
+                st[i].insert(obs[i].astype(np.float32), 0.0,
+                             np.array([[g["actions"][j, s, i]]], np.int64) if compact else g["actions_st"][j, i, s],
                              g["action_log_probs"][j, i, s], g["value_preds"][j, i, s],
                              np.float32(out["reward"][0, i]), masks[i])
             assert bool(out["done"][0]) == bool(g["done"][j, s])
@@ -172,8 +178,12 @@ def test_collector_gae_advnorm(golden_dir):
             assert np.abs(adv - g["adv"][j, i]).max() < 2e-6
         for i in range(N):
             st[i].after_update()
-            assert np.array_equal(st[i].obs, g["after_obs"][j, i])
-            assert np.array_equal(st[i].masks, g["after_masks"][j, i])
+            if compact:
+                assert np.array_equal(st[i].obs[0], g["after_obs_row0"][j, i]) and np.array_equal(st[i].masks[0], g["after_masks_row0"][j, i])
+                assert float(np.abs(st[i].obs[1:]).sum()) == g["after_rest_abs_sum"][j, i] == 0.0
+            else:
+                assert np.array_equal(st[i].obs, g["after_obs"][j, i])
+                assert np.array_equal(st[i].masks, g["after_masks"][j, i])
 
 
 def test_oracle_rollout_equals_per_step_calls():
