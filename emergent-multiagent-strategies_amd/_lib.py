@@ -70,7 +70,10 @@ class StateHost(C.Structure):
 
 FA_RNG_MT19937, FA_RNG_PHILOX = 0, 1
 # fa_config.step_kernel (include/fortattack.h FA_KERNEL_*)
-STEP_KERNELS = {"auto": 0, "pipe": 1, "pipe3": 2, "waves1": 3, "waves2": 4, "waves3": 5, "pairs": 6, "chain": 7}
+STEP_KERNELS = {"auto": 0, "pipe": 1, "pipe3": 2, "waves1": 3, "waves2": 4, "waves3": 5}
+# csrc/experiments/fa_step_experiments.h: kernels of variant libraries only (tools/build_variant.py); fa_create of the
+# product library refuses these values
+EXPERIMENT_STEP_KERNELS = {"pairs": 64, "chain": 65}
 
 # every symbol include/fortattack.h declares
 EXPORTS = {

@@ -6,8 +6,12 @@ import subprocess
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB = os.path.join(CSRC, "libfortattack_hip.so")
+# FA_LIBRARY: load another build of the same C ABI instead (the variant libraries of tools/build_variant.py -- the
+# experiment step kernels' parity tests, A/B runs); never built or rebuilt from here
+if os.environ.get("FA_LIBRARY"):
+    LIB = os.path.abspath(os.environ["FA_LIBRARY"])
 OBJ = os.path.join(CSRC, "_obj")            # objects + assembly of the last build (git-ignored)
-SOURCES = ["fa_step.hip", "fa_collect.hip", "fa_policy.hip", "fa_attend.hip", "fa_train.hip", "fa_train_dw.hip", "fa_fold.hip", "fa_rccl.hip", "fa_api.hip"]
+SOURCES = ["fa_step_pipe.hip", "fa_step_classic.hip", "fa_collect.hip", "fa_policy.hip", "fa_attend.hip", "fa_train.hip", "fa_train_dw.hip", "fa_fold.hip", "fa_rccl.hip", "fa_api.hip"]
 # -ffp-contract=off: the fp64 step must evaluate every operation as the reference does
 # (no fused multiply-add); no -ffast-math for the same reason.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
@@ -18,9 +22,11 @@ def hipcc():
 
 
 def needs_build():
+    if os.environ.get("FA_LIBRARY"):
+        return False
     if not os.path.isfile(LIB):
         return True
-    deps = [os.path.join(CSRC, f) for f in SOURCES + ["fa_device.h", "fa_probe.h", "fa_policy.h", "fa_mfma.h", "fa_train.h"]]
+    deps = [os.path.join(CSRC, f) for f in SOURCES + ["fa_device.h", "fa_step_common.h", "experiments/fa_step_experiments.h", "fa_probe.h", "fa_policy.h", "fa_mfma.h", "fa_train.h"]]
     deps.append(os.path.join(ROOT, "include", "fortattack.h"))
     return any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in deps)
 
@@ -52,7 +58,7 @@ def _compile_one(src, verbose):
 
 
 def build(force=False, verbose=False):
-    if not force and not needs_build():
+    if os.environ.get("FA_LIBRARY") or (not force and not needs_build()):
         return LIB
     from concurrent.futures import ThreadPoolExecutor
     os.makedirs(OBJ, exist_ok=True)

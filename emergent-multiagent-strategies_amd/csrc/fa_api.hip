@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "fa_device.h"
+#include "experiments/fa_step_experiments.h"
 #include "fa_policy.h"
 #include "fa_train.h"
 #include "fortattack.h"
@@ -15,6 +16,7 @@
 hipError_t fa_launch_step(const FaStepArgs &a, hipStream_t st);
 hipError_t fa_launch_reset(const FaStepArgs &a, hipStream_t st);
 const char *fa_step_variant_name(int G, int A, int E, int nsteps, int step_kernel, bool choice);
+int fa_step_experiments_linked(); // fa_step_classic.hip: 1 in a variant library that carries csrc/experiments/
 hipError_t fa_launch_seed(const FaState &s, int E, uint64_t base_seed, int64_t env_offset, int skip_words,
                           hipStream_t st);
 hipError_t fa_launch_selftest(unsigned long long n_per_thread, unsigned long long seed, unsigned long long *mismatch,
@@ -227,12 +229,16 @@ int fa_create(const fa_config *cfg, fa_env **out) {
     if (cfg->max_time_steps < 1) return fail(FA_ERR_INVALID, "fa_create: max_time_steps must be >= 1");
     if (cfg->rng_mode != FA_RNG_MT19937 && cfg->rng_mode != FA_RNG_PHILOX)
         return fail(FA_ERR_INVALID, "fa_create: unknown rng_mode");
-    if (cfg->step_kernel < FA_KERNEL_AUTO || cfg->step_kernel > FA_KERNEL_CHAIN)
+    const bool experiment = cfg->step_kernel == FA_KERNEL_EXP_PAIRS || cfg->step_kernel == FA_KERNEL_EXP_CHAIN;
+    if (experiment && !fa_step_experiments_linked())
+        return fail(FA_ERR_INVALID, "fa_create: this library does not carry the experiment step kernels (build a variant: "
+                                    "tools/build_variant.py experiments --add experiments/fa_step_experiments.hip)");
+    if (!experiment && (cfg->step_kernel < FA_KERNEL_AUTO || cfg->step_kernel > FA_KERNEL_WAVES3))
         return fail(FA_ERR_INVALID, "fa_create: unknown step_kernel");
     if (cfg->step_kernel != FA_KERNEL_AUTO && cfg->step_kernel != FA_KERNEL_WAVES1 &&
         !((cfg->num_guards == 3 && cfg->num_attackers == 3) || (cfg->num_guards == 5 && cfg->num_attackers == 5)))
         return fail(FA_ERR_INVALID, "fa_create: the multi-wave step kernels exist for 3v3 and 5v5 only");
-    if (cfg->step_kernel == FA_KERNEL_PAIRS && !(cfg->num_guards == 3 && cfg->num_attackers == 3))
+    if (cfg->step_kernel == FA_KERNEL_EXP_PAIRS && !(cfg->num_guards == 3 && cfg->num_attackers == 3))
         return fail(FA_ERR_INVALID, "fa_create: the pair-per-lane step kernel exists for 3v3 only");
     if (!(cfg->world.contact_margin > 0) || !(cfg->world.agent_size > 0))
         return fail(FA_ERR_INVALID, "fa_create: contact_margin and agent_size must be > 0");

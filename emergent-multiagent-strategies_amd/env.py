@@ -50,7 +50,7 @@ class BatchedFortAttack(object):
         cfg.base_seed, cfg.env_offset = int(base_seed), int(env_offset)
         cfg.rng_skip_doubles = -1 if skip_doubles is None else int(skip_doubles)
         cfg.track_counters = int(bool(track_counters))
-        cfg.step_kernel = _lib.STEP_KERNELS[step_kernel]   # "auto" | "pipe" | "pipe3" | "waves1" | "waves2" | "waves3"
+        cfg.step_kernel = {**_lib.STEP_KERNELS, **_lib.EXPERIMENT_STEP_KERNELS}[step_kernel]   # "auto" | "pipe" | "pipe3" | "waves1" | "waves2" | "waves3"
         self.cfg = cfg
         self.E, self.G, self.A = cfg.num_envs, cfg.num_guards, cfg.num_attackers
         self.N = self.G + self.A

@@ -49,11 +49,9 @@ enum { FA_KERNEL_AUTO = 0,
        FA_KERNEL_PIPE3 = 2,   /* fa_step_pipe_kernel, three workgroups per CU build (<= 168 VGPRs) */
        FA_KERNEL_WAVES1 = 3,  /* fa_step_kernel, one wave per workgroup */
        FA_KERNEL_WAVES2 = 4,  /* ... with the force wave (3v3 / 5v5) */
-       FA_KERNEL_WAVES3 = 5,  /* ... with force and wall waves (3v3 / 5v5) */
-       FA_KERNEL_PAIRS = 6,   /* fa_step_pair_kernel (round-4 experiment, 3v3): lane = (agent, partner), one wave, no
-                                 workgroup barrier; never picked by AUTO */
-       FA_KERNEL_CHAIN = 7 }; /* fa_step_chain_kernel (round-4 experiment, 3v3 / 5v5, num_steps >= 2): one workgroup barrier
-                                 per step, the helpers' results reach the state's wave through tagged LDS hand-offs */
+       FA_KERNEL_WAVES3 = 5 }; /* ... with force and wall waves (3v3 / 5v5) */
+/* (values >= 64 name experiment kernels that exist in variant libraries only -- csrc/experiments/fa_step_experiments.h,
+ * tools/build_variant.py; this library's fa_create refuses them) */
 enum { FA_RNG_MT19937 = 0, /* numpy legacy RandomState stream: parity with the reference */
        FA_RNG_PHILOX = 1 }; /* counter based, stateless: perf mode */
 

@@ -122,3 +122,18 @@ def test_step_kernel_names_match_the_header_enum(fa):
     enum = dict((k.lower(), int(v)) for k, v in re.findall(r"FA_KERNEL_([A-Z0-9]+)\s*=\s*(\d+)", text))
     assert enum and enum == fa._lib.STEP_KERNELS
     assert sorted(enum.values()) == list(range(len(enum)))            # dense: fa_create range-checks AUTO .. the last one
+    # the experiment kernels are not part of the public enum: their values live beside their source
+    exp = open(os.path.join(PKG, "csrc", "experiments", "fa_step_experiments.h")).read()
+    exp = dict((k.lower(), int(v)) for k, v in re.findall(r"FA_KERNEL_EXP_(PAIRS|CHAIN)\s*=\s*(\d+)", exp))
+    assert exp == fa._lib.EXPERIMENT_STEP_KERNELS and min(exp.values()) > max(enum.values())
+
+
+def test_product_library_has_no_experiment_kernels(fa):
+    """Only what AUTO (or a pinned product build) can launch ships: the round-4 experiment kernels' code objects are absent from
+    the product library (they are built into tools/_build/lib_experiments.so by tools/build_variant.py)."""
+    blob = open(fa._lib.lib_path(), "rb").read()
+    assert b"fa_step_pipe_kernel" in blob and b"fa_step_kernel" in blob
+    assert b"_Z19fa_step_pair_kernel" not in blob and b"_Z20fa_step_chain_kernel" not in blob   # (the mangled kernel symbols)
+    assert b"_Z19fa_step_pipe_kernel" in blob
+    src = open(os.path.join(PKG, "build.py")).read()
+    assert "experiments/fa_step_experiments.hip" not in src

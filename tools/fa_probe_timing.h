@@ -7,7 +7,7 @@ __device__ unsigned long long g_pl[128];
 #define FA_PL_TICK(k) if ((threadIdx.x & 255) == 0 && blockIdx.x == 100 && blockIdx.y == 0) g_pl[(k) + (threadIdx.x >> 8) * 64] = clock64();
 extern "C" int fa_dbg_policy(unsigned long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pl), sizeof(unsigned long long) * 128); }
 #define FA_TR_TICK(k)
-#elif !defined(FA_PROBE_TRAIN_TU) // ---- the step kernels' translation unit (fa_step.hip)
+#elif !defined(FA_PROBE_TRAIN_TU) // ---- the pipelined step kernel's translation unit (fa_step_pipe.hip)
 #ifndef FA_TICK_WAVE1
 #define FA_TICK_WAVE1 0 // 1: report pair wave 1 instead of the last pair wave
 #endif

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Experiment helper: compile fa_step.hip to gfx950 assembly and print the instruction histogram of
+"""Experiment helper: compile fa_step_pipe.hip to gfx950 assembly and print the instruction histogram of
 the pipelined kernel's wave-0 loop (a lone wave issues one instruction of any kind per 4 cycles, so
 the instruction count of this loop IS the step-to-step chain).  usage: isa_w0.py [G A COLLECT NPW MINW] [--dump]"""
 import collections, os, re, subprocess, sys
@@ -9,7 +9,7 @@ G, A, COL, NPW, MINW = (args + ["3", "3", "1", "2", "2"][len(args):])[:5]
 asm = "/tmp/fa_step.s"
 subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-I",
                        os.path.join(ROOT, "include"), "-S", "--cuda-device-only",
-                       os.path.join(ROOT, "emergent-multiagent-strategies_amd/csrc/fa_step.hip"), "-o", asm],
+                       os.path.join(ROOT, "emergent-multiagent-strategies_amd/csrc/fa_step_pipe.hip"), "-o", asm],
                       stderr=subprocess.DEVNULL)
 name = "_Z19fa_step_pipe_kernelILi%sELi%sELb%sELi%sELi%sEEv10FaStepArgs" % (G, A, COL, NPW, MINW)
 lines = open(asm).read().split("\n")

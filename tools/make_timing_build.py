@@ -12,5 +12,5 @@ os.makedirs(os.path.join(ROOT, "tools", "_build"), exist_ok=True)
 out = os.path.join(ROOT, "tools", "_build", os.environ.get("FA_TIMING_LIB", "libfa_timing.so"))
 subprocess.check_call(["/opt/rocm/bin/hipcc"] + sys.argv[1:] + [ "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
                        "-shared", '-DFA_PROBE_IMPL="%s"' % os.environ.get("FA_PROBE", "fa_probe_timing.h"), "-I", os.path.join(ROOT, "tools"), "-I", os.path.join(ROOT, "include")] +
-                      [os.path.join(CSRC, f) for f in ("fa_step.hip", "fa_collect.hip", "fa_policy.hip", "fa_attend.hip", "fa_train.hip", "fa_train_dw.hip", "fa_fold.hip", "fa_rccl.hip", "fa_api.hip")] + ["-o", out])
+                      [os.path.join(CSRC, f) for f in ("fa_step_pipe.hip", "fa_step_classic.hip", "fa_collect.hip", "fa_policy.hip", "fa_attend.hip", "fa_train.hip", "fa_train_dw.hip", "fa_fold.hip", "fa_rccl.hip", "fa_api.hip")] + ["-o", out])
 print(out)
