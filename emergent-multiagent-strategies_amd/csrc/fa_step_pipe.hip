@@ -153,12 +153,17 @@ __global__ __launch_bounds__((NPW + 2) * FA_WAVE, MINW) void fa_step_pipe_kernel
         // episode bookkeeping by wave 1, the observation rows by the last pair wave
         const bool rew_wave = wave_id == 1, out_wave = wave_id == NPW;
         double prev = 0.0, ep_rew = 0.0;
+        // the finished-episode statistics stay in registers for the launch: as read-modify-writes of global memory inside the
+        // loop they put two load round trips (s_waitcnt vmcnt(0) each, ~1 500 cycles) into every step in which an env of the
+        // wave ends its episode -- on the wave that arrives last at P.  Same additions in the same order: same bits.
+        double ep_sum = 0.0;
+        unsigned alive_end = 0u;
         if (rew_wave) {
             prev = a.s.prev[idx];
-            if (a.track_counters) ep_rew = a.s.ep_rew[idx];
+            if (a.track_counters) { ep_rew = a.s.ep_rew[idx]; ep_sum = a.s.ep_rew_sum[idx]; alive_end = a.s.alive_end[idx]; }
             // complete the loads here: first used inside the loop, they would put a vmcnt(0) --
             // which on gfx9 also drains every store in flight -- into each iteration
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(prev), "+v"(ep_rew));
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(prev), "+v"(ep_rew), "+v"(ep_sum), "+v"(alive_end));
         }
         int act_prev = 0;
         bool alive0_prev = false;
@@ -196,8 +201,8 @@ __global__ __launch_bounds__((NPW + 2) * FA_WAVE, MINW) void fa_step_pipe_kernel
             if (a.track_counters) {
                 ep_rew += alive0 ? rew : 0.0;
                 if (done) {
-                    a.s.ep_rew_sum[idx] += ep_rew;
-                    if (alive1) a.s.alive_end[idx] += 1u;
+                    ep_sum += ep_rew;
+                    if (alive1) alive_end += 1u;
                     ep_rew = 0.0;
                 }
             }
@@ -326,7 +331,7 @@ __global__ __launch_bounds__((NPW + 2) * FA_WAVE, MINW) void fa_step_pipe_kernel
         if (rew_wave) {
             emit_rew(ns & 1);
             a.s.prev[idx] = prev;
-            if (a.track_counters) a.s.ep_rew[idx] = ep_rew;
+            if (a.track_counters) { a.s.ep_rew[idx] = ep_rew; a.s.ep_rew_sum[idx] = ep_sum; a.s.alive_end[idx] = alive_end; }
         }
         if (out_wave) emit_obs(ns & 1);
         if (FA_TICK_WAVE1 ? rew_wave : out_wave) { FA_TICK_FLUSH(10, 14, 29) }
