@@ -100,6 +100,106 @@ def measured_stream(dev):
     return out
 
 
+
+def git_blob_hash(path):
+    """git's blob id of a tracked file (so that a committed PMC record quoted in the line can be pinned), or None."""
+    try:
+        return subprocess.run(["git", "hash-object", path], capture_output=True, text=True, cwd=ROOT, timeout=20).stdout.strip() or None
+    except Exception:
+        return None
+
+
+def live_traffic(kernel_prefix, args, budget_s=150):
+    """HBM bytes per launch of the dominant kernel, measured NOW: two rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE cannot
+    share one on gfx950) over `bench.py --pmc-probe` -- this run's workload, 3 + 12 rollout launches, nothing else -- each with
+    --kernel-trace only, as MI355X_MICROARCH.md prescribes; bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (KiB counters, the
+    gfx950 FETCH_SIZE x2 correction).  Returns (bytes or None, how)."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.isfile("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return None, "rocprofv3 not found on this box"
+    vals = {}
+    t_start = time.perf_counter()
+    tmp = tempfile.mkdtemp(prefix="fa_pmc_", dir="/tmp")
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            left = budget_s - (time.perf_counter() - t_start)
+            if left < 20:
+                return None, "PMC passes ran out of their %d s budget" % budget_s
+            out = os.path.join(tmp, ctr)
+            cmd = [exe, "--kernel-trace", "--pmc", ctr, "-f", "csv", "-d", out, "-o", "p", "--", sys.executable,
+                   os.path.abspath(__file__), "--pmc-probe", "--envs", str(args.envs), "--rollout", str(args.rollout),
+                   "--guards", str(args.guards), "--attackers", str(args.attackers)] + (["--no-counters"] if args.no_counters else [])
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=left, cwd="/tmp",
+                               env=dict(os.environ, TMPDIR="/tmp"))
+            acc = []
+            for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if row.get("Counter_Name") == ctr and kernel_prefix in row.get("Kernel_Name", ""):
+                        acc.append(float(row["Counter_Value"]))
+            if not acc:
+                return None, "rocprofv3 --pmc %s produced no rows for %s (rc %d): %s" % (ctr, kernel_prefix, r.returncode, (r.stderr or "")[-200:])
+            vals[ctr] = (sum(acc) / len(acc), len(acc))
+    except Exception as exc:
+        return None, "live PMC passes failed: %r" % (exc,)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    b = (2.0 * vals["FETCH_SIZE"][0] + vals["WRITE_SIZE"][0]) * 1024.0
+    return b, ("live: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (two passes) over bench.py --pmc-probe in this run, "
+               "%d / %d launches; (2 * FETCH_SIZE + WRITE_SIZE) * 1024" % (vals["FETCH_SIZE"][1], vals["WRITE_SIZE"][1]))
+
+
+def pmc_probe(args):
+    """The workload of live_traffic's rocprofv3 passes: the bench's rollout launch, 3 + 12 times, nothing else."""
+    import torch
+    import emergent_multiagent_strategies_amd as fa
+    E, G, A, T = args.envs, args.guards, args.attackers, args.rollout
+    eng = fa.BatchedFortAttack(E, G, A, 100, base_seed=0, device=0, track_counters=not args.no_counters)
+    st = fa.JointRolloutStorage(T, E, G + A, device="cuda:0")
+    eng.bind_storage(st)
+    st.actions.copy_(torch.randint(0, 8, st.actions.shape, device="cuda:0", generator=torch.Generator(device="cuda:0").manual_seed(1234)))
+    eng.collect_reset()
+    for _ in range(15):
+        eng.collect_rollout(0, T)
+    torch.cuda.synchronize()
+
+
+def issue_model(G, A, E, T, launch_s, clock_khz, n_cus):
+    """roofline.secondary: the issue model of wave 0's step loop generated at build time from the assembly
+    (emergent-multiagent-strategies_amd/isa_model.py -> csrc/fa_isa_model.json) next to the cycles per step measured in this run."""
+    path = os.path.join(ROOT, "emergent-multiagent-strategies_amd", "csrc", "fa_isa_model.json")
+    try:
+        m = json.load(open(path))
+    except Exception as exc:
+        return {"error": "no issue model beside the library: %r" % (exc,)}
+    epw = 64 // (G + A)
+    grid = (E + epw - 1) // epw
+    tag = ("%dv%d" % (G, A)) + ("" if grid <= 2 * n_cus else "_3percu")
+    k = m.get(tag)
+    if not k or "wave0" not in k.get("loops", {}):
+        return {"error": "the issue model has no entry %r" % tag}
+    w0 = k["loops"]["wave0"]
+    measured = launch_s / T * clock_khz * 1e3
+    return {"bound": "instruction issue of the state's wave (wave 0) of fa_step_pipe_kernel: one instruction per 4 cycles, fp64 at full "
+                     "rate on gfx950; the other waves' loops are listed for the same build",
+            "generated_from": "csrc/_obj/fa_step_pipe.s at build time (isa_model.py), symbol " + k["symbol"],
+            "instrs_per_step": w0["instructions_per_step"], "fp64_instrs_per_step": w0["fp64_instructions_per_step"],
+            "loop_instructions_static": w0["instructions"], "restage_path_instructions": w0["restage_path_instructions"],
+            "model_cycles_per_step": w0["model_cycles_per_step"], "measured_cycles_per_step": measured,
+            "frac": w0["model_cycles_per_step"] / measured if measured > 0 else None,
+            "shader_clock_khz": clock_khz,
+            "other_waves_loop_instructions": {r: v["instructions"] for r, v in k["loops"].items() if r != "wave0"},
+            "spill_reloads_in_step_loops": {r: v.get("spill_reloads", 0) for r, v in k["loops"].items()},
+            "vgprs": k["vgprs"], "sgpr_spill_count": k["sgpr_spill_count"], "scratch_bytes": k["scratch_bytes"],
+            "workgroups": grid, "cus": n_cus,
+            "cus_with_two_workgroups": max(0, min(grid, 2 * n_cus) - n_cus) if grid <= 2 * n_cus else None,
+            "what_the_rest_is": "two workgroup barriers per step (last arrival -> release ~ 200-250 cycles each) and the LDS round trips "
+                                "behind them; on CUs that hold two workgroups the wave shares its SIMD with a helper wave of the other"}
+
+
 def policy_kernel_label(E, G, A):
     """The fa_policy_kernel instantiation fa_collect_act launches for this shape (csrc/fa_policy.hip: policy_rows)."""
     n_max = max(G, A)
@@ -278,10 +378,22 @@ def main():
                     help="with --gpus 1: open a process group of ONE rank and take the several-rank path anyway (the "
                          "all-gather, the merge kernel, the second-stream exchange run on one rank and must change nothing): how "
                          "a one-GPU box executes the RCCL path")
+    ap.add_argument("--pmc-probe", action="store_true", help=argparse.SUPPRESS)   # the workload of the live PMC passes (live_traffic)
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="do not run the two rocprofv3 PMC passes for roofline.traffic (quote the committed record instead)")
+    ap.add_argument("--smoke", action="store_true",
+                    help="a short self-check of the --gpus N path before a timed run: 2 rollouts + collector tail, 1 closed-loop "
+                         "rollout and 1 PPO update, no CPU baseline / E-sweep / 5v5 records (< 20 s after start-up)")
     ap.add_argument("--share-devices", action="store_true",
                     help="map ranks onto the visible GPUs round-robin (smoke-testing the multi-rank "
                          "path on a box with fewer GPUs than ranks; use with --backend gloo)")
     args = ap.parse_args()
+    if args.pmc_probe:
+        return pmc_probe(args)
+    if args.smoke:
+        args.steps, args.warmup, args.min_seconds = 2, 1, 0.0
+        args.closed_loop_rollouts, args.closed_loop_updates = 1, 1
+        args.no_cpu_baseline = args.no_esweep = args.no_5v5 = args.no_live_traffic = True
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args))
@@ -457,10 +569,38 @@ def main():
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
+    rank_ms = [elapsed * 1e3 / steps]
     if world > 1:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        every = [torch.zeros_like(tt) for _ in range(world)]
+        dist.all_gather(every, tt)
+        rank_ms = [float(x.item()) * 1e3 / steps for x in every]       # every rank's own clock over the same region
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+
+    # steady state: the driver's --steps 20 is a ~4 ms region; the same loop kept up for >= 0.5 s rides in the same line
+    steady = None
+    if elapsed < 0.5 and not args.smoke:
+        n2 = max(steps, int(0.55 / max(elapsed / steps, 1e-6)) + 1)
+        if world > 1:
+            ts = torch.tensor([n2], device=dev, dtype=torch.int64)
+            dist.all_reduce(ts, op=dist.ReduceOp.MAX)
+            n2 = int(ts.item())
+        barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(n2):
+            hot_path()
+        drain()
+        torch.cuda.synchronize()
+        barrier()
+        e2 = time.perf_counter() - t1
+        if world > 1:
+            tt = torch.tensor([e2], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            e2 = float(tt.item())
+        steady = {"steps": n2, "timed_seconds": e2, "ms_per_step": e2 * 1e3 / n2, "value": world * E * T * n2 / e2,
+                  "unit": "env-steps/s", "note": "the same hot path, same buffers, timed right after the exact-%d-step region" % steps}
 
     # the second-stream exchange must leave what the one-stream form leaves (same launches, same order per buffer)
     pipelined_ok = None
@@ -480,8 +620,14 @@ def main():
     # MI355X_MICROARCH.md); only attached when the run uses the profiled configuration.
     traffic, traffic_src = None, None
     kernel_name = eng.step_variant(T // launches_per_rollout)   # which step kernel these launches ran
-    if (E, G, A, T) == (4096, 3, 3, 128):
-        for rnd in ("r04", "r03", "r02", "r01"):
+    if rank == 0 and world == 1 and graph is None and not args.no_live_traffic:
+        torch.cuda.synchronize()
+        traffic, traffic_src = live_traffic(kernel_name.split("/")[0], args)
+        live_note = traffic_src
+    else:
+        live_note = "not attempted (several ranks, per-step launches, or --no-live-traffic)"
+    if traffic is None and (E, G, A, T) == (4096, 3, 3, 128):
+        for rnd in ("r05", "r04", "r03", "r02", "r01"):
             prof = os.path.join(ROOT, "profiles", "%s_%s_summary.json" % (rnd, "fused" if graph is None else "perstep"))
             if not os.path.isfile(prof):
                 continue
@@ -490,7 +636,9 @@ def main():
                 k = [v for n, v in ks.items() if n.split("<")[0].endswith(kernel_name.split("/")[0]) and "<3, 3," in n
                      and "hbm_bytes_per_launch" in v]
                 if k:
-                    traffic, traffic_src = k[0]["hbm_bytes_per_launch"], os.path.relpath(prof, ROOT)
+                    traffic = k[0]["hbm_bytes_per_launch"]
+                    traffic_src = "%s (committed record, git blob %s; NOT measured in this run: %s)" % (
+                        os.path.relpath(prof, ROOT), git_blob_hash(prof), live_note)
                     break
             except Exception:
                 pass
@@ -540,14 +688,21 @@ def main():
                 # world state in registers, so `frac` (algorithmic bytes, the agreed accounting) is NOT HBM
                 # utilisation -- this is
                 "traffic_frac": (traffic / launch_s / 1e9 / HBM_PEAK_GBPS) if traffic else None,
-                "limiter": "per-wave issue chain (latency), not bandwidth, at this batch size: see DESIGN.md 3.1 / 7",
+                "limiter": "instruction issue of the state's wave + two barrier round trips per step, not bandwidth, at this batch size: "
+                           "see `secondary` and DESIGN.md 3.1 / 7",
                 "measured_stream_GBps": measured_stream(dev),
                 "algorithmic_bytes_per_launch": bytes_per_launch,
                 "algorithmic_bytes_per_env_step": algorithmic_bytes_per_env_step(N),
                 "env_steps_per_launch": E * (T // launches_per_rollout),
                 "avg_launch_us": launch_s * 1e6, "timed_by": "hipEvents on the launch stream, %d launches" % (
-                    len(ev) * launches_per_rollout)},
+                    len(ev) * launches_per_rollout),
+                "secondary": (issue_model(G, A, E, T, launch_s, getattr(torch.cuda.get_device_properties(local_rank), "clock_rate", 2400000),
+                                          torch.cuda.get_device_properties(local_rank).multi_processor_count)
+                              if graph is None and kernel_name.startswith("fa_step_pipe_kernel") else None)},
             "env_rollout_ms": roll_ms,
+            "steady_state": steady,
+            "rank_ms_per_step": {"per_rank": rank_ms, "min": min(rank_ms), "max": max(rank_ms),
+                                 "spread_pct": 100.0 * (max(rank_ms) - min(rank_ms)) / max(min(rank_ms), 1e-12)},
         }
         # which exchange carried the advantage statistics (and the closed loop's gradients), seen by how many ranks
         res["collective"] = {"ranks": dist.get_world_size() if exchanging else 1,
@@ -559,6 +714,10 @@ def main():
                              "forced_on_one_rank": bool(args.force_collective),
                              "second_stream_exchange_equals_one_stream": pipelined_ok,
                              "per_optimizer_step": "one all_reduce of the flat f32 gradient buffer (149 908 floats) per team"}
+        if world > 1 and args.backend == "nccl" and res["collective"]["rccl_ranks"] != world:
+            raise SystemExit("bench.py --gpus %d: RCCL saw %d ranks" % (world, res["collective"]["rccl_ranks"]))
+        if args.smoke:
+            res["smoke"] = True
         if closed is not None:
             res["closed_loop"] = closed
         if extra:

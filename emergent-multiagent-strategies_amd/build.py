@@ -31,12 +31,16 @@ def needs_build():
     return any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in deps)
 
 
-def _load_lint():
+def _load_mod(fname):
     import importlib.util           # by path: this file is also loaded stand-alone (__graft_entry__.build)
-    spec = importlib.util.spec_from_file_location("_fa_isa_lint", os.path.join(os.path.dirname(os.path.abspath(__file__)), "isa_lint.py"))
+    spec = importlib.util.spec_from_file_location("_fa_" + fname[:-3], os.path.join(os.path.dirname(os.path.abspath(__file__)), fname))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     return mod
+
+
+def _load_lint():
+    return _load_mod("isa_lint.py")
 
 
 def _compile_one(src, verbose):
@@ -68,6 +72,12 @@ def build(force=False, verbose=False):
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    # the issue model of the pipelined step kernel, read off this build's assembly (bench.py: roofline.secondary), and its
+    # regression gate: FLAT stores, spill reloads in the critical step loops, instruction count of wave 0's loop
+    isa_model = _load_mod("isa_model.py")
+    bad = isa_model.check(isa_model.write(os.path.join(OBJ, "fa_step_pipe.s")))
+    if bad:
+        raise RuntimeError("isa_model: the shipped step-kernel instantiations regressed: " + "; ".join(bad))
     return LIB
 
 

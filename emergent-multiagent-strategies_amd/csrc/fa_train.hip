@@ -20,7 +20,12 @@
 //
 // Saved for the backward and for fa_train_dw_kernel (fa_train.h FA_RECA_* / FA_RECB_*): per round the hidden state
 // entering it, the attention mix, dZ and dg; per tile h3, [dP | dV], and the opponent stage's mix_o, de_opp, h1, dg_o;
-// all attention weights stay in LDS.  g = h A and the opponents' encodings are recomputed (cheaper than a round trip).
+// all attention weights stay in LDS.  g = h A of every round is SAVED by the forward too (recG: the backward reloads it instead
+// of recomputing it -- one more GEMM per round cost more than the round trip); the opponents' encodings are recomputed.
+// Footprint: FA_TR_SAVE_FLOATS = 81 920 floats = 320 KB of records per 32-row tile -- 524 MB per fa_ppo_grad call at config 3
+// (1 639 tiles; ~0.9 GB at 5v5), written once by the tile and read back once (backward / fa_train_dw_kernel) -- next to which the
+// 47 MB of partial slabs and 10 KB of small gradients per tile are small: the records ARE the update's HBM traffic
+// (PMC: 971 MB per tile-kernel launch).  Each captured GraphedPPOStep holds its own scratch.
 //
 // Buffers (32 x 132 floats each): B0 = h (forward) / h_in of the round being differentiated; B1 = g, hmix, P;
 // B2 = ho, V, recomputed g; B3 = the running dL/dh.

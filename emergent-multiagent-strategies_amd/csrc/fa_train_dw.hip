@@ -12,7 +12,8 @@
 // for the whole range -- 48 / 40 tiles per workgroup -- and both operands of an MFMA are 4-byte LDS reads of one row
 // segment (A[i][kk] = X[row kk][i], B[kk][j] = dY[row kk][j]: bank-conflict free, 7-8 reads per 6 MFMAs).
 // A workgroup ends with ONE partial slab (192 / 160 KB): 47 MB per minibatch where rounds 2-3 wrote (and re-read)
-// 311 MB of per-tile slabs, and no accumulator lives in fa_train_kernel across its rounds.
+// 311 MB of per-tile slabs, and no accumulator lives in fa_train_kernel across its rounds.  (What this kernel READS is the
+// larger number: the tiles' records, 320 KB per 32-row tile = 524 MB per call at config 3 -- fa_train.hip's header.)
 // Roofline: MFMA-bound -- 3.1 k MFMAs per record A against 64 KB of loads (5.3 B per CU-cycle, HBM gives ~10).
 // No atomics; every sum has a fixed order: bitwise reproducible.
 #include <hip/hip_runtime.h>

@@ -464,10 +464,24 @@ class FortAttackGlobalEnv(object):
         self.observation_spaces = MASpace(tuple(Box(-np.inf, np.inf, (6,)) for _ in range(e.N)))
         self.action_range = [0., 1.]
         self._cache = None
-        self._act = torch.zeros((1, e.N), dtype=torch.int64, device=e.device)
         self._obs64 = torch.empty((1, e.N, 6), dtype=torch.float64, device=e.device)
-        self._rew64 = torch.empty((1, e.N), dtype=torch.float64, device=e.device)
-        self._done = torch.empty((1,), dtype=torch.uint8, device=e.device)
+        # step(): actions are read from, and the (N, 6) observation, the N rewards and the done flag are written to,
+        # PINNED HOST memory by the kernel itself (one launch + one stream synchronisation per env.step: no staging copies).
+        # One packed block of doubles: obs | reward | done (first byte of the last slot).
+        N = e.N
+        self._h_act = torch.zeros((1, N), dtype=torch.int64).pin_memory()
+        self._h_out = torch.zeros(7 * N + 1, dtype=torch.float64).pin_memory()
+        self._np_act = self._h_act.numpy()
+        out = self._h_out.numpy()
+        self._np_obs, self._np_rew = out[:6 * N].reshape(N, 6), out[6 * N:7 * N]
+        self._np_done = out[7 * N:].view(np.uint8)
+        io = _lib.StepIO()
+        io.actions = C.c_void_p(self._h_act.data_ptr())
+        io.act_stride_env, io.act_stride_agent = N, 1
+        base = self._h_out.data_ptr()
+        io.obs_f64, io.reward_f64, io.done = C.c_void_p(base), C.c_void_p(base + 48 * N), C.c_void_p(base + 56 * N)
+        io.auto_reset = 0
+        self._io = io
         self._alive_before = np.ones(e.N, bool)
         self.world = _WorldView(self)
         self.agents = self.world.policy_agents
@@ -522,16 +536,18 @@ class FortAttackGlobalEnv(object):
             raise AssertionError("expected %d actions, got %d" % (self.n, a.shape[0]))
         self._cache = None
         self._stepped = True
-        self._act.copy_(torch.from_numpy(a.astype(np.int64)).view(1, -1))
-        self._eng.step(self._act, auto_reset=False, want=(),
-                       out=dict(obs_f64=self._obs64, reward_f64=self._rew64, done=self._done))
-        obs = self._obs64[0].cpu().numpy()
-        rew = self._rew64[0].cpu().numpy()
+        self._np_act[0, :] = a
+        e = self._eng
+        stream = torch.cuda.current_stream(e.device)
+        _lib.check(e._lib.fa_step(e._h, C.byref(self._io), C.c_void_p(stream.cuda_stream)), "fa_step")
+        stream.synchronize()
+        obs = self._np_obs.copy()
+        rew = self._np_rew
         # fortattack_env_v1.py:87-92: an agent that is neither alive nor justDied gets the int literal 0;
         # (alive or justDied) after the step == alive before it
         reward_n = [rew[i] if self._alive_before[i] else 0 for i in range(self.n)]
         self._alive_before = obs[:, 0] != 0
-        done = bool(self._done.item())
+        done = bool(self._np_done[0])
         return obs, reward_n, done, {"n": [{} for _ in range(self.n)]}
 
     def render(self, attn_list=None, mode="human", close=False, size=350, viz_dead=False):
@@ -542,7 +558,7 @@ class FortAttackGlobalEnv(object):
             return []
         from .render import render_state
         st = self._eng.get_state()
-        shoot = (self._act.cpu().numpy().reshape(1, -1) == 7) if getattr(self, "_stepped", False) else None
+        shoot = (self._np_act.reshape(1, -1) == 7) if getattr(self, "_stepped", False) else None
         return [render_state(st, 0, self._eng.G, shoot=shoot, size=size, viz_dead=viz_dead)]
 
     def terminate(self):
@@ -579,10 +595,15 @@ def ppo_grad(obs, action, value_pred, ret, old_logp, adv, w, wt, scale, team, G,
         assert all(t.is_cuda and t.dtype == torch.float64 and t.is_contiguous() and t.numel() == N for t in adv_stats)
     assert action.dtype == torch.int64 and action.is_contiguous() and N == G + A
     assert idx is None or (idx.is_cuda and idx.dtype == torch.int64 and idx.is_contiguous())
+    sf, hf = C.c_int64(), C.c_int64()
+    _lib.check(lib.fa_ppo_grad_scratch(B, G, A, C.byref(sf), C.byref(hf)), "fa_ppo_grad_scratch")
     if scratch is None:
-        sf, hf = C.c_int64(), C.c_int64()
-        _lib.check(lib.fa_ppo_grad_scratch(B, G, A, C.byref(sf), C.byref(hf)), "fa_ppo_grad_scratch")
         scratch = (torch.empty(sf.value, device=obs.device), torch.empty(hf.value, device=obs.device))
+    elif scratch[0].numel() < sf.value or scratch[1].numel() < hf.value or any(
+            not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()) for t in scratch):
+        # (a scratch sized for another minibatch / team shape or an older record layout: the kernels would write past it)
+        raise ValueError("ppo_grad: the scratch passed in holds (%d, %d) floats, this call needs (%d, %d) (fa_ppo_grad_scratch)"
+                         % (scratch[0].numel(), scratch[1].numel(), sf.value, hf.value))
     if out is None:
         out = torch.empty(lib.fa_ppo_grad_floats(), device=obs.device)
     io = _lib.PPOGradIO()
@@ -595,6 +616,6 @@ def ppo_grad(obs, action, value_pred, ret, old_logp, adv, w, wt, scale, team, G,
     io.B, io.num_guards, io.num_attackers, io.team = B, G, A, team
     io.clip_param, io.value_loss_coef, io.entropy_coef = clip, c_value, c_entropy
     io.clipped_value_loss, io.normalize = int(bool(clipped_value_loss)), int(bool(normalize))
-    io.share_cu = int(bool(share_cu))    # leave room on the CUs for another stream's small launches (fa_train.hip)
+    io.share_cu = int(bool(share_cu))    # (kept in the ABI; the 32-row tile kernel shares a CU two ways always and ignores it)
     _lib.check(lib.fa_ppo_grad(C.byref(io), _stream()), "fa_ppo_grad")
     return out, scratch

@@ -403,7 +403,8 @@ class BatchedLearner(object):
 
     def close(self):
         """Release what the constructor took from the communication layer: the library's RCCL communicators
-        (ncclCommDestroy) and the per-team process groups.  Idempotent; also run when the learner is collected."""
+        (ncclCommDestroy) and the per-team process groups.  Idempotent.  Call it (or use the learner as a context manager)
+        on every rank at the same point of the program: garbage collection does NOT do it (__del__ only warns)."""
         for ex in [self._exch] + list(self._team_exch):
             if ex is not None:
                 ex.close()
@@ -417,9 +418,21 @@ class BatchedLearner(object):
                         pass
         self._team_groups = [self.group, self.group]
 
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
     def __del__(self):
+        # collection can happen at any point (another learner's stream capture open, one rank only): nothing here may
+        # synchronise or tear down a process group.  close() -- or the context manager -- does that; a learner that
+        # still holds communicators when it is collected says so.
         try:
-            self.close()
+            if self._exch is not None or any(ex is not None for ex in self._team_exch):
+                import warnings
+                warnings.warn("BatchedLearner collected without close(): its RCCL communicators / per-team process groups "
+                              "are left to the process exit", ResourceWarning)
         except Exception:
             pass
 
@@ -440,17 +453,19 @@ class BatchedLearner(object):
 
     def load(self, path):
         ck = torch.load(path, map_location=self.device, weights_only=False)
+        # everything that can refuse the checkpoint is checked BEFORE any state changes: a failed load leaves the learner as it was
+        seed = int(ck["fa_sample_seed"]) if "fa_sample_seed" in ck else None
+        if seed is not None and seed != self.sample_seed and self._graphs is not None:
+            raise RuntimeError("the rollout graph is already captured with another sample_seed: load() before reset()")
         self.load_models(ck["models"])
         if "fa_rollout_counter" in ck:          # (absent in the reference's own checkpoints)
             self._rollout_counter.fill_(int(ck["fa_rollout_counter"]))
-        if "fa_sample_seed" in ck:              # the sampling stream continues where the saved run stopped
-            if int(ck["fa_sample_seed"]) != self.sample_seed:
+        if seed is not None:                    # the sampling stream continues where the saved run stopped
+            if seed != self.sample_seed:
                 import warnings
                 warnings.warn("checkpoint was written with sample_seed %d, this learner was built with %d: continuing the "
-                              "checkpoint's sampling stream" % (int(ck["fa_sample_seed"]), self.sample_seed))
-            if self._graphs is not None and int(ck["fa_sample_seed"]) != self.sample_seed:
-                raise RuntimeError("the rollout graph is already captured with another sample_seed: load() before reset()")
-            self.sample_seed = int(ck["fa_sample_seed"])
+                              "checkpoint's sampling stream" % (seed, self.sample_seed))
+            self.sample_seed = seed
 
     # ---- ensemble of frozen attacker strategies (train_fortattack_v2.py, learner.py:119-140) ----
     def load_attacker_ensemble(self, checkpoints, hidden_dim=128):

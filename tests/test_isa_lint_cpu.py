@@ -69,3 +69,42 @@ def test_clean_patterns_pass(tmp_path):
 def test_build_runs_the_lint_on_every_source():
     src = open(os.path.join(ROOT, "emergent-multiagent-strategies_amd", "build.py")).read()
     assert "isa_lint.lint(" in src and "--cuda-device-only" in src and "raise RuntimeError" in src
+
+
+def _model():
+    spec = importlib.util.spec_from_file_location("_isa_model", os.path.join(ROOT, "emergent-multiagent-strategies_amd", "isa_model.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_issue_model_of_the_shipped_step_kernel_is_generated_from_this_build_and_has_no_regression():
+    """csrc/fa_isa_model.json (what bench.py quotes as roofline.secondary) is what isa_model.py reads off the assembly of the
+    current build, every wave role's step loop is found, and the regression gate of build() is clean: no FLAT memory
+    instruction, no spill reload in wave 0's / the walls wave's loop, wave 0's loop within its recorded instruction count."""
+    import json
+    from emergent_multiagent_strategies_amd import build
+    build.build()
+    im = _model()
+    asm = os.path.join(ROOT, "emergent-multiagent-strategies_amd", "csrc", "_obj", "fa_step_pipe.s")
+    if not os.path.isfile(asm):
+        build.build(force=True)
+    m = im.model(asm)
+    assert json.load(open(im.OUT)) == json.loads(json.dumps(m))
+    assert im.check(m) == []
+    for tag in ("3v3", "5v5_3percu"):
+        k = m[tag]
+        assert set(k["loops"]) >= {"wave0", "pairs", "walls"}, k["loops"].keys()
+        w0 = k["loops"]["wave0"]
+        assert w0["barriers"] == 2 and w0.get("spill_reloads", 0) == 0 and w0["model_cycles_per_step"] == round(4 * w0["instructions_per_step"], 1)
+        assert k["kernel_totals"].get("flat", 0) == 0 and k["vgprs"] <= 168 and k["scratch_bytes"] == 0
+
+
+def test_issue_model_gate_flags_regressions():
+    im = _model()
+    ok = {"3v3": {"kernel_totals": {"flat": 0}, "vgpr_spill_count": 0,
+                  "loops": {"wave0": {"instructions": 491, "spill_reloads": 0}, "walls": {"instructions": 387}}}}
+    assert im.check(ok) == []
+    bad = {"3v3": {"kernel_totals": {"flat": 2}, "vgpr_spill_count": 3,
+                   "loops": {"wave0": {"instructions": 600, "spill_reloads": 4}, "walls": {"instructions": 400, "spill_reloads": 16}}}}
+    assert len(im.check(bad)) == 5
