@@ -95,10 +95,80 @@ __device__ __forceinline__ void store_acc_relu_mask(float *dst, const f32x16 &ac
 // Backward of the attention of ONE env by a 16-lane sub-group (cf. fa_attend.hip): rows r0 .. r0+n-1 of
 // dout / g (g is overwritten by dg), the env's nk key rows at key0, their gradient ADDED into dkey0 rows
 // (ADD) or written (!ADD).  W floats per row.
+#ifndef FA_ATTN_BWD_STREAM_KEYS
+#define FA_ATTN_BWD_STREAM_KEYS 1
+#endif
 template <int W, bool ADD, int MT>
 __device__ __forceinline__ void attend_env_bwd(const float *dout0, float *g0, const float *key0, float *dkey0, const float *attn0,
                                                int n, int nk, int q) {
     constexpr int C = W / 16;
+    if constexpr (FA_ATTN_BWD_STREAM_KEYS && MT > 4) {
+        // Larger teams: the keys are NOT held in registers (kv[MT][C] + dk[MT][C] = 96 registers at MT = 6 put 47 VGPRs of the
+        // 5v5 instantiation into scratch).  One pass over the keys per row, each key read from LDS once:
+        //     da_j = dout . k_j,  dot = sum_j a_j da_j,  U = sum_j (a_j da_j) k_j,  V = sum_j a_j k_j
+        // then dg = sum_j a_j (da_j - dot) k_j = U - dot V, and the key gradients need scalars only:
+        //     dk_j += a_j dout + a_j (da_j - dot) g.
+        float dk[MT][C];
+#pragma unroll
+        for (int j = 0; j < MT; ++j)
+#pragma unroll
+            for (int c = 0; c < C; ++c) dk[j][c] = 0.0f;
+        for (int i = 0; i < n; ++i) {
+            float gv[C], dov[C], U[C], V[C];
+#pragma unroll
+            for (int c = 0; c < C; c += 4) {
+                *reinterpret_cast<float4 *>(gv + c) = *reinterpret_cast<const float4 *>(g0 + i * LDA + q * C + c);
+                *reinterpret_cast<float4 *>(dov + c) = *reinterpret_cast<const float4 *>(dout0 + i * LDA + q * C + c);
+            }
+#pragma unroll
+            for (int c = 0; c < C; ++c) { U[c] = 0.0f; V[c] = 0.0f; }
+            float a[MT], da[MT], dot = 0.0f;
+#pragma unroll
+            for (int j = 0; j < MT; ++j) {
+                a[j] = 0.0f;
+                da[j] = 0.0f;
+                if (j < nk) {
+                    float kj[C];
+#pragma unroll
+                    for (int c = 0; c < C; c += 4)
+                        *reinterpret_cast<float4 *>(kj + c) = *reinterpret_cast<const float4 *>(key0 + j * LDA + q * C + c);
+                    a[j] = attn0[i * 8 + j];
+                    float d = 0.0f;
+#pragma unroll
+                    for (int c = 0; c < C; ++c) d = fmaf(dov[c], kj[c], d);
+                    da[j] = group16_sum(d);
+                    const float ada = a[j] * da[j];
+                    dot += ada;
+#pragma unroll
+                    for (int c = 0; c < C; ++c) { U[c] = fmaf(ada, kj[c], U[c]); V[c] = fmaf(a[j], kj[c], V[c]); }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < MT; ++j)
+                if (j < nk) {
+                    const float ds = a[j] * (da[j] - dot);
+#pragma unroll
+                    for (int c = 0; c < C; ++c) dk[j][c] = fmaf(a[j], dov[c], fmaf(ds, gv[c], dk[j][c]));
+                }
+            float dgv[C];
+#pragma unroll
+            for (int c = 0; c < C; ++c) dgv[c] = fmaf(-dot, V[c], U[c]);
+#pragma unroll
+            for (int c = 0; c < C; c += 4) *reinterpret_cast<float4 *>(g0 + i * LDA + q * C + c) = *reinterpret_cast<const float4 *>(dgv + c);
+        }
+#pragma unroll
+        for (int j = 0; j < MT; ++j)
+            if (j < nk) {
+#pragma unroll
+                for (int c = 0; c < C; c += 4) {
+                    float4 *p = reinterpret_cast<float4 *>(dkey0 + j * LDA + q * C + c);
+                    float4 v = *reinterpret_cast<const float4 *>(&dk[j][c]);
+                    if (ADD) { const float4 o = *p; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+                    *p = v;
+                }
+            }
+        return;
+    }
     float kv[MT][C], dk[MT][C];
 #pragma unroll
     for (int j = 0; j < MT; ++j)
