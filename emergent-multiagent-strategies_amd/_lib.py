@@ -128,6 +128,7 @@ EXPORTS = {
     "fa_set_state": (C.c_int, [c_p, C.POINTER(StateHost)]),
     "fa_selftest_math": (C.c_int, [c_p, C.c_uint64, C.c_uint64, c_p]),
     "fa_step_variant": (C.c_char_p, [c_p, C.c_int32]),
+    "fa_policy_variant": (C.c_char_p, [c_p]),
     "fa_rng_peek": (C.c_int, [c_p, C.c_int32, C.c_int32, c_p]),
 }
 

@@ -878,6 +878,14 @@ int fa_selftest_math(fa_env *env, uint64_t samples, uint64_t seed, uint64_t *mis
     return FA_OK;
 }
 
+const char *fa_policy_variant(fa_env *env) {
+    if (!env) return "";
+    const int E = env->cfg.num_envs, G = env->cfg.num_guards, A = env->cfg.num_attackers;
+    if (G > FA_POLICY_MAX_TEAM || A > FA_POLICY_MAX_TEAM) return "";
+    const int n_max = G > A ? G : A;
+    return fa_policy_tile_envs(E, G, A) * n_max > 64 ? "fa_policy_kernel<3, 8>" : "fa_policy_kernel<2, 4>";
+}
+
 const char *fa_step_variant(fa_env *env, int32_t num_steps) {
     if (!env) return "";
     return fa_step_variant_name(env->cfg.num_guards, env->cfg.num_attackers, env->cfg.num_envs, num_steps,

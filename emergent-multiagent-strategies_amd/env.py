@@ -352,6 +352,10 @@ class BatchedFortAttack(object):
         """fa_step_variant: name of the step kernel a launch of `num_steps` env-steps uses."""
         return self._lib.fa_step_variant(self._h, int(num_steps)).decode()
 
+    def policy_variant(self):
+        """fa_policy_variant: the fa_policy_kernel shape policy_act / collect_act launch (no attacker pool)."""
+        return self._lib.fa_policy_variant(self._h).decode()
+
     def rng_peek(self, e, count):
         out = np.empty(count, np.float64)
         _lib.check(self._lib.fa_rng_peek(self._h, int(e), int(count), out.ctypes.data_as(C.c_void_p)),

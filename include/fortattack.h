@@ -430,6 +430,9 @@ int fa_selftest_math(fa_env *env, uint64_t samples, uint64_t seed, uint64_t *mis
 /* Name of the step kernel variant a fa_step / fa_collect_rollout launch of `num_steps` env-steps
  * uses on this env (reporting only: bench.py labels its roofline line with it). */
 const char *fa_step_variant(fa_env *env, int32_t num_steps);
+/* which fa_policy_kernel shape fa_policy_act / fa_collect_act launch for this handle:
+ * "fa_policy_kernel<3, 8>" (96-row tiles, eight waves) or "fa_policy_kernel<2, 4>" (64-row tiles, four waves: small batches) */
+const char *fa_policy_variant(fa_env *env);
 /* next `count` random_sample() doubles env e would draw (does not advance the stream) */
 int fa_rng_peek(fa_env *env, int32_t e, int32_t count, double *out_host);
 

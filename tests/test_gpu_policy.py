@@ -51,11 +51,14 @@ def _torch_reference(pols, obs, G):
     return torch.cat((lg, la), 1), torch.cat((vg, va), 1)[..., 0]
 
 
-@pytest.mark.parametrize("G,A,E", [(3, 3, 4096), (5, 5, 1000), (2, 4, 333), (1, 3, 65), (8, 8, 50), (3, 3, 1), (4, 1, 97)])
+@pytest.mark.parametrize("G,A,E", [(3, 3, 4096), (5, 5, 1000), (2, 4, 333), (1, 3, 65), (8, 8, 50), (3, 3, 1), (4, 1, 97),
+                                   (5, 5, 4096),    # config 5's per-GPU shape: 2 x 216 workgroups of 19 envs
+                                   (5, 5, 3990), (5, 3, 4096), (2, 5, 4096)])
 def test_fused_forward_matches_torch_module(fa, G, A, E):
     N = G + A
     pols, packed = _policies(fa, G, A, 10 * G + A)
     eng = fa.BatchedFortAttack(E, G, A, 20)
+    assert eng.policy_variant() == ("fa_policy_kernel<3, 8>" if 2 * -(-E // (96 // max(G, A))) >= 192 else "fa_policy_kernel<2, 4>")
     obs = _obs(E, N, E)
     logits, value = _torch_reference(pols, obs, G)
     v, act, lp = eng.policy_act(obs, packed[0], packed[1], deterministic=True)
