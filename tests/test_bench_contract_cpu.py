@@ -1,4 +1,4 @@
-"""CPU: the committed record of the driver's bench command (profiles/r04_bench_final.json, written on the GPU box by
+"""CPU: the committed record of the driver's bench command (profiles/r05_bench_final.json, written on the GPU box by
 `python bench.py --gpus 1 --steps 20 --warmup 5`) carries every field the bench contract names, with consistent arithmetic --
 so that an edit of bench.py that drops or renames one shows up here, not at the end of a round."""
 import json
@@ -7,8 +7,12 @@ import os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def E_T(d):
+    return d["config"]["envs_per_gpu"] * d["config"]["rollout_steps"]
+
+
 def _rec():
-    return json.load(open(os.path.join(ROOT, "profiles", "r04_bench_final.json")))
+    return json.load(open(os.path.join(ROOT, "profiles", "r05_bench_final.json")))
 
 
 def test_bench_line_has_the_contract_fields():
@@ -36,6 +40,18 @@ def test_roofline_and_cpu_baseline_objects():
     assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["avg_launch_us"] * 1e-6) / 1e9) <= 1e-6 * r["achieved"]
     assert r["algorithmic_bytes_per_launch"] == r["algorithmic_bytes_per_env_step"] * r["env_steps_per_launch"]
     assert r["traffic"] is None or 0 < r["traffic"] < r["algorithmic_bytes_per_launch"]   # the state stays in registers
+    assert r["traffic_source"].startswith("live:")                                         # measured in the run (two PMC passes)
+    # the issue model of the step kernel, generated from the build's assembly, beside the measured cycles per step
+    s2 = r["secondary"]
+    for k in ("bound", "instrs_per_step", "fp64_instrs_per_step", "model_cycles_per_step", "measured_cycles_per_step", "frac",
+              "cus_with_two_workgroups", "generated_from"):
+        assert k in s2, k
+    assert abs(s2["model_cycles_per_step"] - 4 * s2["instrs_per_step"]) < 1e-6 and 0.5 < s2["frac"] < 1.0
+    assert abs(s2["frac"] - s2["model_cycles_per_step"] / s2["measured_cycles_per_step"]) < 1e-9
+    assert s2["cus_with_two_workgroups"] == s2["workgroups"] - s2["cus"] == 154
+    assert s2["spill_reloads_in_step_loops"]["wave0"] == 0 and s2["spill_reloads_in_step_loops"]["walls"] == 0
+    st = d["steady_state"]
+    assert st["timed_seconds"] >= 0.5 and abs(st["value"] - E_T(d) * st["steps"] / st["timed_seconds"]) <= 1e-6 * st["value"]
     c = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
