@@ -27,6 +27,9 @@ POLICY_ROW_DEVIATION = {"value_rel": 0.0, "logp_abs": 0.0}
 # the trajectory the training takes.  Bounds = 5 x / 4 x the largest.  (Round 3 allowed 1e-4 relative / 1e-4 absolute
 # without a record of what was observed.)
 VALUE_REL_TOL, LOGP_ABS_TOL = 2e-4, 6e-4
+# ... and for FRESHLY INITIALISED policies (the first rollout of a test, before any update: small logits, |V| < 1) the bound
+# round 3 used stays: a regression of the fused forward below the soak-derived bounds above still shows up there
+FRESH_VALUE_REL_TOL, FRESH_LOGP_ABS_TOL = 1e-4, 1e-4
 
 
 def _check_rollout_against_oracle(fa, learner, orc, first):
@@ -59,8 +62,8 @@ def _check_rollout_against_oracle(fa, learner, orc, first):
             lpdev = float((lp.view(T, E, -1, 1) - st.action_log_probs[:, :, own]).abs().max())
             POLICY_ROW_DEVIATION["value_rel"] = max(POLICY_ROW_DEVIATION["value_rel"], vdev)
             POLICY_ROW_DEVIATION["logp_abs"] = max(POLICY_ROW_DEVIATION["logp_abs"], lpdev)
-            assert vdev < VALUE_REL_TOL, (vdev, vscale)
-            assert lpdev < LOGP_ABS_TOL, lpdev
+            assert vdev < (FRESH_VALUE_REL_TOL if first else VALUE_REL_TOL), (vdev, vscale)
+            assert lpdev < (FRESH_LOGP_ABS_TOL if first else LOGP_ABS_TOL), lpdev
     # GAE over the stored rows == numpy oracle, bit for bit
     vals, rets = st.value_preds.cpu().numpy(), st.returns.cpu().numpy()
     return ep_start, rew, vals, msk, rets
