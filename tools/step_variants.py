@@ -8,7 +8,7 @@ import emergent_multiagent_strategies_amd as fa
 G = A = 3
 T = 128
 for E in [int(x) for x in sys.argv[1:]] or [4096]:
-    for kern in ("pipe", "pipe3", "waves1", "waves2", "waves3", "pairs", "chain"):
+    for kern in ("pipe", "pipe3", "waves1", "waves2", "waves3", ):
         try:
             eng = fa.BatchedFortAttack(E, G, A, 100, base_seed=0, step_kernel=kern)
         except Exception as exc:
