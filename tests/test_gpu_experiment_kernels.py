@@ -28,6 +28,13 @@ def test_product_library_refuses_the_experiment_kernels():
 def test_experiment_kernels_from_the_variant_library_vs_oracle():
     if not os.path.isfile(VARIANT):
         pytest.skip("tools/_build/lib_experiments.so not built (tools/build_variant.py experiments --add experiments/fa_step_experiments.hip)")
+    import ctypes
+    import emergent_multiagent_strategies_amd as fa
+    lib = ctypes.CDLL(VARIANT)
+    missing = [n for n in fa._lib.EXPORTS if not hasattr(lib, n)]
+    if missing or os.path.getmtime(VARIANT) < os.path.getmtime(fa._lib.lib_path()):
+        pytest.skip("tools/_build/lib_experiments.so is older than the product library (lacks %s): rebuild it with "
+                    "__graft_entry__.build() or tools/build_variant.py" % (missing[:3] or "nothing, but predates it"))
     env = dict(os.environ, FA_LIBRARY=VARIANT)
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.join(HERE, "experiment_kernels_cases.py")],
                        env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, cwd=os.path.dirname(HERE))
