@@ -109,7 +109,7 @@ def git_blob_hash(path):
         return None
 
 
-def live_traffic(kernel_prefix, args, budget_s=150):
+def live_traffic(kernel_prefix, args, budget_s=150, device=0):
     """HBM bytes per launch of the dominant kernel, measured NOW: two rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE cannot
     share one on gfx950) over `bench.py --pmc-probe` -- this run's workload, 3 + 12 rollout launches, nothing else -- each with
     --kernel-trace only, as MI355X_MICROARCH.md prescribes; bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (KiB counters, the
@@ -132,9 +132,23 @@ def live_traffic(kernel_prefix, args, budget_s=150):
             out = os.path.join(tmp, ctr)
             cmd = [exe, "--kernel-trace", "--pmc", ctr, "-f", "csv", "-d", out, "-o", "p", "--", sys.executable,
                    os.path.abspath(__file__), "--pmc-probe", "--envs", str(args.envs), "--rollout", str(args.rollout),
-                   "--guards", str(args.guards), "--attackers", str(args.attackers)] + (["--no-counters"] if args.no_counters else [])
-            r = subprocess.run(cmd, capture_output=True, text=True, timeout=left, cwd="/tmp",
-                               env=dict(os.environ, TMPDIR="/tmp"))
+                   "--guards", str(args.guards), "--attackers", str(args.attackers), "--probe-device", str(device)] + (
+                       ["--no-counters"] if args.no_counters else [])
+            # own session: when the budget runs out the WHOLE group goes (rocprofv3 and the profiled python under it --
+            # a surviving grandchild would keep the GPU busy under the sections timed after this one)
+            proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd="/tmp",
+                                    env=dict(os.environ, TMPDIR="/tmp"), start_new_session=True)
+            try:
+                _, err = proc.communicate(timeout=left)
+            except subprocess.TimeoutExpired:
+                import signal
+                try:
+                    os.killpg(proc.pid, signal.SIGKILL)
+                except OSError:
+                    pass
+                proc.communicate()
+                return None, "PMC pass %s ran out of the %d s budget (its process group was killed)" % (ctr, budget_s)
+            r = type("R", (), {"returncode": proc.returncode, "stderr": err})
             acc = []
             for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
                 for row in csv.DictReader(open(f)):
@@ -157,17 +171,20 @@ def pmc_probe(args):
     import torch
     import emergent_multiagent_strategies_amd as fa
     E, G, A, T = args.envs, args.guards, args.attackers, args.rollout
-    eng = fa.BatchedFortAttack(E, G, A, 100, base_seed=0, device=0, track_counters=not args.no_counters)
-    st = fa.JointRolloutStorage(T, E, G + A, device="cuda:0")
+    d = int(args.probe_device)
+    dev = "cuda:%d" % d
+    torch.cuda.set_device(d)
+    eng = fa.BatchedFortAttack(E, G, A, 100, base_seed=0, device=d, track_counters=not args.no_counters)
+    st = fa.JointRolloutStorage(T, E, G + A, device=dev)
     eng.bind_storage(st)
-    st.actions.copy_(torch.randint(0, 8, st.actions.shape, device="cuda:0", generator=torch.Generator(device="cuda:0").manual_seed(1234)))
+    st.actions.copy_(torch.randint(0, 8, st.actions.shape, device=dev, generator=torch.Generator(device=dev).manual_seed(1234)))
     eng.collect_reset()
     for _ in range(15):
         eng.collect_rollout(0, T)
     torch.cuda.synchronize()
 
 
-def issue_model(G, A, E, T, launch_s, clock_khz, n_cus):
+def issue_model(G, A, E, T, launch_s, clock_khz, n_cus, variant=None):
     """roofline.secondary: the issue model of wave 0's step loop generated at build time from the assembly
     (emergent-multiagent-strategies_amd/isa_model.py -> csrc/fa_isa_model.json) next to the cycles per step measured in this run."""
     path = os.path.join(ROOT, "emergent-multiagent-strategies_amd", "csrc", "fa_isa_model.json")
@@ -177,7 +194,10 @@ def issue_model(G, A, E, T, launch_s, clock_khz, n_cus):
         return {"error": "no issue model beside the library: %r" % (exc,)}
     epw = 64 // (G + A)
     grid = (E + epw - 1) // epw
-    tag = ("%dv%d" % (G, A)) + ("" if grid <= 2 * n_cus else "_3percu")
+    # which build was launched is the LIBRARY's decision (fa_step_variant: "... /3 per CU"), not re-derived from this
+    # device's CU count (the dispatch's threshold is a constant of the build)
+    three = ("/3 per CU" in variant) if variant is not None else (grid > 2 * n_cus)
+    tag = ("%dv%d" % (G, A)) + ("_3percu" if three else "")
     k = m.get(tag)
     if not k or "wave0" not in k.get("loops", {}):
         return {"error": "the issue model has no entry %r" % tag}
@@ -195,7 +215,7 @@ def issue_model(G, A, E, T, launch_s, clock_khz, n_cus):
             "spill_reloads_in_step_loops": {r: v.get("spill_reloads", 0) for r, v in k["loops"].items()},
             "vgprs": k["vgprs"], "sgpr_spill_count": k["sgpr_spill_count"], "scratch_bytes": k["scratch_bytes"],
             "workgroups": grid, "cus": n_cus,
-            "cus_with_two_workgroups": max(0, min(grid, 2 * n_cus) - n_cus) if grid <= 2 * n_cus else None,
+            "cus_with_two_workgroups": max(0, min(grid, 2 * n_cus) - n_cus) if not three else None,
             "what_the_rest_is": "two workgroup barriers per step (last arrival -> release ~ 200-250 cycles each) and the LDS round trips "
                                 "behind them; on CUs that hold two workgroups the wave shares its SIMD with a helper wave of the other"}
 
@@ -379,6 +399,19 @@ def main():
                          "all-gather, the merge kernel, the second-stream exchange run on one rank and must change nothing): how "
                          "a one-GPU box executes the RCCL path")
     ap.add_argument("--pmc-probe", action="store_true", help=argparse.SUPPRESS)   # the workload of the live PMC passes (live_traffic)
+    ap.add_argument("--probe-device", type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument("--exchange", choices=["auto", "library", "torch"], default="auto",
+                    help="who carries the per-rollout exchange of the advantage moments when there are several ranks (or "
+                         "--force-collective): 'library' = ONE C call per rollout (fa_gae_allreduce_normalize: scan + moments, "
+                         "ncclAllGather on the library's own RCCL communicator, merge + normalisation, all on the launch stream); "
+                         "'torch' = fa_gae_moments, torch.distributed.all_gather_into_tensor, fa_adv_merge_normalize from Python; "
+                         "'auto' = library with --backend nccl when RCCL can be opened, torch otherwise")
+    ap.add_argument("--graph-hot-path", action="store_true",
+                    help="capture rollout + collector tail (with its collective, when the exchange is the library's) in ONE "
+                         "hipGraph and replay it per bench step: the host's share per step is one graph launch.  The dominant "
+                         "kernel is then timed with hipEvents over eager launches right behind the timed region")
+    ap.add_argument("--no-pin", action="store_true",
+                    help="do not pin the rank's process to its slice of the GPU-local cores (collective.rank_binding)")
     ap.add_argument("--no-live-traffic", action="store_true",
                     help="do not run the two rocprofv3 PMC passes for roofline.traffic (quote the committed record instead)")
     ap.add_argument("--smoke", action="store_true",
@@ -445,8 +478,21 @@ def main():
 
     # which device and which CPUs every rank ended up on (a rank whose CPUs sit on the other socket, or two ranks on one
     # device, show up here and not as an unexplained slow rank)
+    orig_affinity = set(os.sched_getaffinity(0))
+    pin = None
+    if not args.no_pin:
+        # every rollout ends in a cross-rank exchange: a rank whose host thread migrates across sockets, or shares its
+        # cores with the other ranks' Python, paces all GPUs.  Each rank takes its own slice of its GPU's NUMA-local cores.
+        lists = None
+        if world > 1:
+            box = [None] * world
+            dist.all_gather_object(box, (rank, fa_dist.gpu_local_cpulist(local_rank)[0]))   # one node: every rank is local
+            lists = [l for _, l in sorted(box)]
+        pin = fa_dist.pin_rank_to_gpu_local_cpus(local_rank, rank, world, lists)
     binding = [{"rank": rank, "local_rank": local_rank, "device": torch.cuda.get_device_name(local_rank),
                 "device_index": local_rank, "pid": os.getpid(),
+                "cpu_affinity_at_start": "%d cpus: %s" % (len(orig_affinity), _ranges(sorted(orig_affinity))),
+                "pin": pin,
                 "cpu_affinity": "%d cpus: %s" % (len(os.sched_getaffinity(0)), _ranges(sorted(os.sched_getaffinity(0))))}]
     if world > 1:
         box = [None] * world
@@ -493,6 +539,19 @@ def main():
     tail_stream = torch.cuda.Stream() if args.two_stream_tail else None
     pending = {"tail_done": None}
     gather_buf = torch.zeros((world, N, 3), dtype=torch.float64, device=dev) if exchanging else None
+    # who carries the exchange: the library's own RCCL communicator (ONE C call per rollout, stream-ordered: nothing of
+    # the several-rank tail goes through the Python interpreter or torch.distributed) or torch.distributed from Python
+    lib_exchange, exchange_route = None, None
+    if exchanging:
+        want_lib = args.exchange == "library" or (args.exchange == "auto" and args.backend == "nccl"
+                                                   and bool(fa._lib.load().fa_rccl_available()))
+        if want_lib:
+            lib_exchange = fa_dist.LibraryExchange(dev)
+            if lib_exchange.ranks() != world:
+                raise SystemExit("bench.py: the library's RCCL communicator saw %d ranks, not %d" % (lib_exchange.ranks(), world))
+        exchange_route = ("library: fa_gae_allreduce_normalize (scan + moments, ncclAllGather on the library's communicator, merge + "
+                          "normalisation; one C call per rollout)" if lib_exchange is not None else
+                          "torch: fa_gae_moments, torch.distributed.all_gather_into_tensor (%s), fa_adv_merge_normalize" % args.backend)
 
     def exchange_and_normalise(mom, mean, std):
         if exchanging:
@@ -506,6 +565,9 @@ def main():
             main_stream.wait_event(pending["tail_done"])           # the previous statistics / normalisation have read `returns`
         if not exchanging and tail_stream is None:
             eng.gae_normalize(0.99, 0.95, out=adv)                 # one rank: scan + moment partials, fold + normalisation
+            return
+        if lib_exchange is not None and tail_stream is None:
+            lib_exchange.gae_allreduce_normalize(eng, 0.99, 0.95, out=adv)   # several ranks: the whole tail, one C call
             return
         mom, mean, std = eng.gae_moments(0.99, 0.95)               # scan + moment partials, fold: this rank's (n, mean, M2)
         if tail_stream is None:
@@ -538,6 +600,23 @@ def main():
     for _ in range(max(args.warmup, 1)):
         hot_path()
     torch.cuda.synchronize()
+    hot_graph = None
+    if args.graph_hot_path:
+        if tail_stream is not None or graph is not None or (exchanging and lib_exchange is None):
+            raise SystemExit("--graph-hot-path needs the fused launch, the one-stream tail and (with several ranks) --exchange library")
+        eager_hot_path = hot_path
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            eager_hot_path()                                       # the side stream's first use of every kernel / of the communicator
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        hot_graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(hot_graph, capture_error_mode="thread_local"):
+            eager_hot_path()
+        hot_path = hot_graph.replay
+        hot_path()
+        torch.cuda.synchronize()
     steps_requested = 20 if args.steps is None else args.steps
     min_seconds = (0.5 if args.steps is None else 0.0) if args.min_seconds is None else args.min_seconds
     steps = steps_requested
@@ -558,17 +637,27 @@ def main():
     # HIP events on the launch stream bracket every env rollout launch of the timed region
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
     t0 = time.perf_counter()
-    for k in range(steps):
-        ev[k][0].record()
-        env_rollout()
-        ev[k][1].record()
-        if not args.no_collector:
-            collector_tail()
+    if hot_graph is not None:
+        for k in range(steps):
+            hot_graph.replay()                    # rollout + tail (+ the collective): one graph launch per bench step
+    else:
+        for k in range(steps):
+            ev[k][0].record()
+            env_rollout()
+            ev[k][1].record()
+            if not args.no_collector:
+                collector_tail()
     host_enqueue = time.perf_counter() - t0       # the host's share: everything above only ENQUEUES work
     drain()
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
+    if hot_graph is not None:                     # the dominant kernel's launch time: eager launches right behind the timed region
+        for k in range(steps):
+            ev[k][0].record()
+            env_rollout()
+            ev[k][1].record()
+        torch.cuda.synchronize()
     rank_ms = [elapsed * 1e3 / steps]
     if world > 1:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -607,6 +696,12 @@ def main():
     if tail_stream is not None and not args.no_collector:
         mean, std = gae_adv_mean_std(eng, 0.99, 0.95)
         pipelined_ok = bool(torch.equal(eng.adv_normalize(mean, std), adv))
+    # ... and the library's one-call tail what the torch route leaves
+    lib_route_ok = None
+    if lib_exchange is not None and not args.no_collector and tail_stream is None:
+        mom, _, _ = eng.gae_moments(0.99, 0.95)
+        dist.all_gather_into_tensor(gather_buf.view(-1), mom.view(-1))
+        lib_route_ok = bool(torch.equal(eng.adv_merge_normalize(gather_buf)[0], adv))
     env_steps = world * E * T * steps
     value = env_steps / elapsed
     launches_per_rollout = T if graph is not None else 1
@@ -620,9 +715,24 @@ def main():
     # MI355X_MICROARCH.md); only attached when the run uses the profiled configuration.
     traffic, traffic_src = None, None
     kernel_name = eng.step_variant(T // launches_per_rollout)   # which step kernel these launches ran
+    closed = None
+    if not args.no_closed_loop:
+        closed = closed_loop(fa, args, rank, local_rank, world, dev, barrier)
+    # a default 3v3 run on one GPU also carries the 5v5 shapes one GPU can run (BASELINE config 5's per-GPU shape)
+    extra = {}
+    if world == 1 and (G, A) == (3, 3) and not args.no_5v5:
+        extra["single_env_facade"] = facade_record(fa, G, A, dev)
+        extra["fused_5v5"] = fused_record(fa, 5, 5, E, T, dev)
+        if not args.no_closed_loop:
+            extra["closed_loop_5v5"] = closed_loop(fa, args, rank, local_rank, world, dev, barrier, G=5, A=5, rollouts=10, updates=2)
+            extra["closed_loop_5v5_ens5"] = closed_loop(fa, args, rank, local_rank, world, dev, barrier, G=5, A=5, ensemble=5,
+                                                        rollouts=10, updates=2)
+    esweep_rec = esweep(fa, G, A, dev) if (rank == 0 and world == 1 and not args.no_esweep and (G, A) == (3, 3)) else None
+
+    # the PMC passes run BEHIND every timed section (they start two more processes on this GPU)
     if rank == 0 and world == 1 and graph is None and not args.no_live_traffic:
         torch.cuda.synchronize()
-        traffic, traffic_src = live_traffic(kernel_name.split("/")[0], args)
+        traffic, traffic_src = live_traffic(kernel_name.split("/")[0], args, device=local_rank)
         live_note = traffic_src
     else:
         live_note = "not attempted (several ranks, per-step launches, or --no-live-traffic)"
@@ -642,19 +752,6 @@ def main():
                     break
             except Exception:
                 pass
-
-    closed = None
-    if not args.no_closed_loop:
-        closed = closed_loop(fa, args, rank, local_rank, world, dev, barrier)
-    # a default 3v3 run on one GPU also carries the 5v5 shapes one GPU can run (BASELINE config 5's per-GPU shape)
-    extra = {}
-    if world == 1 and (G, A) == (3, 3) and not args.no_5v5:
-        extra["single_env_facade"] = facade_record(fa, G, A, dev)
-        extra["fused_5v5"] = fused_record(fa, 5, 5, E, T, dev)
-        if not args.no_closed_loop:
-            extra["closed_loop_5v5"] = closed_loop(fa, args, rank, local_rank, world, dev, barrier, G=5, A=5, rollouts=10, updates=2)
-            extra["closed_loop_5v5_ens5"] = closed_loop(fa, args, rank, local_rank, world, dev, barrier, G=5, A=5, ensemble=5,
-                                                        rollouts=10, updates=2)
 
     if rank == 0:
         res = {
@@ -694,10 +791,11 @@ def main():
                 "algorithmic_bytes_per_launch": bytes_per_launch,
                 "algorithmic_bytes_per_env_step": algorithmic_bytes_per_env_step(N),
                 "env_steps_per_launch": E * (T // launches_per_rollout),
-                "avg_launch_us": launch_s * 1e6, "timed_by": "hipEvents on the launch stream, %d launches" % (
-                    len(ev) * launches_per_rollout),
+                "avg_launch_us": launch_s * 1e6, "timed_by": "hipEvents on the launch stream, %d launches%s" % (
+                    len(ev) * launches_per_rollout, "" if hot_graph is None else
+                    " (eager launches right behind the timed region: the timed region itself replays one hipGraph per step)"),
                 "secondary": (issue_model(G, A, E, T, launch_s, getattr(torch.cuda.get_device_properties(local_rank), "clock_rate", 2400000),
-                                          torch.cuda.get_device_properties(local_rank).multi_processor_count)
+                                          torch.cuda.get_device_properties(local_rank).multi_processor_count, variant=kernel_name)
                               if graph is None and kernel_name.startswith("fa_step_pipe_kernel") else None)},
             "env_rollout_ms": roll_ms,
             "steady_state": steady,
@@ -709,8 +807,12 @@ def main():
                              "backend": dist.get_backend() if exchanging else None,
                              "rccl_ranks": (dist.get_world_size() if (exchanging and dist.get_backend() == "nccl") else 0),
                              "rank_binding": binding,
-                             "per_rollout": "one all_gather_into_tensor of N x 3 f64 (advantage moments) + exact merge, between the "
+                             "per_rollout": "one all-gather of N x 3 f64 (advantage moments) + exact merge, between the "
                                             "moments sweep and the normalisation",
+                             "exchange_route": exchange_route,
+                             "library_rccl_ranks": lib_exchange.ranks() if lib_exchange is not None else 0,
+                             "hot_path_in_one_graph": hot_graph is not None,
+                             "library_exchange_equals_torch_route": lib_route_ok,
                              "forced_on_one_rank": bool(args.force_collective),
                              "second_stream_exchange_equals_one_stream": pipelined_ok,
                              "per_optimizer_step": "one all_reduce of the flat f32 gradient buffer (149 908 floats) per team"}
@@ -722,10 +824,15 @@ def main():
             res["closed_loop"] = closed
         if extra:
             res.update(extra)
-        if world == 1 and not args.no_esweep and (G, A) == (3, 3):
-            res["esweep"] = esweep(fa, G, A, dev)
+        if esweep_rec is not None:
+            res["esweep"] = esweep_rec
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(E, G, A, T)
+            now = os.sched_getaffinity(0)
+            os.sched_setaffinity(0, orig_affinity)     # the CPU baseline gets every core the process started with, not the rank's slice
+            try:
+                res["cpu_baseline"] = cpu_baseline(E, G, A, T)
+            finally:
+                os.sched_setaffinity(0, now)
         sys.stdout.flush()
         try:                                   # what C libraries printf'ed while fd 1 pointed at stderr (RCCL's version
             import ctypes                      # banner sits in the C stdio buffer until exit) must not follow the line
@@ -736,6 +843,8 @@ def main():
         print(json.dumps(res), flush=True)
         sys.stdout.flush()
         os.dup2(2, 1)                          # anything printed after the line (process-group teardown) goes to stderr again
+    if lib_exchange is not None:
+        lib_exchange.close()
     if exchanging:
         dist.destroy_process_group()
 

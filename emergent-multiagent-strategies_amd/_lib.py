@@ -123,6 +123,7 @@ EXPORTS = {
     "fa_rccl_comm_destroy": (C.c_int, [c_p]),
     "fa_rccl_comm_ranks": (C.c_int, [c_p]),
     "fa_adv_allreduce": (C.c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "fa_gae_allreduce_normalize": (C.c_int, [c_p, C.c_double, C.c_double, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "fa_grad_allreduce": (C.c_int, [c_p, C.c_int64, c_p, c_p]),
     "fa_get_state": (C.c_int, [c_p, C.POINTER(StateHost)]),
     "fa_set_state": (C.c_int, [c_p, C.POINTER(StateHost)]),

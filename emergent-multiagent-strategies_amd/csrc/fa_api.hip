@@ -741,8 +741,27 @@ int fa_ppo_grad(const fa_ppo_grad_io *io, void *stream) {
         a.scale_out = io->out + FA_SLAB_LOSS + 8;
         a.normalize = io->normalize != 0;
     }
-    FA_HIP(fa_launch_train(a, s));                                                  // tiles: forward, losses, dL/dX
-    FA_HIP(fa_launch_train_dw(a.rec_a, a.rec_b, (int)tiles, dw_slabs, s));          // dW = X^T dY over all rows
+    // Chunked hand-off (FA_PPO_CHUNKS = C, default 1): the tiles of the minibatch in C chunks, tile kernel and weight-gradient
+    // GEMM alternating on the stream -- chunk c's records (320 KB per tile) are consumed while they may still sit in the 256 MiB
+    // Infinity Cache and every chunk reuses the SAME record slots; the GEMM continues from the partial slabs of the earlier
+    // chunks (fixed chunk order: still bitwise reproducible run to run).
+    static const int chunks_env = [] { const char *v = getenv("FA_PPO_CHUNKS"); const int c = v ? atoi(v) : 1; return c < 1 ? 1 : c; }();
+    const int chunks = chunks_env > (int)tiles ? (int)tiles : chunks_env;
+    if (chunks == 1) {
+        FA_HIP(fa_launch_train(a, s));                                                  // tiles: forward, losses, dL/dX
+        FA_HIP(fa_launch_train_dw(a.rec_a, a.rec_b, (int)tiles, dw_slabs, false, s));   // dW = X^T dY over all rows
+    } else {
+        const int per = ((int)tiles + chunks - 1) / chunks;
+        a.rec_b = io->hsave + (size_t)per * 3 * FA_RECA_FLOATS;     // the record slots of ONE chunk
+        a.rec_g = a.rec_b + (size_t)per * FA_RECB_FLOATS;
+        for (int c = 0, t0 = 0; t0 < (int)tiles; ++c, t0 += per) {
+            a.tile0 = t0;
+            a.ntiles = (int)tiles - t0 < per ? (int)tiles - t0 : per;
+            a.rec_tile0 = 0;
+            FA_HIP(fa_launch_train(a, s));
+            FA_HIP(fa_launch_train_dw(a.rec_a, a.rec_b, a.ntiles, dw_slabs, c > 0, s));
+        }
+    }
     FA_HIP(fa_launch_train_reduce(a.mslab, (int)tiles, mpart, dw_slabs, io->out, s)); // fixed-order sums -> out
     return FA_OK;
 }

@@ -163,6 +163,20 @@ int fa_adv_allreduce(fa_env *env, const double *moments, double *gathered, void 
     return FA_OK;
 }
 
+int fa_gae_allreduce_normalize(fa_env *env, double gamma, double tau, void *nccl_comm, double *moments, double *gathered,
+                               float *adv_out, double *mean_out, double *std_out, void *stream) {
+    if (!env || !moments || !gathered || !nccl_comm || !adv_out || !mean_out || !std_out)
+        return fa_api_fail(FA_ERR_INVALID, "fa_gae_allreduce_normalize: null argument");
+    if (int rc = need("fa_gae_allreduce_normalize")) return rc;
+    int world = 0;
+    FA_NCCL("fa_gae_allreduce_normalize", rccl().CommCount(static_cast<ncclComm_t>(nccl_comm), &world));
+    // scan + moment partials, fold (this rank's triple; mean_out / std_out hold the LOCAL values until the merge rewrites them)
+    if (int rc = fa_gae_moments(env, gamma, tau, moments, mean_out, std_out, stream)) return rc;
+    FA_NCCL("fa_gae_allreduce_normalize", rccl().AllGather(moments, gathered, (size_t)fa_num_agents(env) * 3, ncclFloat64,
+                                                           static_cast<ncclComm_t>(nccl_comm), static_cast<hipStream_t>(stream)));
+    return fa_adv_merge_normalize(env, gathered, world, adv_out, mean_out, std_out, stream);
+}
+
 int fa_grad_allreduce(float *flat, int64_t n, void *nccl_comm, void *stream) {
     if (!flat || !nccl_comm || n < 1) return fa_api_fail(FA_ERR_INVALID, "fa_grad_allreduce: null argument");
     if (int rc = need("fa_grad_allreduce")) return rc;

@@ -7,6 +7,11 @@
 #include "fa_policy.h"
 #include "fortattack.h"
 
+// the records' stores (tile kernel) and loads (weight-gradient GEMM) carry the non-temporal hint: each is written once and
+// read once by another kernel (0: plain accesses -- the A/B of the chunked hand-off, profiles/r06_experiments/)
+#ifndef FA_REC_NT
+#define FA_REC_NT 1
+#endif
 #define FA_TR_ROWS 32 // (env, agent) rows per workgroup tile: four 32 x 132-float LDS buffers, two workgroups per CU
 
 // Transposed weights for the backward's dX = dY W^T GEMMs, each in the packed B-operand order of
@@ -81,6 +86,9 @@ struct FaTrainArgs {
     float *rec_b;              // [tiles][FA_RECB_FLOATS]
     float *rec_g;              // [tiles][3][FA_REC_PLANE]
     int32_t B, G, A, team;     // team 0: the guards' policy on the guards' rows; 1: the attackers'
+    int32_t tile0, ntiles;     // this launch covers tiles [tile0, tile0 + ntiles) of the minibatch (ntiles 0: all of them);
+    int32_t rec_tile0;         // its records go to slots [rec_tile0, rec_tile0 + ntiles) of rec_a / rec_b / rec_g (chunked
+                               // hand-off to fa_train_dw_kernel: fa_api.hip fa_ppo_grad); mslab stays indexed by the tile
     const float *mask_part;    // with scale == null: FA_MASK_PARTS partial alive-mask sums (fa_launch_mask_parts); the
     float *scale_out;          // kernel derives the scale pair itself (`normalize`: divide by the mask mean) and
     int32_t normalize;         // workgroup 0 leaves it at scale_out[0..1]
@@ -108,7 +116,8 @@ hipError_t fa_launch_adam(float *p, float *g, float *m, float *v, float *steps, 
                           float beta1, float beta2, float eps, float max_norm, float *scratch, const float *hyper,
                           hipStream_t st);
 // The weight-gradient GEMMs over the records of `tiles` tiles -> FA_DW_WGS_A + FA_DW_WGS_B partial slabs at dw_slabs
-hipError_t fa_launch_train_dw(const float *rec_a, const float *rec_b, int tiles, float *dw_slabs, hipStream_t st);
+// (accumulate: the partial slabs already hold the sums of earlier chunks of the minibatch -- start from them)
+hipError_t fa_launch_train_dw(const float *rec_a, const float *rec_b, int tiles, float *dw_slabs, bool accumulate, hipStream_t st);
 // mslab of `tiles` tiles -> mpart[FA_MRED_PARTS][FA_MSLAB_FLOATS]; then out[k], k < FA_SLAB_LOSS + 8, from the partial
 // slabs and mpart (fixed orders: reproducible); out[FA_SLAB_LOSS + 8..9] is where fa_ppo_grad keeps the scale pair when
 // the caller passes none

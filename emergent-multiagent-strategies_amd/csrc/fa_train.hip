@@ -250,15 +250,16 @@ __device__ __forceinline__ void fa_train_body(const FaTrainArgs &a) {
     const int n = a.team == 0 ? a.G : a.A, m = N - n;
     const int own0 = a.team == 0 ? 0 : a.G, opp0 = a.team == 0 ? a.G : 0;
     const int ET = TR / (n > m ? n : m);
-    const int e0 = blockIdx.x * ET;
+    const int tile = blockIdx.x + a.tile0, slot = blockIdx.x + a.rec_tile0;
+    const int e0 = tile * ET;
     if (e0 >= a.B) return;
     const int ne = (a.B - e0) < ET ? (a.B - e0) : ET;
     const int RU = ET * n, RO = ET * m; // rows in use (own / opponent side); envs beyond `ne` are zero rows
     const float *W = a.w;
     const float4 *Wq = reinterpret_cast<const float4 *>(a.w), *Tq = reinterpret_cast<const float4 *>(a.wt);
-    float *mslab = a.mslab + (size_t)blockIdx.x * FA_MSLAB_FLOATS;
-    float *recA = a.rec_a + (size_t)blockIdx.x * 3 * FA_RECA_FLOATS, *recB = a.rec_b + (size_t)blockIdx.x * FA_RECB_FLOATS;
-    float *recG = a.rec_g + (size_t)blockIdx.x * 3 * FA_REC_PLANE;
+    float *mslab = a.mslab + (size_t)tile * FA_MSLAB_FLOATS;
+    float *recA = a.rec_a + (size_t)slot * 3 * FA_RECA_FLOATS, *recB = a.rec_b + (size_t)slot * FA_RECB_FLOATS;
+    float *recG = a.rec_g + (size_t)slot * 3 * FA_REC_PLANE;
 
     // dense tile <-> LDS: W floats per row (128: four 16-byte pieces per thread; 64: two)
     auto save_tile = [&](const float *src, float *dst) { // 32 x 128 LDS -> global
@@ -267,7 +268,11 @@ __device__ __forceinline__ void fa_train_body(const FaTrainArgs &a) {
             const int r = k >> 5, c4 = k & 31;
             // (non-temporal: a record is read once, by another kernel -- it need not displace the weights in L2)
             typedef float v4f __attribute__((ext_vector_type(4)));
+#if FA_REC_NT
             __builtin_nontemporal_store(*reinterpret_cast<const v4f *>(src + r * LDA + c4 * 4), reinterpret_cast<v4f *>(dst) + k);
+#else
+            reinterpret_cast<v4f *>(dst)[k] = *reinterpret_cast<const v4f *>(src + r * LDA + c4 * 4);
+#endif
         }
     };
     auto save_tile64 = [&](const float *src, float *dst) { // 32 x 64 LDS (at src, row stride LDA) -> global
@@ -489,7 +494,7 @@ __device__ __forceinline__ void fa_train_body(const FaTrainArgs &a) {
             const float cnt = (float)a.B * (float)n, mm = t / cnt;
             unmask = mm != 0.0f ? mm : 1.0f;
             inv_count = a.normalize ? 1.0f / (cnt * unmask) : 1.0f / cnt;
-            if (blockIdx.x == 0 && lane == 0) { a.scale_out[0] = inv_count; a.scale_out[1] = unmask; }
+            if (tile == 0 && lane == 0) { a.scale_out[0] = inv_count; a.scale_out[1] = unmask; }
         }
         float vl = 0.0f, al = 0.0f, en = 0.0f, mk = 0.0f;
         float dlg[FA_NUM_ACTIONS], dval = 0.0f;
@@ -834,7 +839,7 @@ int fa_train_tile_envs(int G, int A) { return TR / (G > A ? G : A); }
 
 hipError_t fa_launch_train(const FaTrainArgs &a, hipStream_t st) {
     const int ET = fa_train_tile_envs(a.G, a.A);
-    const dim3 grid((a.B + ET - 1) / ET), block(NTH);
+    const dim3 grid(a.ntiles > 0 ? a.ntiles : (a.B + ET - 1) / ET), block(NTH);
     const int big = a.G > a.A ? a.G : a.A;
 #define FA_TRAIN_LAUNCH(MT)                                                                                   \
     do {                                                                                                      \

@@ -33,9 +33,15 @@ __device__ __forceinline__ void store_tile_global(float *dst, int C, const f32x1
     for (int reg = 0; reg < 16; ++reg) dst[((reg & 3) + 8 * (reg >> 2) + 4 * hh) * C + col] = acc[reg];
 }
 
+__device__ __forceinline__ void load_tile_global(const float *src, int C, f32x16 &acc, int lane) {
+    const int col = lane & 31, hh = lane >> 5;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) acc[reg] = src[((reg & 3) + 8 * (reg >> 2) + 4 * hh) * C + col];
+}
+
 // JOB 0: records A (FA_RECA_FLOATS floats), JOB 1: records B (FA_RECB_FLOATS)
 template <int JOB>
-__device__ __forceinline__ void dw_range(const float *__restrict__ rec, int q0, int q1, float *__restrict__ slab, float *sT) {
+__device__ __forceinline__ void dw_range(const float *__restrict__ rec, int q0, int q1, float *slab, float *sT, bool accumulate) {
     constexpr int RF = JOB == 0 ? FA_RECA_FLOATS : FA_RECB_FLOATS;
     constexpr int NS = RF / 4 / DW_NT; // 16-byte pieces per thread and record: 8 / 10
     constexpr int NACC = JOB == 0 ? 6 : 5;
@@ -45,6 +51,18 @@ __device__ __forceinline__ void dw_range(const float *__restrict__ rec, int q0, 
     f32x16 acc[NACC];
 #pragma unroll
     for (int t = 0; t < NACC; ++t) acc[t] = f32x16{};
+    if (accumulate) { // a later chunk of the minibatch: continue from the slab the earlier chunks left (fixed chunk order)
+        if (JOB == 0) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) load_tile_global(slab + ((up * 4 + u) * 32) * 128 + c * 32, 128, acc[c], lane);
+            load_tile_global(slab + 256 * 128 + (u * 32) * 128 + (up * 2) * 32, 128, acc[4], lane);
+            load_tile_global(slab + 256 * 128 + (u * 32) * 128 + (up * 2 + 1) * 32, 128, acc[5], lane);
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) load_tile_global(slab + (u * 32) * 256 + (up * 4 + c) * 32, 256, acc[c], lane);
+            load_tile_global(slab + 128 * 256 + up * 64 * 64 + ((u >> 1) * 32) * 64 + (u & 1) * 32, 64, acc[4], lane);
+        }
+    }
     // this wave's operand columns inside the LDS image of a record (row stride RS floats)
     //   A: waves 0..3: X = h_in block u with dZ blocks 0..3 (dW7 rows 32u..) and with dg blocks 0, 1 (dA_m rows 32u..);
     //      waves 4..7: X = hmix block u with dZ blocks 0..3 (dW7 rows 128 + 32u..), h_in block u with dg blocks 2, 3
@@ -85,7 +103,11 @@ __device__ __forceinline__ void dw_range(const float *__restrict__ rec, int q0, 
         const int cur = ((q - q0) & 1) * FA_RECB_FLOATS, nxt = FA_RECB_FLOATS - cur; // float offsets of the two images
         src = reinterpret_cast<const f32x4 *>(rec + (size_t)(q + 1 < q1 ? q + 1 : q) * RF);
 #pragma unroll
+#if FA_REC_NT
         for (int j = 0; j < NS; ++j) stage[j] = __builtin_nontemporal_load(src + tid + j * DW_NT); // (read once)
+#else
+        for (int j = 0; j < NS; ++j) stage[j] = src[tid + j * DW_NT];
+#endif
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int t = 0; t < FA_TR_ROWS / 2; ++t) {
@@ -120,17 +142,17 @@ __device__ __forceinline__ void dw_range(const float *__restrict__ rec, int q0, 
 }
 
 __global__ __launch_bounds__(DW_NT) void fa_train_dw_kernel(const float *__restrict__ rec_a, const float *__restrict__ rec_b, int tiles,
-                                                            float *__restrict__ dw_slabs) {
+                                                            float *dw_slabs, bool accumulate) {
     __shared__ __attribute__((aligned(16))) float sT[2 * FA_RECB_FLOATS]; // 2 x 80 KB: two records (all of a CU's LDS)
     const int b = blockIdx.x;
     if (b < FA_DW_WGS_A) {
         const int cnt = tiles * 3, per = (cnt + FA_DW_WGS_A - 1) / FA_DW_WGS_A;
         const int q0 = min(b * per, cnt), q1 = min(q0 + per, cnt);
-        dw_range<0>(rec_a, q0, q1, dw_slabs + (size_t)b * FA_DWA_FLOATS, sT);
+        dw_range<0>(rec_a, q0, q1, dw_slabs + (size_t)b * FA_DWA_FLOATS, sT, accumulate);
     } else {
         const int w = b - FA_DW_WGS_A, per = (tiles + FA_DW_WGS_B - 1) / FA_DW_WGS_B;
         const int q0 = min(w * per, tiles), q1 = min(q0 + per, tiles);
-        dw_range<1>(rec_b, q0, q1, dw_slabs + (size_t)FA_DW_WGS_A * FA_DWA_FLOATS + (size_t)w * FA_DWB_FLOATS, sT);
+        dw_range<1>(rec_b, q0, q1, dw_slabs + (size_t)FA_DW_WGS_A * FA_DWA_FLOATS + (size_t)w * FA_DWB_FLOATS, sT, accumulate);
     }
 }
 
@@ -203,8 +225,8 @@ __global__ __launch_bounds__(128) void fa_train_reduce_kernel(const float *__res
 }
 } // namespace
 
-hipError_t fa_launch_train_dw(const float *rec_a, const float *rec_b, int tiles, float *dw_slabs, hipStream_t st) {
-    hipLaunchKernelGGL(fa_train_dw_kernel, dim3(FA_DW_WGS_A + FA_DW_WGS_B), dim3(DW_NT), 0, st, rec_a, rec_b, tiles, dw_slabs);
+hipError_t fa_launch_train_dw(const float *rec_a, const float *rec_b, int tiles, float *dw_slabs, bool accumulate, hipStream_t st) {
+    hipLaunchKernelGGL(fa_train_dw_kernel, dim3(FA_DW_WGS_A + FA_DW_WGS_B), dim3(DW_NT), 0, st, rec_a, rec_b, tiles, dw_slabs, accumulate);
     return hipGetLastError();
 }
 

@@ -19,6 +19,7 @@ without torch uses; here torch.distributed only hands the 128-byte communicator 
 one rank and must change nothing): how the GPU tests execute RCCL on a one-GPU box.
 """
 import ctypes as C
+import os
 
 import torch
 import torch.distributed as dist
@@ -79,6 +80,27 @@ class LibraryExchange(object):
                                           self._std.data_ptr(), C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)),
                 "fa_adv_allreduce")
         return self._mean, self._std
+
+    def gae_allreduce_normalize(self, eng, gamma=0.99, tau=0.95, out=None):
+        """The whole several-rank collector tail of one rollout as ONE library call on the current stream
+        (fa_gae_allreduce_normalize: GAE scan + this rank's moments, the all-gather, merge + normalisation): what
+        bench.py --gpus N enqueues per rollout -- no Python between the four device operations, capturable in a hipGraph.
+        Returns (adv (T, E, N, 1) float32, mean (N,), std (N,)) over ALL ranks' samples."""
+        if self._gather is None:
+            self._gather = torch.zeros((self.world, eng.N, 3), dtype=torch.float64, device=eng.device)
+            self._mean = torch.zeros(eng.N, dtype=torch.float64, device=eng.device)
+            self._std = torch.zeros(eng.N, dtype=torch.float64, device=eng.device)
+        if getattr(self, "_mom", None) is None:
+            self._mom = torch.zeros((eng.N, 3), dtype=torch.float64, device=eng.device)
+        if out is None:
+            out = torch.empty((eng.storage.num_steps, eng.E, eng.N, 1), dtype=torch.float32, device=eng.device)
+        L = self._L
+        L.check(L.load().fa_gae_allreduce_normalize(eng._h, float(gamma), float(tau), self.comm, self._mom.data_ptr(),
+                                                    self._gather.data_ptr(), out.data_ptr(), self._mean.data_ptr(),
+                                                    self._std.data_ptr(),
+                                                    C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)),
+                "fa_gae_allreduce_normalize")
+        return out, self._mean, self._std
 
     def all_reduce_(self, flat):
         """Sum `flat` (float32, contiguous) over the ranks in place, on the current stream."""
@@ -169,3 +191,67 @@ def shard_range(num_envs_total, rank, world):
         raise ValueError("num_envs_total must be divisible by the world size")
     per = num_envs_total // world
     return rank * per, per
+
+
+# ---- rank -> CPU binding -------------------------------------------------------------------------------------------
+# Every rollout ends in a cross-rank exchange, so the slowest rank's host thread paces all GPUs: a rank whose thread
+# migrates between sockets, or shares cores with seven other Python ranks, stalls the job.  Each rank therefore pins
+# itself to its own slice of the cores that are local to its GPU (the PCI device's NUMA node from sysfs).
+
+def parse_cpulist(text):
+    """'0-3,8,10-11' -> [0, 1, 2, 3, 8, 10, 11] (the kernel's cpulist format)."""
+    cpus = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.extend(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def choose_cpus(allowed, gpu_local, slot, slots):
+    """The CPUs rank `slot` of the `slots` ranks that share `gpu_local` should run on: an even, disjoint split of
+    (allowed & gpu_local) -- of `allowed` alone when the GPU's local list is unknown or lies outside the cgroup.
+    Pure function (tests/test_dist_cpu.py).  Returns (cpus, source)."""
+    allowed = sorted(set(allowed))
+    local = sorted(set(allowed) & set(gpu_local or []))
+    pool, source = (local, "numa-local") if local else (allowed, "allowed-split")
+    slots = max(1, int(slots))
+    per = len(pool) // slots
+    if per < 1:                                     # more ranks than cores: share the pool
+        return pool, source + " (shared: fewer cores than ranks)"
+    slot = int(slot) % slots
+    return pool[slot * per:(slot + 1) * per], source
+
+
+def gpu_local_cpulist(device_index):
+    """The cpulist sysfs reports as local to the GPU's PCI device ([] when it cannot be told)."""
+    try:
+        p = torch.cuda.get_device_properties(device_index)
+        bdf = "%04x:%02x:%02x.0" % (int(getattr(p, "pci_domain_id", 0)), int(p.pci_bus_id), int(p.pci_device_id))
+        with open("/sys/bus/pci/devices/%s/local_cpulist" % bdf) as f:
+            return parse_cpulist(f.read()), bdf
+    except Exception:
+        return [], None
+
+
+def pin_rank_to_gpu_local_cpus(device_index, local_rank, local_world, peers_local_lists=None):
+    """os.sched_setaffinity for this process (see above).  `peers_local_lists`: every local rank's GPU-local cpulist in
+    local-rank order (so that ranks whose GPUs share a NUMA node split it); None = assume all ranks share one list.
+    Returns a record for the bench line's `rank_binding`."""
+    before = sorted(os.sched_getaffinity(0))
+    local, bdf = gpu_local_cpulist(device_index)
+    if peers_local_lists:
+        same = [r for r, l in enumerate(peers_local_lists) if sorted(l) == sorted(local)]
+        slot, slots = (same.index(local_rank), len(same)) if local_rank in same else (local_rank, local_world)
+    else:
+        slot, slots = local_rank, local_world
+    cpus, source = choose_cpus(before, local, slot, slots)
+    rec = {"pci": bdf, "gpu_local_cpus": len(local), "source": source, "slot": "%d/%d" % (slot, slots)}
+    try:
+        os.sched_setaffinity(0, cpus)
+        rec["pinned_to"] = len(cpus)
+    except OSError as exc:
+        rec["pinned_to"] = None
+        rec["error"] = str(exc)
+    return rec

@@ -413,6 +413,14 @@ int fa_rccl_comm_ranks(void *comm);          /* ncclCommCount (>= 1), negative o
  * fa_adv_merge in rank order: every rank ends with the same bits in mean_out / std_out (N doubles each). */
 int fa_adv_allreduce(fa_env *env, const double *moments, double *gathered, void *nccl_comm, double *mean_out,
                      double *std_out, void *stream);
+/* The WHOLE several-rank collector tail of one rollout as ONE call (what bench.py --gpus N and a torch-free consumer
+ * enqueue per rollout; learner.py:191-211 + ppo.py:121-124 over all ranks): fa_gae_moments (GAE scan + this rank's
+ * moments -> `moments`, N x 3), ncclAllGather into `gathered` (world, N, 3), then fa_adv_merge_normalize (merge in rank
+ * order + normalisation -> adv_out (T, E, N), mean_out / std_out).  Four device operations enqueued back to back on
+ * `stream`, nothing on the host in between; capturable in a hipGraph together with fa_collect_rollout (the collective
+ * becomes a graph node: tests/test_gpu_rccl.py).  == fa_gae_moments + fa_adv_allreduce + fa_adv_normalize bit for bit. */
+int fa_gae_allreduce_normalize(fa_env *env, double gamma, double tau, void *nccl_comm, double *moments, double *gathered,
+                               float *adv_out, double *mean_out, double *std_out, void *stream);
 /* ncclAllReduce(sum, float32) of `n` floats in place: the flat gradient buffer of one optimizer step (the
  * un-normalised gradients + loss sums + this rank's alive-mask mean, learner.py GraphedPPOStep). */
 int fa_grad_allreduce(float *flat, int64_t n, void *nccl_comm, void *stream);

@@ -181,3 +181,38 @@ def test_two_rank_ppo_update_equals_one_rank_on_the_union_minibatches():
         moved = max(moved, float((v - init[k]).abs().max()))
     assert moved > 1e-3                                                      # the update did something
     assert np.abs(losses.numpy() - got[0][1]).max() < 1e-5
+
+
+def test_rank_cpu_binding_split():
+    """dist.choose_cpus / parse_cpulist: the slice of cores a rank pins itself to (bench.py `rank_binding`): disjoint
+    per rank, NUMA-local where the GPU's list intersects the cgroup's, an even split of the allowed set otherwise."""
+    from emergent_multiagent_strategies_amd.dist import choose_cpus, parse_cpulist
+    assert parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11] and parse_cpulist("") == []
+    allowed = list(range(0, 256))
+    node0, node1 = parse_cpulist("0-63,128-191"), parse_cpulist("64-127,192-255")
+    got = [choose_cpus(allowed, node0 if r < 4 else node1, r % 4, 4) for r in range(8)]
+    assert all(src == "numa-local" and len(c) == 32 for c, src in got)
+    flat = [c for cpus, _ in got for c in cpus]
+    assert len(flat) == len(set(flat)) == 256                                  # disjoint, every core used once
+    assert set(got[0][0]) <= set(node0) and set(got[7][0]) <= set(node1)
+    # a cgroup of 16 CPUs that the GPU's node does not cover: even split of what is allowed
+    cpus, src = choose_cpus(range(100, 116), node0[:8], 1, 2)
+    assert src == "allowed-split" and cpus == list(range(108, 116))
+    # unknown GPU locality
+    cpus, src = choose_cpus(range(8), [], 3, 4)
+    assert src == "allowed-split" and cpus == [6, 7]
+    # more ranks than cores: share
+    cpus, src = choose_cpus(range(4), [], 5, 8)
+    assert cpus == [0, 1, 2, 3] and "shared" in src
+
+
+def test_pin_rank_record_and_restore():
+    from emergent_multiagent_strategies_amd.dist import pin_rank_to_gpu_local_cpus
+    before = os.sched_getaffinity(0)
+    try:
+        rec = pin_rank_to_gpu_local_cpus(0, 1, 2)            # no GPU here: falls back to the allowed-set split
+        now = os.sched_getaffinity(0)
+        assert rec["pinned_to"] == len(now) and now <= before and (len(before) < 2 or len(now) == len(before) // 2)
+        assert rec["source"].startswith("allowed-split") or rec["source"].startswith("numa-local")
+    finally:
+        os.sched_setaffinity(0, before)

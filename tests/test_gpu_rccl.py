@@ -49,6 +49,60 @@ def _collector(fa, exchange=None):
     return mean.cpu().numpy().copy(), std.cpu().numpy().copy()
 
 
+def _one_call_tail(fa, ex):
+    """fa_gae_allreduce_normalize (the several-rank collector tail as ONE library call: scan + moments, ncclAllGather,
+    merge + normalisation) eagerly and CAPTURED in a hipGraph together with fa_collect_rollout -- what `bench.py --gpus N
+    [--graph-hot-path]` enqueues per rollout -- against fa_gae_normalize (the one-rank tail) from the same state, two
+    rollouts each: advantages, mean, std."""
+    E, G, A, T = 640, 3, 3, 32
+    N = G + A
+    g = torch.Generator(device="cuda").manual_seed(11)
+    acts = torch.randint(0, 8, (T, E, N, 1), device="cuda", generator=g)
+    vals = torch.randn((T + 1, E, N, 1), device="cuda", generator=g)
+
+    def fresh():
+        eng = fa.BatchedFortAttack(E, G, A, 15, base_seed=6)
+        st = fa.JointRolloutStorage(T, E, N, device="cuda")
+        eng.bind_storage(st)
+        st.actions.copy_(acts)
+        st.value_preds.copy_(vals)
+        eng.collect_reset()
+        return eng, st
+
+    res = {}
+    eng, st = fresh()                                           # reference: no collective
+    ref = []
+    for _ in range(2):
+        eng.collect_rollout(0, T)
+        adv, _, mean, std = eng.gae_normalize(0.99, 0.95)
+        torch.cuda.synchronize()
+        ref.append((adv.clone(), mean.clone(), std.clone(), st.returns.clone()))
+    eng, st = fresh()                                           # eager: one C call per rollout
+    ok = True
+    for k in range(2):
+        eng.collect_rollout(0, T)
+        adv, mean, std = ex.gae_allreduce_normalize(eng, 0.99, 0.95)
+        torch.cuda.synchronize()
+        ok &= bool(torch.equal(adv, ref[k][0]) and torch.equal(mean, ref[k][1]) and torch.equal(std, ref[k][2])
+                   and torch.equal(st.returns, ref[k][3]))
+    res["eager"] = ok
+    eng, st = fresh()                                           # captured: rollout + tail + the collective in ONE graph
+    out = torch.empty((T, E, N, 1), device="cuda")
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+        eng.collect_rollout(0, T)
+        ex.gae_allreduce_normalize(eng, 0.99, 0.95, out=out)
+    ok = True
+    for k in range(2):
+        graph.replay()
+        torch.cuda.synchronize()
+        ok &= bool(torch.equal(out, ref[k][0]) and torch.equal(ex._mean, ref[k][1]) and torch.equal(ex._std, ref[k][2])
+                   and torch.equal(st.returns, ref[k][3]))
+    res["captured"] = ok
+    return res
+
+
 def _learner(fa, exchange="torch"):
     """Two collect + update rounds of the closed-loop learner (hidden_dim 128, hipGraphs, fused update)."""
     torch.manual_seed(0)
@@ -109,6 +163,7 @@ def _worker(route, port, q):
             ex.all_reduce_(z)
             torch.cuda.synchronize()
             assert float(z.sum()) == 2000.0
+            out["one_call"] = _one_call_tail(fa, ex)
             ex.close()
             L, out["coll_p"], out["coll_l"], out["coll_a"], two = _learner(fa, exchange="rccl")
             assert L._exch.ranks() == 1
@@ -132,6 +187,8 @@ def test_one_rank_through_rccl_changes_nothing(route):
     assert out["rccl_maps"], "librccl was not mapped into the process"
     assert out["ranks"] == 1 and (out["backend"] == "nccl" if route == "torch-nccl" else "rccl" in out["backend"])
     assert out["two_graphs"]                                        # every optimizer step: graph 1 -> all-reduce -> graph 2
+    if route == "library":                                          # the one-call tail, eager and inside a hipGraph
+        assert out["one_call"] == {"eager": True, "captured": True}, out["one_call"]
     # the advantage statistics through the all-gather + merge: the same bits
     assert np.array_equal(out["plain_ms"][0], out["coll_ms"][0]) and np.array_equal(out["plain_ms"][1], out["coll_ms"][1])
     # the same rollout (sampling does not depend on the exchange) ...
@@ -162,3 +219,28 @@ def test_bench_exchange_on_rccl_with_one_rank():
     assert c["rccl_ranks"] == 1 and c["backend"] == "nccl" and c["forced_on_one_rank"] is True
     assert c["second_stream_exchange_equals_one_stream"] is True
     assert r["steps"] == 10 and r["value"] > 0 and r["closed_loop"]["train_env_steps_per_s"] > 0
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_bench_library_exchange_one_call_per_rollout(graph):
+    """bench.py's DEFAULT several-rank hot path (`--exchange auto` with backend nccl): the whole collector tail of a rollout --
+    scan + moments, ncclAllGather on the library's own communicator, merge + normalisation -- is ONE C call on the launch
+    stream (no torch.distributed call per rollout), optionally captured with the rollout in one hipGraph; it must leave the
+    advantages the torch route leaves, and the rank pins itself to its slice of the GPU-local cores."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--force-collective", "--backend", "nccl",
+                          "--envs", "1024", "--rollout", "32", "--steps", "10", "--warmup", "2", "--no-cpu-baseline", "--no-5v5",
+                          "--no-esweep", "--no-closed-loop", "--no-live-traffic"] + (["--graph-hot-path"] if graph else []),
+                         cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    c = r["collective"]
+    assert c["rccl_ranks"] == 1 and c["library_rccl_ranks"] == 1 and c["exchange_route"].startswith("library")
+    assert c["library_exchange_equals_torch_route"] is True and c["hot_path_in_one_graph"] is graph
+    b = c["rank_binding"][0]
+    assert b["pin"] is not None and b["pin"]["pinned_to"] and b["pin"]["pinned_to"] >= 1
+    assert r["steps"] == 10 and r["value"] > 0 and r["roofline"]["avg_launch_us"] > 0
