@@ -18,6 +18,7 @@
 // No atomics; every sum has a fixed order: bitwise reproducible.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "fa_train.h"
 
@@ -156,6 +157,226 @@ __global__ __launch_bounds__(DW_NT) void fa_train_dw_kernel(const float *__restr
     }
 }
 
+// ---- the same GEMM on the bf16 matrix cores with fp32-class accuracy: the three-way split -------------------------------
+// gfx950's v_mfma_f32_32x32x16_bf16 retires 16 x the MACs per cycle of v_mfma_f32_32x32x2_f32.  A float is the EXACT sum of
+// three bf16 numbers -- hi = x rounded to nearest at 8 significant bits, mid = the remainder rounded likewise, lo = what is
+// left (<= 6 bits): x = hi + mid + lo with no error, |mid| <= 2^-9 |x|, |lo| <= 2^-18 |x| -- so x y = the sum of nine
+// bf16 x bf16 products, each exact in the MFMA's fp32 accumulator.  The six largest are issued (hi hi, hi mid, mid hi,
+// hi lo, lo hi, mid mid); the three dropped ones (mid lo, lo mid, lo lo) are <= 2^-26 |x y| together and of either sign (a
+// truncating split leaves them all with the sign of x y: a bias the size of one fp32 rounding per product, measured as
+// 2-3 x the fp32 kernel's error against an fp64 GEMM) -- a quarter of ONE fp32 rounding of the product, which the fp32
+// FMA chain of the kernel above commits at every step.  6 MFMAs of 32 cycles cover K = 16 where the fp32 form needs 8 of 64:
+// 2.67 x less matrix-core time for the same sums.  The split happens once per element, in registers, on the way from global
+// memory to the LDS image (the records in HBM stay fp32); the image holds the operands already in MFMA fragment order --
+// [plane][k half][term][column][8 bf16 of consecutive rows] -- so that both operands of an MFMA are one 16-byte LDS read,
+// conflict-free.  Half a record (16 rows = one K = 16 step) per stage, two images, one barrier per stage.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// x -> the bit patterns of (hi, mid, lo) in the HIGH halves of three words
+__device__ __forceinline__ unsigned bf16_rne_hi(float x) { // round to nearest even at bit 16, result in the high half
+    const unsigned u = __float_as_uint(x);
+    return (u + 0x7fffu + ((u >> 16) & 1u)) & 0xffff0000u;
+}
+__device__ __forceinline__ void split3(float x, unsigned &h, unsigned &m, unsigned &l) {
+#ifdef DW3_KO_SPLIT
+    h = m = l = __float_as_uint(x);
+    return;
+#endif
+    h = bf16_rne_hi(x);
+    const float r1 = x - __uint_as_float(h);            // exact; |r1| <= 2^-9 |x|
+    m = bf16_rne_hi(r1);
+    l = __float_as_uint(r1 - __uint_as_float(m));       // exact, <= 2^-18 |x| on x's 2^-23 grid: <= 6 significant bits, a bf16 as it is
+}
+// the high halves of (a, b) -> one word, a in the low half (element 2j), b in the high half (element 2j + 1)
+__device__ __forceinline__ unsigned pack_hi(unsigned a, unsigned b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
+
+// image geometry: a "plane" is 128 columns wide; element (plane, khalf, term, col) = 16 bytes
+#define DW3_PLANE_BYTES (2 * 3 * 128 * 16)
+__device__ __forceinline__ int dw3_off(int plane, int khalf, int term, int col) { // in 16-byte units
+    return ((plane * 2 + khalf) * 3 + term) * 128 + col;
+}
+
+// one unit of staging: 8 rows x 2 columns of fp32 (rows r0 .. r0 + 7 of a matrix with row stride `rs`) -> registers
+struct Dw3Unit { f32x2 v[8]; };
+__device__ __forceinline__ void dw3_load(Dw3Unit &u, const float *__restrict__ base, int rs) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) u.v[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x2 *>(base + j * rs));
+}
+// registers -> split -> the image: column col + c of (plane, khalf), c = 0 / 1 (two rows at a time: short live ranges)
+__device__ __forceinline__ void dw3_store_col(const Dw3Unit &u, int c, u32x4 *img, int plane, int khalf, int col) {
+    u32x4 H, M, L;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        unsigned h0, m0, l0, h1, m1, l1;
+        split3(u.v[2 * j][c], h0, m0, l0);
+        split3(u.v[2 * j + 1][c], h1, m1, l1);
+        H[j] = pack_hi(h0, h1);
+        M[j] = pack_hi(m0, m1);
+        L[j] = pack_hi(l0, l1);
+    }
+    img[dw3_off(plane, khalf, 0, col + c)] = H;
+    img[dw3_off(plane, khalf, 1, col + c)] = M;
+    img[dw3_off(plane, khalf, 2, col + c)] = L;
+}
+
+struct Dw3Frag { bf16x8 h, m, l; };
+__device__ __forceinline__ Dw3Frag dw3_frag(const u32x4 *img, int plane, int khalf, int col) {
+    Dw3Frag f;
+    f.h = __builtin_bit_cast(bf16x8, img[dw3_off(plane, khalf, 0, col)]);
+    f.m = __builtin_bit_cast(bf16x8, img[dw3_off(plane, khalf, 1, col)]);
+    f.l = __builtin_bit_cast(bf16x8, img[dw3_off(plane, khalf, 2, col)]);
+    return f;
+}
+// acc += X^T Y over the 16 rows of the stage: the six largest of the nine cross products, small ones first
+__device__ __forceinline__ void dw3_mma(f32x16 &acc, const Dw3Frag &x, const Dw3Frag &y) {
+#ifdef DW3_KO_MFMA // (knock-out builds, tools/build_variant.py: where the kernel's time goes)
+    acc[0] += __builtin_bit_cast(float, (unsigned)x.h[0]) + __builtin_bit_cast(float, (unsigned)y.l[7]);
+    return;
+#endif
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x.h, y.l, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x.l, y.h, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x.m, y.m, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x.h, y.m, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x.m, y.h, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x.h, y.h, acc, 0, 0, 0);
+}
+
+// JOB 0: records A = planes [h_in | hmix | dZ | dg], each 32 x 128.  JOB 1: records B as five 128-wide virtual planes
+// [h3 | dPV[:, :128] | dPV[:, 128:] | mix_o, de_opp | h1, dg_o].  A stage = rows 16 s .. 16 s + 15 of a record.
+template <int JOB>
+__device__ __forceinline__ void dw3_range(const float *__restrict__ rec, int qfirst, int qstride, int nrec, float *slab, u32x4 *sI,
+                                          bool accumulate) {
+    constexpr int RF = JOB == 0 ? FA_RECA_FLOATS : FA_RECB_FLOATS;
+    constexpr int NP = JOB == 0 ? 4 : 5;
+    constexpr int IMG = NP * DW3_PLANE_BYTES / 16; // 16-byte units per image
+    constexpr int NACC = JOB == 0 ? 6 : 5;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, hh = lane >> 5, u = wave & 3, up = wave >> 2;
+    f32x16 acc[NACC];
+#pragma unroll
+    for (int t = 0; t < NACC; ++t) acc[t] = f32x16{};
+    if (accumulate) {
+        if (JOB == 0) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) load_tile_global(slab + ((up * 4 + u) * 32) * 128 + c * 32, 128, acc[c], lane);
+            load_tile_global(slab + 256 * 128 + (u * 32) * 128 + (up * 2) * 32, 128, acc[4], lane);
+            load_tile_global(slab + 256 * 128 + (u * 32) * 128 + (up * 2 + 1) * 32, 128, acc[5], lane);
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) load_tile_global(slab + (u * 32) * 256 + (up * 4 + c) * 32, 256, acc[c], lane);
+            load_tile_global(slab + 128 * 256 + up * 64 * 64 + ((u >> 1) * 32) * 64 + (u & 1) * 32, 64, acc[4], lane);
+        }
+    }
+    // staging: thread -> unit (plane, khalf, column pair); JOB 1 has 640 units: threads 0..127 take one of plane 4 as well
+    const int s_plane = tid >> 7, s_kh = (tid >> 6) & 1, s_cp = tid & 63;
+    auto unit_src = [&](int plane, int kh, int cp, const float *r, int &rs) -> const float * { // first of the unit's 8 rows
+        const int col = 2 * cp;
+        if (JOB == 0) { rs = 128; return r + plane * FA_REC_PLANE + (kh * 8) * 128 + col; }
+        if (plane == 0) { rs = 128; return r + FA_RECB_H3 + (kh * 8) * 128 + col; }
+        if (plane <= 2) { rs = 256; return r + FA_RECB_DPV + (kh * 8) * 256 + (plane - 1) * 128 + col; }
+        rs = 64; // two 32 x 64 matrices side by side
+        const int basef = plane == 3 ? (col < 64 ? FA_RECB_MO : FA_RECB_DE) : (col < 64 ? FA_RECB_H1 : FA_RECB_DGO);
+        return r + basef + (kh * 8) * 64 + (col & 63);
+    };
+    // the unit's first row inside a record and its row stride: loop invariant
+    int rs, rs2 = 64;
+    const float *ubase = unit_src(s_plane, s_kh, s_cp, rec, rs);
+    const float *ubase2 = JOB == 1 ? unit_src(4, s_kh, s_cp, rec, rs2) : rec;
+    const bool two = JOB == 1 && tid < 128;
+    // Prefetch distance TWO stages, two register sets: the loads of stage s + 2 are requested at the top of stage s; what
+    // stage s splits and writes to LDS (the image of stage s + 1) was requested a whole stage earlier, so the split's VALU
+    // work interleaves with the MFMAs without anybody waiting for HBM (requested one stage ahead only, the scheduler hoists
+    // the split in front of the MFMAs and every stage starts with an exposed HBM round trip: 148 us per call instead of ...).
+    Dw3Unit s0, s1, t0, t1; // (t*: the second unit of JOB 1's threads 0..127)
+    // The workgroup's records are qfirst, qfirst + qstride, ...: INTERLEAVED over the workgroups, so that at any moment the
+    // 200 / 56 workgroups read one contiguous window of the record array (contiguous per-workgroup ranges put 256 streams at a
+    // fixed 1.6 MB stride: a few HBM channels take most of the requests)
+    const int st0 = 0, st1 = 2 * nrec;
+    auto stage_load = [&](int st, Dw3Unit &a, Dw3Unit &b) { // st = 2 * (local record) + half
+        st = st < st1 ? st : st1 - 1;
+#ifdef DW3_KO_LOAD
+        st &= 1; // every stage re-reads the workgroup's first record: L2 hits
+#endif
+        const size_t ro = (size_t)(qfirst + (st >> 1) * qstride) * RF;
+        const int row0 = (st & 1) * 16;
+        dw3_load(a, ubase + ro + row0 * rs, rs);
+        if (two) dw3_load(b, ubase2 + ro + row0 * rs2, rs2);
+    };
+    // One stage: six groups of six MFMAs (five for JOB 1), the operands of group g + 1 read from LDS ahead of group g's MFMAs,
+    // the split + LDS write of the NEXT stage's image spread over the groups a column at a time; scheduling fences between the
+    // groups (left alone the scheduler hoists all LDS reads and the whole split to the top: 82 spilled registers)
+    auto stage = [&](const u32x4 *cur, u32x4 *nxt, const Dw3Unit &a, const Dw3Unit &b) {
+        const Dw3Frag xa = dw3_frag(cur, JOB == 0 ? (up ? 1 : 0) : 0, hh, u * 32 + li);
+        const Dw3Frag xb = JOB == 0 ? dw3_frag(cur, 0, hh, u * 32 + li) : dw3_frag(cur, 3 + up, hh, (u >> 1) * 32 + li);
+        auto yfrag = [&](int g) {
+            if (JOB == 0) return g < 4 ? dw3_frag(cur, 2, hh, g * 32 + li) : dw3_frag(cur, 3, hh, (up * 2 + g - 4) * 32 + li);
+            return g < 4 ? dw3_frag(cur, 1 + up, hh, g * 32 + li) : dw3_frag(cur, 3 + up, hh, 64 + (u & 1) * 32 + li);
+        };
+        Dw3Frag y = yfrag(0);
+#pragma unroll
+        for (int g = 0; g < NACC; ++g) {
+            Dw3Frag yn = y;
+            if (g + 1 < NACC) yn = yfrag(g + 1);
+            dw3_mma(acc[g], g < 4 ? xa : xb, y);
+            if (g == 0) dw3_store_col(a, 0, nxt, s_plane, s_kh, 2 * s_cp);
+            if (g == 1) dw3_store_col(a, 1, nxt, s_plane, s_kh, 2 * s_cp);
+            if (JOB == 1 && two && g == 2) dw3_store_col(b, 0, nxt, 4, s_kh, 2 * s_cp);
+            if (JOB == 1 && two && g == 3) dw3_store_col(b, 1, nxt, 4, s_kh, 2 * s_cp);
+            y = yn;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    u32x4 *img0 = sI, *img1 = sI + IMG;
+    if (st0 < st1) {
+        stage_load(st0, s0, t0);
+        stage_load(st0 + 1, s1, t1);
+        dw3_store_col(s0, 0, img0, s_plane, s_kh, 2 * s_cp);
+        dw3_store_col(s0, 1, img0, s_plane, s_kh, 2 * s_cp);
+        if (two) {
+            dw3_store_col(t0, 0, img0, 4, s_kh, 2 * s_cp);
+            dw3_store_col(t0, 1, img0, 4, s_kh, 2 * s_cp);
+        }
+    }
+    __syncthreads();
+    for (int st = st0; st < st1; st += 2) { // (a whole number of records: an even number of stages)
+        stage_load(st + 2, s0, t0);
+        __builtin_amdgcn_sched_barrier(0);
+        stage(img0, img1, s1, t1);
+        __syncthreads();
+        stage_load(st + 3, s1, t1);
+        __builtin_amdgcn_sched_barrier(0);
+        stage(img1, img0, s0, t0);
+        __syncthreads();
+    }
+    if (JOB == 0) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) store_tile_global(slab + ((up * 4 + u) * 32) * 128 + c * 32, 128, acc[c], lane);
+        store_tile_global(slab + 256 * 128 + (u * 32) * 128 + (up * 2) * 32, 128, acc[4], lane);
+        store_tile_global(slab + 256 * 128 + (u * 32) * 128 + (up * 2 + 1) * 32, 128, acc[5], lane);
+    } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) store_tile_global(slab + (u * 32) * 256 + (up * 4 + c) * 32, 256, acc[c], lane);
+        store_tile_global(slab + 128 * 256 + up * 64 * 64 + ((u >> 1) * 32) * 64 + (u & 1) * 32, 64, acc[4], lane);
+    }
+}
+
+__global__ __launch_bounds__(DW_NT) void fa_train_dw3_kernel(const float *__restrict__ rec_a, const float *__restrict__ rec_b, int tiles,
+                                                             float *dw_slabs, bool accumulate) {
+    __shared__ __attribute__((aligned(16))) u32x4 sI[2 * 5 * DW3_PLANE_BYTES / 16]; // two images of <= 5 planes: 120 KB
+    const int b = blockIdx.x;
+    if (b < FA_DW_WGS_A) {
+        const int cnt = tiles * 3;
+        dw3_range<0>(rec_a, b, FA_DW_WGS_A, b < cnt ? (cnt - b + FA_DW_WGS_A - 1) / FA_DW_WGS_A : 0, dw_slabs + (size_t)b * FA_DWA_FLOATS, sI,
+                     accumulate);
+    } else {
+        const int w = b - FA_DW_WGS_A;
+        dw3_range<1>(rec_b, w, FA_DW_WGS_B, w < tiles ? (tiles - w + FA_DW_WGS_B - 1) / FA_DW_WGS_B : 0,
+                     dw_slabs + (size_t)FA_DW_WGS_A * FA_DWA_FLOATS + (size_t)w * FA_DWB_FLOATS, sI, accumulate);
+    }
+}
+
 // Stage 1 of the small gradients: part p sums the tiles [p * per, (p + 1) * per) of mslab (coalesced: a thread per
 // element), FA_MRED_PARTS parts.
 __global__ __launch_bounds__(256) void fa_train_mred_kernel(const float *__restrict__ mslab, int tiles, float *__restrict__ mpart) {
@@ -226,6 +447,12 @@ __global__ __launch_bounds__(128) void fa_train_reduce_kernel(const float *__res
 } // namespace
 
 hipError_t fa_launch_train_dw(const float *rec_a, const float *rec_b, int tiles, float *dw_slabs, bool accumulate, hipStream_t st) {
+    // FA_DW_GEMM=f32: the fp32-MFMA form (rounds 4-5; the definition the split form is tested against)
+    const char *v = getenv("FA_DW_GEMM");
+    if (!(v && v[0] == 'f')) {
+        hipLaunchKernelGGL(fa_train_dw3_kernel, dim3(FA_DW_WGS_A + FA_DW_WGS_B), dim3(DW_NT), 0, st, rec_a, rec_b, tiles, dw_slabs, accumulate);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(fa_train_dw_kernel, dim3(FA_DW_WGS_A + FA_DW_WGS_B), dim3(DW_NT), 0, st, rec_a, rec_b, tiles, dw_slabs, accumulate);
     return hipGetLastError();
 }

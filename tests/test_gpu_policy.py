@@ -287,6 +287,67 @@ def test_fused_ppo_grad_matches_torch_autograd(fa, G, A, team, B, clipped):
     assert max(worst.values()) < 2e-3, worst
 
 
+@pytest.mark.parametrize("G,A,B", [(3, 3, 16384), (5, 5, 4096)])
+def test_dw_gemm_split_bf16_is_fp32_class_against_an_fp64_gemm(fa, monkeypatch, G, A, B):
+    """The weight-gradient GEMM of fa_ppo_grad on the bf16 matrix cores (csrc/fa_train_dw.hip fa_train_dw3_kernel: every
+    float32 operand split EXACTLY into three bf16 terms, six of the nine cross products, fp32 accumulate) against the
+    fp32-MFMA form (FA_DW_GEMM=f32) -- both against the SAME products summed in float64 from the operand records the tile
+    kernel left (config 3's minibatch: 1 639 tiles, 4 917 + 1 639 records).  Bar: the split form's largest error is at most
+    2 x the fp32-MFMA kernel's (it is smaller: its products are exact, only the accumulation rounds)."""
+    from emergent_multiagent_strategies_amd import mpnn_pack as mp_
+    from emergent_multiagent_strategies_amd.env import ppo_grad
+    N = G + A
+    pols, _ = _policies(fa, G, A, 3)
+    g = torch.Generator(device="cuda").manual_seed(B)
+    obs = _obs(B, N, 5)
+    rnd = lambda *s: torch.randn(*s, device="cuda", generator=g)
+    action = torch.randint(0, 8, (B, N, 1), device="cuda", generator=g)
+    value_pred, ret, adv = rnd(B, N, 1), rnd(B, N, 1), rnd(B, N, 1)
+    old_logp = -torch.rand((B, N, 1), device="cuda", generator=g) * 2.5
+    w, wt = torch.zeros(mp_.WEIGHT_FLOATS, device="cuda"), torch.zeros(mp_.TRANS_FLOATS, device="cuda")
+    mp_.pack_from_params(mp_.kernel_params(pols[0]), w, wt)
+    scale = torch.tensor([1.0 / (B * G), 1.0], device="cuda")
+    outs = {}
+    sc = None
+    for mode in ("f32", "bf16x3"):
+        if mode == "f32":
+            monkeypatch.setenv("FA_DW_GEMM", "f32")
+        else:
+            monkeypatch.delenv("FA_DW_GEMM", raising=False)
+        o, sc = ppo_grad(obs, action, value_pred, ret, old_logp, adv, w, wt, scale, 0, G, A, 0.2, 0.5, 0.01, True, scratch=sc)
+        torch.cuda.synchronize()
+        outs[mode] = {k: v.clone() for k, v in mp_.split_plain(o).items()}
+        o2, _ = ppo_grad(obs, action, value_pred, ret, old_logp, adv, w, wt, scale, 0, G, A, 0.2, 0.5, 0.01, True, scratch=sc)
+        torch.cuda.synchronize()
+        L = mp_.WEIGHT_FLOATS + 4
+        assert torch.equal(o[:L], o2[:L]), mode                         # bitwise reproducible, either form
+    # the products in float64 from the records (csrc/fa_train.h: FA_RECA_* / FA_RECB_*)
+    tiles = -(-B // (32 // max(G, A)))
+    hs = sc[1]
+    ra = hs[:tiles * 3 * 16384].view(tiles * 3, 4, 32, 128)
+    rb = hs[tiles * 3 * 16384:tiles * 3 * 16384 + tiles * 20480].view(tiles, 20480)
+    ref = {k: 0 for k in ("W7", "AM", "W8", "BO", "AO")}
+    for q in range(0, tiles * 3, 1024):
+        c = ra[q:q + 1024].double()
+        ref["W7"] = ref["W7"] + torch.einsum("qrk,qrj->kj", torch.cat((c[:, 0], c[:, 1]), -1), c[:, 2])
+        ref["AM"] = ref["AM"] + torch.einsum("qrk,qrj->kj", c[:, 0], c[:, 3])
+    for q in range(0, tiles, 1024):
+        c = rb[q:q + 1024].double()
+        ref["W8"] = ref["W8"] + torch.einsum("qrk,qrj->kj", c[:, :4096].view(-1, 32, 128), c[:, 4096:12288].view(-1, 32, 256))
+        ref["BO"] = ref["BO"] + torch.einsum("qrk,qrj->kj", c[:, 12288:14336].view(-1, 32, 64), c[:, 14336:16384].view(-1, 32, 64))
+        ref["AO"] = ref["AO"] + torch.einsum("qrk,qrj->kj", c[:, 16384:18432].view(-1, 32, 64), c[:, 18432:20480].view(-1, 32, 64))
+    err = {m: {k: float((outs[m][k].double() - ref[k]).abs().max() / ref[k].abs().max()) for k in ref} for m in outs}
+    print({m: {k: "%.1e" % v for k, v in e.items()} for m, e in err.items()})
+    for k in ref:
+        assert float(ref[k].abs().max()) > 0
+        assert err["f32"][k] < 1e-5, (k, err["f32"][k])                 # sanity of the reference itself
+        assert err["bf16x3"][k] <= 2.0 * err["f32"][k] + 1e-8, (k, err)
+    # everything that is not a product of this GEMM is the tile kernel's: identical bits in both forms
+    for k in outs["f32"]:
+        if k not in ref:
+            assert torch.equal(outs["f32"][k], outs["bf16x3"][k]), k
+
+
 def test_fused_ppo_grad_normalises_the_advantages_itself(fa):
     """fa_ppo_grad with (adv_mean, adv_std) instead of an advantage tensor (ppo.py:121-124 inside the kernel): bit for bit
     the result of passing what fa_adv_normalize writes -- (A - (float)mean) / ((float)std + 1e-5f) in float32."""
