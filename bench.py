@@ -187,7 +187,10 @@ def pmc_probe(args):
 def issue_model(G, A, E, T, launch_s, clock_khz, n_cus, variant=None):
     """roofline.secondary: the issue model of wave 0's step loop generated at build time from the assembly
     (emergent-multiagent-strategies_amd/isa_model.py -> csrc/fa_isa_model.json) next to the cycles per step measured in this run."""
-    path = os.path.join(ROOT, "emergent-multiagent-strategies_amd", "csrc", "fa_isa_model.json")
+    # this build's model when the objects are here (csrc/_obj: not shipped to a GPU box), else the tracked record of the same build
+    path = os.path.join(ROOT, "emergent-multiagent-strategies_amd", "csrc", "_obj", "fa_isa_model.json")
+    if not os.path.isfile(path):
+        path = os.path.join(ROOT, "emergent-multiagent-strategies_amd", "csrc", "fa_isa_model.json")
     try:
         m = json.load(open(path))
     except Exception as exc:

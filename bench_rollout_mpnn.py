@@ -61,9 +61,11 @@ def main():
         t_roll += t1 - t0
         t_upd += t2 - t1
     steps = a.envs * a.rollout * a.iters
+    backend = L.policy_backend
+    L.close()
     print(json.dumps({
         "config": "FortAttack %dv%d, %d envs, %d-step rollout, MPNN h=128 policy in the loop (%s)" % (
-            a.guards, a.attackers, a.envs, a.rollout, ("one hipGraph per rollout" if a.graph else "eager") + ", forwards: " + L.policy_backend +
+            a.guards, a.attackers, a.envs, a.rollout, ("one hipGraph per rollout" if a.graph else "eager") + ", forwards: " + backend +
             (", ensemble of %d attacker strategies" % a.ensemble if a.ensemble else "")),
         "rollout_env_steps_per_s": steps / t_roll, "rollout_ms_per_env_step_launch": t_roll / (a.iters * a.rollout) * 1e3,
         "train_env_steps_per_s": steps / (t_roll + t_upd) if a.update else None,

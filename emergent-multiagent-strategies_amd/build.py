@@ -68,16 +68,30 @@ def build(force=False, verbose=False):
     os.makedirs(OBJ, exist_ok=True)
     with ThreadPoolExecutor(max_workers=4) as pool:
         objs = list(pool.map(lambda f: _compile_one(f, verbose), SOURCES))
+    # The issue model of the pipelined step kernel, read off this build's assembly (bench.py: roofline.secondary), and its
+    # regression gate -- FLAT stores, spill reloads in the critical step loops, instruction count of wave 0's loop -- BEFORE the
+    # link, so that a failed gate leaves no library behind that a second, non-forced build() would accept.  The gate is a
+    # performance heuristic tied to one compiler version (hipcc 7.2): FA_ISA_GATE=0 turns its findings into warnings (the
+    # correctness lint, isa_lint, stays fatal).  The model goes to the git-ignored _obj/; the tracked csrc/fa_isa_model.json is
+    # only rewritten on request (FA_ISA_REFRESH=1 or `python isa_model.py --refresh`; tests/test_isa_lint_cpu.py keeps the two equal).
+    isa_model = _load_mod("isa_model.py")
+    m = isa_model.write(os.path.join(OBJ, "fa_step_pipe.s"), os.path.join(OBJ, "fa_isa_model.json"))
+    if os.environ.get("FA_ISA_REFRESH") == "1":
+        isa_model.write(os.path.join(OBJ, "fa_step_pipe.s"))
+    bad = isa_model.check(m)
+    if bad:
+        msg = "isa_model: the shipped step-kernel instantiations regressed: " + "; ".join(bad)
+        if os.environ.get("FA_ISA_GATE", "1") == "0":
+            import warnings
+            warnings.warn(msg + "  (FA_ISA_GATE=0: building anyway)")
+        else:
+            if os.path.isfile(LIB):
+                os.remove(LIB)
+            raise RuntimeError(msg + "  (FA_ISA_GATE=0 builds anyway)")
     cmd = [hipcc(), "--offload-arch=gfx950", "-fPIC", "-shared"] + objs + ["-o", LIB]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
-    # the issue model of the pipelined step kernel, read off this build's assembly (bench.py: roofline.secondary), and its
-    # regression gate: FLAT stores, spill reloads in the critical step loops, instruction count of wave 0's loop
-    isa_model = _load_mod("isa_model.py")
-    bad = isa_model.check(isa_model.write(os.path.join(OBJ, "fa_step_pipe.s")))
-    if bad:
-        raise RuntimeError("isa_model: the shipped step-kernel instantiations regressed: " + "; ".join(bad))
     return LIB
 
 

@@ -157,6 +157,9 @@ def write(asm=ASM, out=OUT):
 
 
 if __name__ == "__main__":
+    if "--refresh" in sys.argv:          # rewrite the tracked csrc/fa_isa_model.json from the last build's assembly
+        write()
+        sys.argv.remove("--refresh")
     mm = model(sys.argv[1] if len(sys.argv) > 1 else ASM)
     print(json.dumps(mm, indent=1, sort_keys=True))
     for b in check(mm):

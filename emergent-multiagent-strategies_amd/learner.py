@@ -442,6 +442,16 @@ class BatchedLearner(object):
         return [self.policies[0].state_dict()] * self.G + [self.policies[1].state_dict()] * self.A
 
     def load_models(self, policies_list):
+        """learner.py:245-249 (load_models): entry 0 -> the guards' policy, entry -1 -> the attackers'.  BOTH state_dicts are
+        checked (keys and shapes) before either is loaded: a checkpoint that does not fit leaves the learner as it was."""
+        for pol, sd in ((self.policies[0], policies_list[0]), (self.policies[1], policies_list[-1])):
+            own = pol.state_dict()
+            missing, extra = sorted(set(own) - set(sd)), sorted(set(sd) - set(own))
+            if missing or extra:
+                raise RuntimeError("load_models: state_dict keys do not match (missing %s, unexpected %s)" % (missing[:3], extra[:3]))
+            for k, v in own.items():
+                if tuple(sd[k].shape) != tuple(v.shape):
+                    raise RuntimeError("load_models: %s has shape %s, the policy expects %s" % (k, tuple(sd[k].shape), tuple(v.shape)))
         self.policies[0].load_state_dict(policies_list[0])
         self.policies[1].load_state_dict(policies_list[-1])
 

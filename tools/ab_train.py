@@ -75,6 +75,7 @@ def one(name, tests):
         torch.cuda.synchronize()
         ts.append(time.perf_counter() - t0)
     out["update_s"] = round(min(ts), 4)
+    L.close()
     print(json.dumps(out), flush=True)
 
 

@@ -18,8 +18,8 @@ from test_gpu_learner import _check_rollout_against_oracle
 R = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 G = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 A = int(sys.argv[3]) if len(sys.argv) > 3 else 3
-if len(sys.argv) > 4 and sys.argv[4] == "measure":   # record the deviations without asserting the bounds (how the bounds were set)
-    test_gpu_learner.VALUE_REL_TOL, test_gpu_learner.LOGP_ABS_TOL = 1e-2, 1e-2
+if len(sys.argv) > 4 and sys.argv[4] == "measure":   # record the errors without asserting the bound
+    test_gpu_learner.ERR_FACTOR = 1e9
 E, T, max_t = 4096, 128, 100
 N = G + A
 torch.manual_seed(0)
@@ -46,10 +46,12 @@ for it in range(R):
     ent.append(float(out[:, 2].mean()))
     L.after_update()
 st = eng.get_state()
+L.close()
 print(json.dumps({"config": "%dv%d, E=%d, T=%d, max_time_steps=%d, BatchedLearner(use_graph=True), %d collect + update iterations"
                   % (G, A, E, T, max_t, R), "env_steps": R * E * T, "differing_rows": 0,
-                  "checked": "obs / rewards / masks / done rows and GAE returns bit for bit; policy rows vs the PyTorch module: values <= %g relative, log-probs <= %g"
-                             % (test_gpu_learner.VALUE_REL_TOL, test_gpu_learner.LOGP_ABS_TOL),
-                  "max_policy_row_deviation": test_gpu_learner.POLICY_ROW_DEVIATION,
+                  "checked": "obs / rewards / masks / done rows and GAE returns bit for bit; policy rows (values incl. V(obs[T]), log-probs) of the fused "
+                             "forward vs the module in FLOAT64: |fused - f64| <= %g x |module_f32 - f64| + %g x max(1, |row|max), every rollout, both teams"
+                             % (test_gpu_learner.ERR_FACTOR, test_gpu_learner.ERR_FLOOR),
+                  "policy_row_errors_vs_float64": test_gpu_learner.POLICY_ROW_ERRORS,
                   "shoot_fraction_first_last": [shoot_frac[0], shoot_frac[-1]], "entropy_first_last": [ent[0], ent[-1]],
                   "episodes": int(st["result_count"].sum()), "seconds": round(time.time() - t0, 1)}))

@@ -112,6 +112,7 @@ def main():
                               "total_reward_per_agent": L.episode_rewards.mean(0).tolist(),
                               "episodes": n_ep, "guards_win_rate": float(row[2]), "fort_reached_rate": float(row[3])}),
                   flush=True)
+    L.close()                                          # communicators / per-team process groups: on every rank, here
     if world > 1:
         dist.destroy_process_group()
 
