@@ -30,8 +30,9 @@ POLICY_ROW_ERRORS = {"value_fused": 0.0, "value_module_f32": 0.0, "logp_fused": 
 
 def _policy_rows_vs_float64(pol, st, own, opp, T, E):
     """max |fused - f64| and max |module_f32 - f64| for the value rows (incl. V(obs[T])) and the log-prob rows of one team."""
-    import copy
-    p64 = copy.deepcopy(pol).double()
+    p64 = type(pol)(num_agents=pol.num_agents, num_opp_agents=pol.num_opp_agents, hidden_dim=pol.h_dim, num_actions=8)
+    p64.load_state_dict(pol.state_dict())
+    p64 = p64.to(st.obs.device).double()
     p64.refresh_fused_weights()
     obs = st.obs[:-1].flatten(0, 1)
     act = st.actions.flatten(0, 1)[:, own]
