@@ -60,7 +60,25 @@ __device__ __forceinline__ void pack_one(const float *__restrict__ plain, float 
     const int k = (lane >> 5) * (K / 2) + 4 * t4 + q, c = 32 * cb + (lane & 31);
     out[s.dst + idx] = transpose ? plain[s.src + c * s.C + k] : plain[s.src + k * s.C + c];
 }
+// element (k, c) of the (K x C) matrix -> its three bf16 terms in the bf16x3 pack at float offset dst3 (fa_policy.h FA_POFF3_*)
+__device__ __forceinline__ unsigned pk_rne_hi(float x) {
+    const unsigned u = __float_as_uint(x);
+    return (u + 0x7fffu + ((u >> 16) & 1u)) & 0xffff0000u;
+}
+__device__ __forceinline__ void pack_x3(float x, float *__restrict__ w, int dst3, int K, int k, int c) {
+    const unsigned h = pk_rne_hi(x);
+    const float r1 = x - __uint_as_float(h);
+    const unsigned m = pk_rne_hi(r1);
+    const unsigned l = __float_as_uint(r1 - __uint_as_float(m));
+    const int hh = k / (K / 2), kk = k - hh * (K / 2), s = kk >> 3, j = kk & 7, cb = c >> 5, li = c & 31;
+    uint16_t *w16 = reinterpret_cast<uint16_t *>(w + dst3);
+    const size_t base = ((size_t)(cb * (K / 16) + s) * 3 * 64 + hh * 32 + li) * 8 + j;
+    w16[base] = (uint16_t)(h >> 16);
+    w16[base + 64 * 8] = (uint16_t)(m >> 16);
+    w16[base + 2 * 64 * 8] = (uint16_t)(l >> 16);
+}
 __global__ __launch_bounds__(256) void fa_pack_kernel(const float *__restrict__ plain, float *__restrict__ w, float *__restrict__ wt) {
+    const int dst3[6] = {FA_POFF3_AO, FA_POFF3_BO, FA_POFF3_AM, FA_POFF3_W7, FA_POFF3_W8, FA_POFF3_W9};
     const PackSpec fwd[6] = {{FA_POFF_AO, 64, 64, FA_POFF_AO}, {FA_POFF_BO, 64, 64, FA_POFF_BO}, {FA_POFF_AM, 128, 128, FA_POFF_AM},
                              {FA_POFF_W7, 256, 128, FA_POFF_W7}, {FA_POFF_W8, 128, 256, FA_POFF_W8}, {FA_POFF_W9, 256, 32, FA_POFF_W9}};
     const int tdst[6] = {FA_TOFF_AOT, FA_TOFF_BOT, FA_TOFF_AMT, FA_TOFF_W7T, FA_TOFF_W8T, FA_TOFF_W9T};
@@ -75,6 +93,10 @@ __global__ __launch_bounds__(256) void fa_pack_kernel(const float *__restrict__ 
         const int n = fwd[m].K * fwd[m].C;
         if (g >= fwd[m].src && g < fwd[m].src + n) {
             pack_one(plain, w, fwd[m], false, g - fwd[m].src);
+            {   // plain element g - src = k * C + c
+                const int e = g - fwd[m].src, k = e / fwd[m].C, c = e - k * fwd[m].C;
+                pack_x3(plain[g], w, dst3[m], fwd[m].K, k, c);
+            }
             PackSpec ts = fwd[m];
             ts.dst = tdst[m];
             pack_one(plain, wt, ts, true, g - fwd[m].src);
@@ -88,6 +110,6 @@ hipError_t fa_launch_tasks(const fa_task *tasks, int n, hipStream_t st) {
     return hipGetLastError();
 }
 hipError_t fa_launch_pack(const float *plain, float *w, float *wt, hipStream_t st) {
-    hipLaunchKernelGGL(fa_pack_kernel, dim3((FA_POLICY_WEIGHT_FLOATS + 255) / 256), dim3(256), 0, st, plain, w, wt);
+    hipLaunchKernelGGL(fa_pack_kernel, dim3((FA_POLICY_PLAIN_FLOATS + 255) / 256), dim3(256), 0, st, plain, w, wt);
     return hipGetLastError();
 }

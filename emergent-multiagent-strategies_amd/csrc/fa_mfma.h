@@ -67,6 +67,98 @@ __device__ __forceinline__ void gemm_cb(const float *arow, const float4 *__restr
     }
 }
 
+// ---- the same GEMM on the bf16 matrix cores, fp32-class accuracy (three-way operand split) ---------------------------------
+// v_mfma_f32_32x32x16_bf16 retires 16 x the MACs per cycle of v_mfma_f32_32x32x2_f32.  A float is the exact sum of three bf16
+// numbers (hi + mid + lo: 8 significant bits each), so a product is the sum of nine bf16 x bf16 products, each exact in the
+// MFMA's fp32 accumulator; the six largest are issued (hi hi, hi mid, mid hi, hi lo, lo hi, mid mid): 6 MFMAs of 32 cycles
+// cover K = 16 where the fp32 form needs 8 of 64 -- 2.67 x less matrix-core time.  The WEIGHTS arrive pre-split (fa_policy.h
+// FA_POFF3_*: split once per optimizer step by fa_pack_weights, round-to-nearest terms, so the three dropped cross products
+// -- <= 2^-24 |a w| together -- carry either sign); the ACTIVATIONS are split here, on the way from LDS into the MFMA, by
+// truncation (4 VALU operations per element, exact: a == hi + mid + lo).  Same K permutation as gemm_cb: lane half hh walks
+// k in [hh K/2, (hh + 1) K/2), eight consecutive k per 16-byte step.
+#ifndef FA_GEMM3_CH
+#define FA_GEMM3_CH 2 // K = 16 steps of weights (3 x 16 bytes per lane each) requested ahead
+#endif
+typedef __bf16 fa_bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned fa_u32x4 __attribute__((ext_vector_type(4)));
+template <int K>
+struct BHead3 {
+    static constexpr int NS = K / 16;
+    static constexpr int CH = NS < FA_GEMM3_CH ? NS : FA_GEMM3_CH;
+    fa_u32x4 v[CH * 3];
+};
+template <int K>
+__device__ __forceinline__ void prefetch_b3(const fa_u32x4 *__restrict__ wp, int lane, BHead3<K> &h) {
+#pragma unroll
+    for (int c = 0; c < BHead3<K>::CH * 3; ++c) h.v[c] = wp[c * 64 + lane];
+}
+// eight floats -> three packed bf16x8 (hi, mid, lo), truncating split
+__device__ __forceinline__ void fa_split8(const float4 &a0, const float4 &a1, fa_u32x4 &H, fa_u32x4 &M, fa_u32x4 &L) {
+    const float x[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+    unsigned h[8], m[8], l[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        h[j] = __float_as_uint(x[j]) & 0xffff0000u;
+        const float r1 = x[j] - __uint_as_float(h[j]);
+        m[j] = __float_as_uint(r1) & 0xffff0000u;
+        l[j] = __float_as_uint(r1 - __uint_as_float(m[j]));
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        H[j] = __builtin_amdgcn_perm(h[2 * j + 1], h[2 * j], 0x07060302u);
+        M[j] = __builtin_amdgcn_perm(m[2 * j + 1], m[2 * j], 0x07060302u);
+        L[j] = __builtin_amdgcn_perm(l[2 * j + 1], l[2 * j], 0x07060302u);
+    }
+}
+// acc[r] += Act[rows of block r][K] * W[K][32 columns of one block]; arow as gemm_cb; wp3: the column block's bf16x3 pack,
+// [K/16][3][64] 16-byte words; head: its first chunk, already requested
+template <int K, int NRB>
+__device__ __forceinline__ void gemm_cb3(const float *arow, const fa_u32x4 *__restrict__ wp3, f32x16 (&acc)[NRB], int lane,
+                                         const BHead3<K> &head) {
+    constexpr int NS = BHead3<K>::NS, CH = BHead3<K>::CH;
+    fa_u32x4 bq[CH * 3], bn[CH * 3];
+#pragma unroll
+    for (int c = 0; c < CH * 3; ++c) bq[c] = head.v[c];
+#pragma unroll
+    for (int s0 = 0; s0 < NS; s0 += CH) {
+        if (s0 + CH < NS) {
+#pragma unroll
+            for (int c = 0; c < CH * 3; ++c) bn[c] = wp3[((s0 + CH) * 3 + c) * 64 + lane];
+#ifndef FA_NO_SCHED_BARRIER
+            __builtin_amdgcn_sched_barrier(0); // (as gemm_cb: keep the requests here)
+#endif
+        }
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const fa_bf16x8 bh = __builtin_bit_cast(fa_bf16x8, bq[c * 3]), bm = __builtin_bit_cast(fa_bf16x8, bq[c * 3 + 1]),
+                            bl = __builtin_bit_cast(fa_bf16x8, bq[c * 3 + 2]);
+#pragma unroll
+            for (int r = 0; r < NRB; ++r) {
+                const float *ap = arow + r * 32 * LDA + (s0 + c) * 8;
+                fa_u32x4 H, M, L;
+                fa_split8(*reinterpret_cast<const float4 *>(ap), *reinterpret_cast<const float4 *>(ap + 4), H, M, L);
+                const fa_bf16x8 ah = __builtin_bit_cast(fa_bf16x8, H), am = __builtin_bit_cast(fa_bf16x8, M),
+                                al = __builtin_bit_cast(fa_bf16x8, L);
+                acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[r], 0, 0, 0);
+                acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[r], 0, 0, 0);
+                acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc[r], 0, 0, 0);
+                acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[r], 0, 0, 0);
+                acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc[r], 0, 0, 0);
+                acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[r], 0, 0, 0);
+            }
+#ifndef FA_NO_SCHED_BARRIER
+            // one K = 16 step at a time: left alone the scheduler hoists the LDS reads and the splits of many steps to the top
+            // (the split's temporaries are 40 registers per row block) and spills
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+        }
+        if (s0 + CH < NS) {
+#pragma unroll
+            for (int c = 0; c < CH * 3; ++c) bq[c] = bn[c];
+        }
+    }
+}
+
 // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
 template <bool RELU>
 __device__ __forceinline__ void store_acc(float *dst, int rb, const f32x16 &acc, float bias, int lane) {

@@ -26,7 +26,19 @@
 #define FA_POFF_B8 91136    // [policy_head.0.bias | value_head.0.bias] [256]
 #define FA_POFF_W9 91392    // packed (256 x 32): rows 0..127 x cols 0..7 = dist.linear.weight^T, rows 128..255 x col 8 = value_head.2.weight^T
 #define FA_POFF_B9 99584    // [dist.linear.bias (8) | value_head.2.bias (1) | 0 ...] [32]
-#define FA_POLICY_WEIGHT_FLOATS 99616
+#define FA_POLICY_PLAIN_FLOATS 99616  // end of the float32 sections above (= the layout of the plain / gradient buffers)
+// The same six dense matrices once more, for the bf16 matrix cores: every float32 weight split EXACTLY into three bf16 terms
+// (hi = round-to-nearest at 8 significant bits, mid = the remainder rounded likewise, lo = the rest; fa_mfma.h gemm_cb3),
+// in the B-operand order of v_mfma_f32_32x32x16_bf16: 16-byte index ((cb * K/16 + s) * 3 + term) * 64 + lane holds the eight
+// bf16 W[k = (lane >> 5) * K/2 + 8 s + j][col = 32 cb + (lane & 31)], j = 0..7, of term 0 / 1 / 2 = hi / mid / lo.
+// 1.5 floats of buffer per weight.  Written by fa_pack_weights (device) / mpnn_pack.pack_policy (host) next to the float32 form.
+#define FA_POFF3_AO 99616   // (64 x 64)
+#define FA_POFF3_BO 105760  // (64 x 64)
+#define FA_POFF3_AM 111904  // (128 x 128)
+#define FA_POFF3_W7 136480  // (256 x 128)
+#define FA_POFF3_W8 185632  // (128 x 256)
+#define FA_POFF3_W9 234784  // (256 x 32)
+#define FA_POLICY_WEIGHT_FLOATS 247072
 
 struct FaPolicyArgs {
     const float *obs;      // (E, N, 6) observation row

@@ -47,7 +47,33 @@
 #ifndef FA_POLICY_WAVES
 #define FA_POLICY_WAVES 8 // waves of the 96-row tile's workgroup (4: one per SIMD, the round-2 shape)
 #endif
+// The dense layers' GEMM: 1 = the bf16 matrix cores with the three-way operand split (fa_mfma.h gemm_cb3: fp32-class accuracy at
+// 6/16 of the fp32 MFMA time; weights pre-split in the pack, FA_POFF3_*), 0 = v_mfma_f32_32x32x2_f32 (the exact fp32 fmaf chain:
+// rounds 2-5, kept as the definition the split form is tested against -- tools/build_variant.py ... -DFA_POLICY_X3=0)
+#ifndef FA_POLICY_X3
+#define FA_POLICY_X3 1
+#endif
 namespace {
+#if FA_POLICY_X3
+typedef fa_u32x4 pw_t;                          // one 16-byte step of packed weights
+template <int K> using PBHead = BHead3<K>;
+template <int K> __device__ __forceinline__ void p_prefetch(const pw_t *__restrict__ wp, int lane, PBHead<K> &h) { prefetch_b3<K>(wp, lane, h); }
+template <int K, int NRB>
+__device__ __forceinline__ void p_gemm(const float *arow, const pw_t *__restrict__ wp, f32x16 (&acc)[NRB], int lane, const PBHead<K> &h) {
+    gemm_cb3<K, NRB>(arow, wp, acc, lane, h);
+}
+// the column block cb of the packed (K x C) matrix at float offset OFF3
+#define FA_PW(OFF, OFF3, K, cb) (reinterpret_cast<const pw_t *>(W + (OFF3)) + (size_t)(cb) * ((K) / 16) * 3 * 64)
+#else
+typedef float4 pw_t;
+template <int K> using PBHead = BHead<K>;
+template <int K> __device__ __forceinline__ void p_prefetch(const pw_t *__restrict__ wp, int lane, PBHead<K> &h) { prefetch_b<K>(wp, lane, h); }
+template <int K, int NRB>
+__device__ __forceinline__ void p_gemm(const float *arow, const pw_t *__restrict__ wp, f32x16 (&acc)[NRB], int lane, const PBHead<K> &h) {
+    gemm_cb<K, NRB>(arow, wp, acc, lane, h);
+}
+#define FA_PW(OFF, OFF3, K, cb) (reinterpret_cast<const pw_t *>(W + (OFF)) + (size_t)(cb) * ((K) / 8) * 64)
+#endif
 __device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
@@ -138,15 +164,15 @@ __global__ __launch_bounds__(NW * 64, NRB == 2 ? 2 : 1) void fa_policy_kernel(Fa
     const bool opp_two = NW == 4 && NRB == 3 && wave < 2;                 // four waves: waves 0, 1 take two row blocks
     const bool opp_on = NW == 4 || wave < 2 * NRB;
     const int ocb = wave & 1, orb = NW >= 8 ? (wave >> 1) : (NRB == 3 ? 2 : (wave >> 1));
-    const float4 *Wq = reinterpret_cast<const float4 *>(W);
-    const float4 *wp_ao = Wq + FA_POFF_AO / 4 + ocb * (64 / 8) * 64;
-    const float4 *wp_bo = Wq + FA_POFF_BO / 4 + ocb * (64 / 8) * 64;
-    const float4 *wp_am = Wq + FA_POFF_AM / 4 + cbw * (128 / 8) * 64;
-    const float4 *wp_w7 = Wq + FA_POFF_W7 / 4 + cbw * (256 / 8) * 64;
-    const float4 *wp_w8p = Wq + FA_POFF_W8 / 4 + cbw * (128 / 8) * 64;
-    const float4 *wp_w8v = Wq + FA_POFF_W8 / 4 + (4 + cbw) * (128 / 8) * 64;
-    BHead<64> hd_o;
-    if (opp_on) prefetch_b<64>(wp_ao, lane, hd_o);
+    const pw_t *wp_ao = FA_PW(FA_POFF_AO, FA_POFF3_AO, 64, ocb);
+    const pw_t *wp_bo = FA_PW(FA_POFF_BO, FA_POFF3_BO, 64, ocb);
+    const pw_t *wp_am = FA_PW(FA_POFF_AM, FA_POFF3_AM, 128, cbw);
+    const pw_t *wp_w7 = FA_PW(FA_POFF_W7, FA_POFF3_W7, 256, cbw);
+    const pw_t *wp_w8p = FA_PW(FA_POFF_W8, FA_POFF3_W8, 128, cbw);
+    const pw_t *wp_w8v = FA_PW(FA_POFF_W8, FA_POFF3_W8, 128, 4 + cbw);
+    const pw_t *wp_w9 = FA_PW(FA_POFF_W9, FA_POFF3_W9, 256, 0);
+    PBHead<64> hd_o;
+    if (opp_on) p_prefetch<64>(wp_ao, lane, hd_o);
     // ---- encoders (mpnn.py:37-38): h1 = relu(x We + be) -> sH[:, 0:64] (own rows), ho -> sG[:, 0:64] (opp rows)
     {
         const int col = tid & 63, grp = tid >> 6;
@@ -178,14 +204,14 @@ __global__ __launch_bounds__(NW * 64, NRB == 2 ? 2 : 1) void fa_policy_kernel(Fa
     // ---- opponent attention (mpnn.py:372-443): g_o = h1 A_o -> sG[:, 64:128] --------------------------------
     if (opp_two) {
         f32x16 acc[2] = {};
-        gemm_cb<64, 2>(sH + li * LDA + hh * 32, wp_ao, acc, lane, hd_o);
-        prefetch_b<64>(wp_bo, lane, hd_o);
+        p_gemm<64, 2>(sH + li * LDA + hh * 32, wp_ao, acc, lane, hd_o);
+        p_prefetch<64>(wp_bo, lane, hd_o);
         store_acc<false>(sG + 64 + ocb * 32, 0, acc[0], 0.0f, lane);
         store_acc<false>(sG + 64 + ocb * 32, 1, acc[1], 0.0f, lane);
     } else if (opp_on) {
         f32x16 acc[1] = {};
-        gemm_cb<64, 1>(sH + (orb * 32 + li) * LDA + hh * 32, wp_ao, acc, lane, hd_o);
-        prefetch_b<64>(wp_bo, lane, hd_o);
+        p_gemm<64, 1>(sH + (orb * 32 + li) * LDA + hh * 32, wp_ao, acc, lane, hd_o);
+        p_prefetch<64>(wp_bo, lane, hd_o);
         store_acc<false>(sG + 64 + ocb * 32, orb, acc[0], 0.0f, lane);
     }
     __syncthreads();
@@ -215,20 +241,20 @@ __global__ __launch_bounds__(NW * 64, NRB == 2 ? 2 : 1) void fa_policy_kernel(Fa
     __syncthreads();
     FA_PL_TICK(3)
     // e_opp = hmix_o B_o -> sH[:, 64:128]   (h = [h1 | e_opp], mpnn.py:143)
-    BHead<128> hd_m;
+    PBHead<128> hd_m;
     if (opp_two) {
         f32x16 acc[2] = {};
-        gemm_cb<64, 2>(sG + li * LDA + 64 + hh * 32, wp_bo, acc, lane, hd_o);
-        prefetch_b<128>(wp_am, lane, hd_m);
+        p_gemm<64, 2>(sG + li * LDA + 64 + hh * 32, wp_bo, acc, lane, hd_o);
+        p_prefetch<128>(wp_am, lane, hd_m);
         store_acc<false>(sH + 64 + ocb * 32, 0, acc[0], 0.0f, lane);
         store_acc<false>(sH + 64 + ocb * 32, 1, acc[1], 0.0f, lane);
     } else if (opp_on) {
         f32x16 acc[1] = {};
-        gemm_cb<64, 1>(sG + (orb * 32 + li) * LDA + 64 + hh * 32, wp_bo, acc, lane, hd_o);
-        prefetch_b<128>(wp_am, lane, hd_m);
+        p_gemm<64, 1>(sG + (orb * 32 + li) * LDA + 64 + hh * 32, wp_bo, acc, lane, hd_o);
+        p_prefetch<128>(wp_am, lane, hd_m);
         store_acc<false>(sH + 64 + ocb * 32, orb, acc[0], 0.0f, lane);
     } else {
-        prefetch_b<128>(wp_am, lane, hd_m);
+        p_prefetch<128>(wp_am, lane, hd_m);
     }
     __syncthreads();
 
@@ -247,13 +273,13 @@ __global__ __launch_bounds__(NW * 64, NRB == 2 ? 2 : 1) void fa_policy_kernel(Fa
             if (r < RU) store_row_regs<128>(sG + r * LDA, q16, ov[k]);
         }
     };
-    BHead<256> hd_u;
+    PBHead<256> hd_u;
     for (int round = 0; round < 3; ++round) {
         FA_PL_TICK(4 + round * 8)
         FA_POLICY_SPLIT({   // g = h A -> sG
             f32x16 acc[NR] = {};
-            gemm_cb<128, NR>(sH + (R0 * 32 + li) * LDA + hh * 64, wp_am, acc, lane, hd_m);
-            prefetch_b<256>(wp_w7, lane, hd_u);
+            p_gemm<128, NR>(sH + (R0 * 32 + li) * LDA + hh * 64, wp_am, acc, lane, hd_m);
+            p_prefetch<256>(wp_w7, lane, hd_u);
 FA_PL_TICK(5 + round * 8)
 _Pragma("unroll")
             for (int rb = 0; rb < NR; ++rb) store_acc<false>(sG + cbw * 32, R0 + rb, acc[rb], 0.0f, lane);
@@ -270,8 +296,8 @@ _Pragma("unroll")
         FA_PL_TICK(9 + round * 8)
         FA_POLICY_SPLIT({   // h' = relu([h | hmix] W7 + bu): lane half 0 walks h, half 1 walks hmix
             f32x16 acc[NR] = {};
-            gemm_cb<256, NR>((hh ? sG : sH) + (R0 * 32 + li) * LDA, wp_w7, acc, lane, hd_u);
-            prefetch_b<128>(round < 2 ? wp_am : wp_w8p, lane, hd_m); // next: the following round's g, or the policy head
+            p_gemm<256, NR>((hh ? sG : sH) + (R0 * 32 + li) * LDA, wp_w7, acc, lane, hd_u);
+            p_prefetch<128>(round < 2 ? wp_am : wp_w8p, lane, hd_m); // next: the following round's g, or the policy head
             const float bias = W[FA_POFF_BU + cbw * 32 + li];
             FA_PL_TICK(10 + round * 8)
             FA_WAVES_BARRIER(); // every wave has read the old h
@@ -287,18 +313,18 @@ _Pragma("unroll")
     // (p goes to sG straight after its GEMM: hmix is dead since the barrier behind the last W7 layer; only v -> sH
     // has to wait until every wave has read h.  One accumulator set live at a time.)
     FA_POLICY_SPLIT({
-        BHead<128> hd_v;
-        prefetch_b<128>(wp_w8v, lane, hd_v);
+        PBHead<128> hd_v;
+        p_prefetch<128>(wp_w8v, lane, hd_v);
         {
             f32x16 accp[NR] = {};
-            gemm_cb<128, NR>(sH + (R0 * 32 + li) * LDA + hh * 64, wp_w8p, accp, lane, hd_m);
+            p_gemm<128, NR>(sH + (R0 * 32 + li) * LDA + hh * 64, wp_w8p, accp, lane, hd_m);
             const float bp = W[FA_POFF_B8 + cbw * 32 + li];
 _Pragma("unroll")
             for (int rb = 0; rb < NR; ++rb) store_acc<true>(sG + cbw * 32, R0 + rb, accp[rb], bp, lane);
         }
         f32x16 accv[NR] = {};
-        gemm_cb<128, NR>(sH + (R0 * 32 + li) * LDA + hh * 64, wp_w8v, accv, lane, hd_v);
-        if (wave < NRB) prefetch_b<256>(Wq + FA_POFF_W9 / 4, lane, hd_u);
+        p_gemm<128, NR>(sH + (R0 * 32 + li) * LDA + hh * 64, wp_w8v, accv, lane, hd_v);
+        if (wave < NRB) p_prefetch<256>(wp_w9, lane, hd_u);
         const float bv = W[FA_POFF_B8 + 128 + cbw * 32 + li];
         FA_WAVES_BARRIER(); // every wave has read h
 _Pragma("unroll")
@@ -336,7 +362,7 @@ _Pragma("unroll")
     }
     if (wave < NRB) {
         f32x16 acc[1] = {};
-        gemm_cb<256, 1>((hh ? sH : sG) + (wave * 32 + li) * LDA, Wq + FA_POFF_W9 / 4, acc, lane, hd_u);
+        p_gemm<256, 1>((hh ? sH : sG) + (wave * 32 + li) * LDA, wp_w9, acc, lane, hd_u);
         if (li < 16) {
             const float bias = W[FA_POFF_B9 + li];
 #pragma unroll

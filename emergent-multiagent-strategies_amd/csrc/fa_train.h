@@ -27,8 +27,8 @@
 // The result of fa_ppo_grad (`out`): the gradient of every kernel-facing matrix in PLAIN row-major layout at the offsets
 // of the forward pack (FA_POFF_*: We (6x64) | be | Woe | boe | A_o (64x64) | B_o | A_m (128x128) | W7 (256x128)
 // | bu | W8 (128x256) | b8 | W9 (256x32) | b9), then the minibatch's loss sums.
-#define FA_SLAB_LOSS FA_POLICY_WEIGHT_FLOATS // [value_loss sum, action_loss sum, entropy*mask sum, mask sum]
-#define FA_SLAB_FLOATS (FA_POLICY_WEIGHT_FLOATS + 16)
+#define FA_SLAB_LOSS FA_POLICY_PLAIN_FLOATS // [value_loss sum, action_loss sum, entropy*mask sum, mask sum]
+#define FA_SLAB_FLOATS (FA_POLICY_PLAIN_FLOATS + 16)
 #define FA_MASK_PARTS 64
 #define FA_NORM_PARTS 64
 #define FA_ADAM_SCRATCH (4 + 2 * FA_NORM_PARTS)

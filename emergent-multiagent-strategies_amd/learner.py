@@ -117,7 +117,7 @@ class GraphedPPOStep(object):
             self._out = torch.zeros(mpnn_pack.SLAB_FLOATS, device=dev)
             self._scratch = None
             inv_count = 1.0 / (mb * n_own)
-            PF, LOSS = mpnn_pack.PF_FLOATS, mpnn_pack.WEIGHT_FLOATS
+            PF, LOSS = mpnn_pack.PF_FLOATS, mpnn_pack.PLAIN_FLOATS
             self._unmask = torch.tensor([0.0, 1.0, 1.0], device=dev)
 
         def fused_fwd_bwd():

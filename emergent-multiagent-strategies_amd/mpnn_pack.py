@@ -22,8 +22,33 @@ HIDDEN = 128
 # csrc/fa_policy.h
 POFF = dict(WE=0, BE=384, WOE=448, BOE=832, AO=896, BO=4992, AM=9088, W7=25472, BU=58240, W8=58368, B8=91136,
             W9=91392, B9=99584)
-WEIGHT_FLOATS = 99616
+PLAIN_FLOATS = 99616          # end of the float32 sections: the layout of the plain / gradient buffers (FA_POLICY_PLAIN_FLOATS)
+# ... followed by the six dense matrices split into three bf16 terms for the bf16 matrix cores (csrc/fa_policy.h FA_POFF3_*)
+POFF3 = dict(AO=99616, BO=105760, AM=111904, W7=136480, W8=185632, W9=234784)
+WEIGHT_FLOATS = 247072        # the packed buffer (FA_POLICY_WEIGHT_FLOATS, fa_policy_weight_floats())
 MAX_TEAM = 8
+
+
+def _rne_hi(x):
+    """float32 tensor -> float32 tensor rounded to nearest-even at 8 significant bits (a bf16 in a float's clothes)."""
+    u = x.contiguous().view(torch.int32)
+    return ((u + 0x7FFF + ((u >> 16) & 1)) & -65536).view(torch.float32)
+
+
+def pack_gemm3(w):
+    """(K, C) matrix -> the bf16x3 B-operand pack as a flat float32 tensor of 1.5 K C floats: every weight (rounded to float32
+    first) is EXACTLY hi + mid + lo, three bf16 numbers; 16-byte index ((cb * K/16 + s) * 3 + term) * 64 + lane holds the eight
+    bf16 W[k = (lane >> 5) * K/2 + 8 s + j][col = 32 cb + (lane & 31)], j = 0..7 (csrc/fa_policy.h; fa_pack_weights writes the same)."""
+    K, C = w.shape
+    assert K % 16 == 0 and C % 32 == 0
+    x = w.float().contiguous()
+    hi = _rne_hi(x)
+    r1 = x - hi
+    mid = _rne_hi(r1)
+    lo = r1 - mid
+    terms = torch.stack([(t.contiguous().view(torch.int32) >> 16).to(torch.int16) for t in (hi, mid, lo)])   # (3, K, C) bf16 bits
+    t = terms.reshape(3, 2, K // 16, 8, C // 32, 32).permute(4, 2, 0, 1, 5, 3).contiguous()                  # cb, s, term, hh, li, j
+    return t.reshape(-1).view(torch.float32)
 
 
 def pack_gemm(w):
@@ -37,6 +62,13 @@ def pack_gemm(w):
 def unpack_gemm(flat, K, C):
     """Inverse of pack_gemm."""
     return flat.reshape(C // 32, K // 8, 2, 32, 4).permute(2, 1, 4, 0, 3).contiguous().reshape(K, C)
+
+
+def unpack_gemm3(flat3, K, C):
+    """Inverse of pack_gemm3: the (K, C) float32 matrix hi + mid + lo (exact: the split loses nothing)."""
+    bits = flat3.contiguous().view(torch.int16).reshape(C // 32, K // 16, 3, 2, 32, 8).permute(2, 3, 1, 5, 0, 4).reshape(3, K, C)
+    t = (bits.to(torch.int32) << 16).view(torch.float32)
+    return (t[0] + t[1]) + t[2]
 
 
 def supported(pol):
@@ -76,6 +108,9 @@ def pack_policy(pol, out=None):
     assert out.numel() == WEIGHT_FLOATS and out.dtype == torch.float32 and out.is_contiguous()
     for k, v in sec.items():
         out[POFF[k]:POFF[k] + v.numel()].copy_(v.reshape(-1).float())
+    for k, (K, C) in (("AO", (64, 64)), ("BO", (64, 64)), ("AM", (128, 128)), ("W7", (256, 128)), ("W8", (128, 256)), ("W9", (256, 32))):
+        x3 = pack_gemm3(unpack_gemm(out[POFF[k]:POFF[k] + K * C], K, C))
+        out[POFF3[k]:POFF3[k] + x3.numel()].copy_(x3)
     return out
 
 
@@ -105,7 +140,7 @@ def folded_forward(flat, own, opp):
 # ---- the PPO update's fused kernel (csrc/fa_train.hip) ---------------------------------------------------------
 TOFF = dict(AOT=0, BOT=4096, AMT=8192, W7T=24576, W8T=57344, W9T=90112)     # csrc/fa_train.h
 TRANS_FLOATS = 98304
-SLAB_FLOATS = WEIGHT_FLOATS + 16
+SLAB_FLOATS = PLAIN_FLOATS + 16
 PLAIN_SHAPES = dict(WE=(6, 64), BE=(64,), WOE=(6, 64), BOE=(64,), AO=(64, 64), BO=(64, 64), AM=(128, 128), W7=(256, 128),
                     BU=(128,), W8=(128, 256), B8=(256,), W9=(256, 32), B9=(32,))
 
@@ -138,6 +173,9 @@ def pack_from_params(P, out_fwd, out_t):
     for k, v in P.items():
         flat = pack_gemm(v.detach()) if k in _GEMMS else v.detach().reshape(-1)
         out_fwd[POFF[k]:POFF[k] + flat.numel()].copy_(flat)
+        if k in _GEMMS and out_fwd.numel() >= WEIGHT_FLOATS:
+            x3 = pack_gemm3(v.detach())
+            out_fwd[POFF3[k]:POFF3[k] + x3.numel()].copy_(x3)
     for k in _GEMMS:
         flat = pack_gemm(P[k].detach().t())
         out_t[TOFF[k + "T"]:TOFF[k + "T"] + flat.numel()].copy_(flat)
@@ -240,7 +278,7 @@ class FlatPolicy(object):
                 self.pflat[off:off + n].copy_(p.data.reshape(-1))
                 p.data = self.pflat[off:off + n].view(p.shape)
                 self.off[name] = off
-        self.plain, self.mscr, self.dmscr = z(WEIGHT_FLOATS), z(128 * 128), z(128 * 128)
+        self.plain, self.mscr, self.dmscr = z(PLAIN_FLOATS), z(128 * 128), z(128 * 128)
         self.w, self.wt = z(WEIGHT_FLOATS), z(TRANS_FLOATS)
         self._fold = [self._tasks(self._fold_stage1()), self._tasks(self._fold_stage2())]
         self._unfold = {}       # gradient buffer address -> its two task lists (captured graphs keep the pointers)

@@ -260,7 +260,7 @@ def test_fused_ppo_grad_matches_torch_autograd(fa, G, A, team, B, clipped):
     scale = torch.tensor([1.0 / (B * n), 1.0], device="cuda")
     out, _ = ppo_grad(obs, action, value_pred, ret, old_logp, adv, w, wt, scale, team, G, A, clip, c_v, c_e, clipped)
     torch.cuda.synchronize()
-    sums = out[mp_.WEIGHT_FLOATS:mp_.WEIGHT_FLOATS + 4] / (B * n)
+    sums = out[mp_.PLAIN_FLOATS:mp_.PLAIN_FLOATS + 4] / (B * n)
     for got, want in zip(sums, (vl, al, en, mm)):
         assert abs(float(got) - float(want)) <= 1e-5 * max(1.0, abs(float(want)))
     grads = mp_.split_plain(out)
@@ -319,7 +319,7 @@ def test_dw_gemm_split_bf16_is_fp32_class_against_an_fp64_gemm(fa, monkeypatch, 
         outs[mode] = {k: v.clone() for k, v in mp_.split_plain(o).items()}
         o2, _ = ppo_grad(obs, action, value_pred, ret, old_logp, adv, w, wt, scale, 0, G, A, 0.2, 0.5, 0.01, True, scratch=sc)
         torch.cuda.synchronize()
-        L = mp_.WEIGHT_FLOATS + 4
+        L = mp_.PLAIN_FLOATS + 4
         assert torch.equal(o[:L], o2[:L]), mode                         # bitwise reproducible, either form
     # the products in float64 from the records (csrc/fa_train.h: FA_RECA_* / FA_RECB_*)
     tiles = -(-B // (32 // max(G, A)))
@@ -371,7 +371,7 @@ def test_fused_ppo_grad_normalises_the_advantages_itself(fa):
     a, _ = ppo_grad(obs, action, value_pred, ret, old_logp, adv.contiguous(), w, wt, None, 1, G, A, 0.2, 0.5, 0.01, True)
     b, _ = ppo_grad(obs, action, value_pred, ret, old_logp, None, w, wt, None, 1, G, A, 0.2, 0.5, 0.01, True, adv_stats=(mean, std))
     torch.cuda.synchronize()
-    used = mp_.WEIGHT_FLOATS + 4                       # gradients + the four loss sums (the buffer's tail is scratch)
+    used = mp_.PLAIN_FLOATS + 4                        # gradients + the four loss sums (the buffer's tail is scratch)
     assert torch.equal(a[:used], b[:used]) and float(a[:used].abs().sum()) > 0
 
 
@@ -394,7 +394,14 @@ def test_flat_policy_fold_and_unfold_match_torch(fa, G, A):
         after = pol.logits_value(obs[:, :G], obs[:, G:])
     assert torch.equal(before[0], after[0]) and torch.equal(before[1], after[1])
     w, wt = fp.fold_pack()
-    assert (w - w_ref).abs().max() <= 2e-6 * max(1.0, float(w_ref.abs().max()))
+    PF = mp_.PLAIN_FLOATS
+    assert (w[:PF] - w_ref[:PF]).abs().max() <= 2e-6 * max(1.0, float(w_ref[:PF].abs().max()))
+    # the bf16x3 half of the pack (what fa_policy_kernel's GEMMs read) is the SAME matrices, exactly: hi + mid + lo == float32
+    for k, (K, C) in (("AO", (64, 64)), ("BO", (64, 64)), ("AM", (128, 128)), ("W7", (256, 128)), ("W8", (128, 256)), ("W9", (256, 32))):
+        a = mp_.unpack_gemm(w[mp_.POFF[k]:mp_.POFF[k] + K * C], K, C)
+        b = mp_.unpack_gemm3(w[mp_.POFF3[k]:mp_.POFF3[k] + K * C * 3 // 2], K, C)
+        assert torch.equal(a, b), k
+        assert torch.equal(mp_.pack_gemm3(a), w[mp_.POFF3[k]:mp_.POFF3[k] + K * C * 3 // 2]), k    # device pack == host pack, bit for bit
     assert (wt - wt_ref).abs().max() <= 2e-6 * max(1.0, float(wt_ref.abs().max()))
     # chain rule: random plain-layout gradients through both routes
     gplain = torch.randn(mp_.SLAB_FLOATS, device="cuda") * 0.1
@@ -446,7 +453,7 @@ def test_fused_ppo_grad_gathers_rows_and_takes_the_mask_mean_itself(fa, normaliz
     got, _ = ppo_grad(obs, action, value_pred, ret, old_logp, adv, w, wt, None, team, G, A, 0.2, 0.5, 0.01, True, idx=idx,
                       normalize=normalize)
     torch.cuda.synchronize()
-    L = mp_.WEIGHT_FLOATS
+    L = mp_.PLAIN_FLOATS
     assert abs(float(got[L + 9]) - float(mm)) < 1e-6
     assert (got[:L + 4] - want[:L + 4]).abs().max() <= 1e-5 * float(want[:L].abs().max())
 

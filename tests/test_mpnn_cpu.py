@@ -210,6 +210,21 @@ def test_packed_weights_reproduce_the_module(n, m):
     assert (logits - l2).abs().max() < 2e-5 and (value - v2).abs().max() < 2e-5
     w = torch.randn(256, 128)
     assert torch.equal(mp_.unpack_gemm(mp_.pack_gemm(w), 256, 128), w)
+    # the bf16x3 pack (csrc/fa_policy.h FA_POFF3_*): every float32 weight is EXACTLY hi + mid + lo; the packed buffer carries
+    # both forms of the same matrices; lane order: 16-byte word ((cb * K/16 + s) * 3 + term) * 64 + lane, element j =
+    # W[(lane >> 5) * K/2 + 8 s + j][32 cb + (lane & 31)]
+    w3 = torch.cat((w, w * 1e-7, w * 3e5, torch.tensor([[0.0, 1.0, -1.0, 2.0 ** -100] * 32] * 16)), 0)[:256]
+    assert torch.equal(mp_.unpack_gemm3(mp_.pack_gemm3(w3), 256, 128), w3)
+    for k, (K, C) in (("AO", (64, 64)), ("AM", (128, 128)), ("W7", (256, 128)), ("W8", (128, 256)), ("W9", (256, 32))):
+        a = mp_.unpack_gemm(flat[mp_.POFF[k]:mp_.POFF[k] + K * C], K, C)
+        b = mp_.unpack_gemm3(flat[mp_.POFF3[k]:mp_.POFF3[k] + K * C * 3 // 2], K, C)
+        assert torch.equal(a, b), k
+    p16 = mp_.pack_gemm3(w).view(torch.int16).view(-1, 8)
+    hi = lambda x: int(mp_._rne_hi(torch.tensor([x])).view(torch.int32).item()) >> 16
+    for cb, s_, lane, j in ((0, 0, 0, 0), (3, 15, 63, 7), (2, 5, 37, 3)):
+        want = hi(float(w[(lane >> 5) * 128 + 8 * s_ + j, 32 * cb + (lane & 31)]))
+        got = int(p16[((cb * 16 + s_) * 3 + 0) * 64 + lane, j].item()) & 0xFFFF
+        assert got == (want & 0xFFFF), (cb, s_, lane, j)
     # lane order: float4 (cb * K/8 + t4) * 64 + lane = W[(lane >> 5) * K/2 + 4*t4 + q][32*cb + (lane & 31)]
     pk, K = mp_.pack_gemm(w).view(-1, 4), 256
     for cb, t4, lane, q in ((0, 0, 0, 0), (3, 31, 63, 3), (1, 7, 40, 2)):
