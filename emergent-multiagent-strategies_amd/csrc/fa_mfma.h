@@ -123,7 +123,11 @@ __device__ __forceinline__ void gemm_cb3(const float *arow, const fa_u32x4 *__re
     for (int s0 = 0; s0 < NS; s0 += CH) {
         if (s0 + CH < NS) {
 #pragma unroll
+#ifdef FA_X3_KO_WLOAD // (knock-out builds: where the time goes)
+            for (int c = 0; c < CH * 3; ++c) bn[c] = bq[c] ^ (unsigned)s0;
+#else
             for (int c = 0; c < CH * 3; ++c) bn[c] = wp3[((s0 + CH) * 3 + c) * 64 + lane];
+#endif
 #ifndef FA_NO_SCHED_BARRIER
             __builtin_amdgcn_sched_barrier(0); // (as gemm_cb: keep the requests here)
 #endif
@@ -136,7 +140,13 @@ __device__ __forceinline__ void gemm_cb3(const float *arow, const fa_u32x4 *__re
             for (int r = 0; r < NRB; ++r) {
                 const float *ap = arow + r * 32 * LDA + (s0 + c) * 8;
                 fa_u32x4 H, M, L;
+#ifdef FA_X3_KO_SPLIT
+                H = __builtin_bit_cast(fa_u32x4, *reinterpret_cast<const float4 *>(ap));
+                M = __builtin_bit_cast(fa_u32x4, *reinterpret_cast<const float4 *>(ap + 4));
+                L = H ^ M;
+#else
                 fa_split8(*reinterpret_cast<const float4 *>(ap), *reinterpret_cast<const float4 *>(ap + 4), H, M, L);
+#endif
                 const fa_bf16x8 ah = __builtin_bit_cast(fa_bf16x8, H), am = __builtin_bit_cast(fa_bf16x8, M),
                                 al = __builtin_bit_cast(fa_bf16x8, L);
                 acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[r], 0, 0, 0);
