@@ -35,6 +35,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~4.7 TB/s measured copy
 
 
+MFMA_BF16_PEAK_TFLOPS = 2516.6  # v_mfma_f32_32x32x16_bf16: 16 x the fp32 MFMA rate (MI355X_MICROARCH.md: ~2.5 PF dense)
 MFMA_F32_PEAK_TFLOPS = 157.3  # v_mfma_f32_32x32x2_f32: 256 CUs x 4 SIMDs x 64 flop/cycle x 2.4 GHz (MI355X_MICROARCH.md)
 
 
@@ -1083,6 +1084,13 @@ def closed_loop_rooflines(fa, L, E, G, A, T):
         flops = E * (G * policy_flops_per_row(G, A) + A * policy_flops_per_row(A, G))
         out["policy"] = {"bound": "mfma", "kernel": policy_kernel_label(E, G, A), "achieved": flops / sec / 1e12,
                          "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": flops / sec / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                         # the dense layers run on the bf16 matrix cores with every fp32 operand split exactly into three bf16
+                         # terms (six of the nine cross products, fp32 accumulate: fp32-class results, csrc/fa_mfma.h gemm_cb3).
+                         # `peak` stays the fp32-MFMA peak -- what an fp32 kernel is priced against; the split form's own
+                         # ceiling is the bf16 dense peak / 6 (six MFMAs per fp32-equivalent block)
+                         "dtype": "f32 (bf16x3 split MFMA, fp32 accumulate)",
+                         "peak_split_form": MFMA_BF16_PEAK_TFLOPS / 6.0,
+                         "frac_of_split_form_peak": flops / sec / 1e12 / (MFMA_BF16_PEAK_TFLOPS / 6.0),
                          "traffic": None, "flops_per_launch": flops, "avg_launch_us": sec * 1e6,
                          "timed_by": "hipEvents on the launch stream, 200 eager launches of fa_collect_act",
                          "share_of_env_step": "one launch per env-step next to one fa_step_kernel launch (~6 us)"}
@@ -1109,9 +1117,11 @@ def closed_loop_rooflines(fa, L, E, G, A, T):
         sec = timed(grad, 20)
         flops = mb * G * train_flops_per_row(G, A)
         out["train"] = {"bound": "mfma", "kernel": "fa_ppo_grad = fa_mask_part_kernel + fa_train_kernel<true, %d> (32-row tiles, two workgroups per CU) + "
-                                                   "fa_train_dw_kernel (weight gradients: split-K MFMA GEMM over all rows) + fa_train_mred_kernel + "
+                                                   "fa_train_dw3_kernel (weight gradients: split-K GEMM over all rows on the bf16 matrix cores, operands "
+                                                   "split exactly into three bf16 terms, fp32 accumulate) + fa_train_mred_kernel + "
                                                    "fa_train_reduce_kernel" % (4 if max(G, A) <= 4 else (6 if max(G, A) <= 6 else 8)),
                         "achieved": flops / sec / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "dtype": "f32 (tile kernel: fp32 MFMA; weight-gradient GEMM: bf16x3 split MFMA, fp32 accumulate)",
                         "frac": flops / sec / 1e12 / MFMA_F32_PEAK_TFLOPS, "traffic": None, "flops_per_launch": flops,
                         "avg_launch_us": sec * 1e6, "minibatch_rows": mb * G,
                         "timed_by": "hipEvents on the launch stream, 20 eager fa_ppo_grad calls (five launches each; the "

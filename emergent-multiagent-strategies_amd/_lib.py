@@ -104,6 +104,7 @@ EXPORTS = {
     "fa_policy_act": (C.c_int, [c_p, C.POINTER(PolicyIO), c_p]),
     "fa_collect_act": (C.c_int, [c_p, C.c_int32, C.POINTER(PolicyIO), c_p]),
     "fa_policy_weight_floats": (C.c_int64, []),
+    "fa_policy_plain_floats": (C.c_int64, []),
     "fa_attend_forward": (C.c_int, [c_p, c_p, c_p, c_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, c_p]),
     "fa_attend_backward": (C.c_int, [c_p, c_p, c_p, c_p, c_p, c_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, c_p]),
     "fa_ppo_grad": (C.c_int, [C.POINTER(PPOGradIO), c_p]),

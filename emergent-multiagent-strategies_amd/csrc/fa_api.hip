@@ -688,6 +688,7 @@ int fa_collect_act(fa_env *env, int32_t step, const fa_policy_io *io, void *stre
 }
 
 int64_t fa_policy_weight_floats(void) { return FA_POLICY_WEIGHT_FLOATS; }
+int64_t fa_policy_plain_floats(void) { return FA_POLICY_PLAIN_FLOATS; }
 
 int64_t fa_ppo_grad_floats(void) { return FA_SLAB_FLOATS; }
 int64_t fa_adam_scratch_floats(void) { return FA_ADAM_SCRATCH; }

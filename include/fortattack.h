@@ -259,11 +259,15 @@ int fa_after_update(fa_env *env, void *stream);
 /* The MPNN actor-critic forward of both teams (reference mpnn.py:117-192: _fwd + act / get_value;
  * called per env-step from learner.py:143-172) as ONE fused launch: encoders, opponent attention,
  * the K = 3 message-passing rounds, policy and value heads, log-softmax and categorical sampling
- * (FixedCategorical.sample / .mode, rlcore/distributions.py:12-17), hidden_dim = 128, fp32 MFMA.
+ * (FixedCategorical.sample / .mode, rlcore/distributions.py:12-17), hidden_dim = 128, float32 results: the dense
+ * layers run on the bf16 matrix cores with every float32 operand split EXACTLY into three bf16 terms (fp32 accumulate;
+ * fp32-class accuracy, csrc/fa_mfma.h gemm_cb3).
  * weights[t] is team t's policy (0 = guards, 1 = attackers) in the packed layout of
- * csrc/fa_policy.h (FA_POFF_*; FA_POLICY_WEIGHT_FLOATS floats; filled from a reference state_dict
- * by mpnn_pack.pack_policy) -- three pairs of consecutive linear maps are pre-multiplied there, which
- * is exact in real arithmetic.  Outputs are (E, N) rows, guards first: value, action (0..7), log-prob of the
+ * csrc/fa_policy.h: fa_policy_weight_floats() floats = the float32 sections (FA_POFF_*, fa_policy_plain_floats() floats:
+ * also the layout of the plain / gradient buffers of the update) followed by the six dense matrices once more as bf16
+ * triples in MFMA operand order (FA_POFF3_*).  Filled from a reference state_dict by mpnn_pack.pack_policy, or on the
+ * device by fa_pack_weights -- three pairs of consecutive linear maps are pre-multiplied there, which is exact in real
+ * arithmetic.  Outputs are (E, N) rows, guards first: value, action (0..7), log-prob of the
  * action.  Sampling stream: Philox4x32-10 keyed by (seed; *counter, step, global env index, agent).
  * Teams of up to 8 agents. */
 typedef struct fa_policy_io {
@@ -292,8 +296,9 @@ int fa_policy_act(fa_env *env, const fa_policy_io *io, void *stream);
  * RolloutStorage.insert, learner.py:143-172, storage.py:33-43); with value_only only value_preds[step]
  * (wrap_horizon's V(obs[T]), learner.py:196-202). */
 int fa_collect_act(fa_env *env, int32_t step, const fa_policy_io *io, void *stream);
-/* number of floats of one team's packed weight buffer */
+/* number of floats of one team's packed weight buffer; of its leading float32 sections (= a plain-layout buffer) */
 int64_t fa_policy_weight_floats(void);
+int64_t fa_policy_plain_floats(void);
 
 /* ---- PPO update: the attention between the agents of one env, forward and backward ---------------
  * (reference mpnn.py:250-332 MultiHeadAttention / :372-443 MultiHeadOppAttention, one head, inside
@@ -369,8 +374,8 @@ typedef struct fa_task {
     int32_t type;
 } fa_task;
 int fa_run_tasks(const fa_task *tasks, int32_t n, void *stream);
-/* plain: fa_policy_weight_floats() floats, row-major matrices at the FA_POFF_* offsets (csrc/fa_policy.h) ->
- * weights (fa_policy_weight_floats()) and weights_t (fa_policy_weight_t_floats()) */
+/* plain: fa_policy_plain_floats() floats, row-major matrices at the FA_POFF_* offsets (csrc/fa_policy.h) ->
+ * weights (fa_policy_weight_floats(): both halves, see fa_policy_io) and weights_t (fa_policy_weight_t_floats()) */
 int fa_pack_weights(const float *plain, float *weights, float *weights_t, void *stream);
 
 /* One optimizer step on a flat parameter buffer: nn.utils.clip_grad_norm_(max_grad_norm) over all n gradients,

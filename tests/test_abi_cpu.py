@@ -137,3 +137,22 @@ def test_product_library_has_no_experiment_kernels(fa):
     assert b"_Z19fa_step_pipe_kernel" in blob
     src = open(os.path.join(PKG, "build.py")).read()
     assert "experiments/fa_step_experiments.hip" not in src
+
+
+def test_buffer_sizes_of_the_binding_match_the_library(fa):
+    """The Python side's buffer sizes and pack offsets are the library's (csrc/fa_policy.h, fa_train.h): the packed weights
+    (float32 sections + the bf16x3 half), the plain / gradient layout, the transposed pack, the gradient slab."""
+    from emergent_multiagent_strategies_amd import mpnn_pack as mp_
+    lib = fa._lib.load()
+    assert lib.fa_policy_weight_floats() == mp_.WEIGHT_FLOATS and lib.fa_policy_plain_floats() == mp_.PLAIN_FLOATS
+    assert lib.fa_policy_weight_t_floats() == mp_.TRANS_FLOATS and lib.fa_ppo_grad_floats() == mp_.SLAB_FLOATS
+    hdr = open(os.path.join(PKG, "csrc", "fa_policy.h")).read()
+    off = dict((k, int(v)) for k, v in re.findall(r"#define FA_POFF_([A-Z0-9]+)\s+(\d+)", hdr))
+    off3 = dict((k, int(v)) for k, v in re.findall(r"#define FA_POFF3_([A-Z0-9]+)\s+(\d+)", hdr))
+    assert off == mp_.POFF and off3 == mp_.POFF3
+    sizes = dict(AO=64 * 64, BO=64 * 64, AM=128 * 128, W7=256 * 128, W8=128 * 256, W9=256 * 32)
+    at = mp_.PLAIN_FLOATS
+    for k in ("AO", "BO", "AM", "W7", "W8", "W9"):          # back to back, 1.5 floats per weight, 16-byte aligned
+        assert off3[k] == at and at % 4 == 0, k
+        at += sizes[k] * 3 // 2
+    assert at == mp_.WEIGHT_FLOATS
