@@ -6,7 +6,7 @@ TAG=${1:-r06}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R
 export TMPDIR=/tmp
-HEAD="--steps 200 --warmup 5 --no-cpu-baseline --no-closed-loop --no-esweep --no-5v5"
+HEAD="--steps 200 --warmup 5 --no-cpu-baseline --no-closed-loop --no-esweep --no-5v5 --no-live-traffic"
 bash tools/profile_gpu.sh ${TAG}_fused "$HEAD"
 bash tools/profile_gpu.sh ${TAG}_5v5_fused "$HEAD --guards 5 --attackers 5"
 bash tools/prof_grad.sh ${TAG} > gpurun_out/${TAG}_grad_kernel_stats.txt 2>&1
