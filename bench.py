@@ -549,13 +549,30 @@ def main():
     if exchanging:
         want_lib = args.exchange == "library" or (args.exchange == "auto" and args.backend == "nccl"
                                                    and bool(fa._lib.load().fa_rccl_available()))
+        lib_fallback = None
         if want_lib:
-            lib_exchange = fa_dist.LibraryExchange(dev)
-            if lib_exchange.ranks() != world:
-                raise SystemExit("bench.py: the library's RCCL communicator saw %d ranks, not %d" % (lib_exchange.ranks(), world))
+            # `auto` must not cost the run: a rank that cannot open the library's communicator says so, and ALL ranks fall back to
+            # the torch route together (the decision is agreed through the process group that exists anyway)
+            try:
+                lib_exchange = fa_dist.LibraryExchange(dev)
+                ok = lib_exchange.ranks() == world
+                err = None if ok else "the library's RCCL communicator saw %d ranks, not %d" % (lib_exchange.ranks(), world)
+            except Exception as exc:
+                ok, err = False, repr(exc)
+            flag = torch.tensor([1 if ok else 0], device=dev if args.backend == "nccl" else "cpu", dtype=torch.int32)
+            if world > 1:
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0:
+                if args.exchange == "library":
+                    raise SystemExit("bench.py --exchange library: %s" % (err or "another rank could not open the library's communicator"))
+                if lib_exchange is not None:
+                    lib_exchange.close()
+                lib_exchange, lib_fallback = None, (err or "another rank could not open the library's communicator")
+                print("rank %d: library exchange unavailable (%s): torch route" % (rank, lib_fallback), file=sys.stderr, flush=True)
         exchange_route = ("library: fa_gae_allreduce_normalize (scan + moments, ncclAllGather on the library's communicator, merge + "
                           "normalisation; one C call per rollout)" if lib_exchange is not None else
-                          "torch: fa_gae_moments, torch.distributed.all_gather_into_tensor (%s), fa_adv_merge_normalize" % args.backend)
+                          "torch: fa_gae_moments, torch.distributed.all_gather_into_tensor (%s), fa_adv_merge_normalize%s" % (
+                              args.backend, "" if not lib_fallback else " [fell back from the library route: %s]" % lib_fallback))
 
     def exchange_and_normalise(mom, mean, std):
         if exchanging:
