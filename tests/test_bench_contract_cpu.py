@@ -1,4 +1,4 @@
-"""CPU: the committed record of the driver's bench command (profiles/r05_bench_final.json, written on the GPU box by
+"""CPU: the committed record of the driver's bench command (profiles/r06_bench_final.json, written on the GPU box by
 `python bench.py --gpus 1 --steps 20 --warmup 5`) carries every field the bench contract names, with consistent arithmetic --
 so that an edit of bench.py that drops or renames one shows up here, not at the end of a round."""
 import json
@@ -12,7 +12,7 @@ def E_T(d):
 
 
 def _rec():
-    return json.load(open(os.path.join(ROOT, "profiles", "r05_bench_final.json")))
+    return json.load(open(os.path.join(ROOT, "profiles", "r06_bench_final.json")))
 
 
 def test_bench_line_has_the_contract_fields():
@@ -64,4 +64,9 @@ def test_closed_loop_records_carry_their_rooflines():
         c = d[k]
         assert c["roofline"]["bound"] == "mfma" and c["roofline"]["peak"] == 157.3
         assert abs(c["roofline"]["frac"] - c["roofline"]["achieved"] / 157.3) < 1e-9
+        # the policy kernel's dense layers run on the bf16 matrix cores with the three-way operand split: the record says so and
+        # prices the launch against the split form's own ceiling as well (bf16 dense peak / 6)
+        assert c["roofline"]["dtype"].startswith("f32 (bf16x3 split MFMA")
+        assert abs(c["roofline"]["frac_of_split_form_peak"] - c["roofline"]["achieved"] / c["roofline"]["peak_split_form"]) < 1e-9
+        assert "bf16x3" in c["update_roofline"]["dtype"]
         assert c["update_s"] > 0 and c["train_env_steps_per_s"] > 0
