@@ -156,3 +156,11 @@ def test_buffer_sizes_of_the_binding_match_the_library(fa):
         assert off3[k] == at and at % 4 == 0, k
         at += sizes[k] * 3 // 2
     assert at == mp_.WEIGHT_FLOATS
+
+
+def test_one_call_tail_refuses_null_arguments(fa):
+    """fa_gae_allreduce_normalize (the several-rank collector tail as one call): a null handle / communicator / buffer is an error
+    code with a message, not a crash -- no GPU needed to say so."""
+    lib = fa._lib.load()
+    rc = lib.fa_gae_allreduce_normalize(None, 0.99, 0.95, None, None, None, None, None, None, None)
+    assert rc < 0 and b"fa_gae_allreduce_normalize" in lib.fa_last_error()
