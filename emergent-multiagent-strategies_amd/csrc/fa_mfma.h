@@ -77,8 +77,8 @@ __device__ __forceinline__ void gemm_cb(const float *arow, const float4 *__restr
 // truncation (4 VALU operations per element, exact: a == hi + mid + lo).  Same K permutation as gemm_cb: lane half hh walks
 // k in [hh K/2, (hh + 1) K/2), eight consecutive k per 16-byte step.
 #ifndef FA_GEMM3_CH
-#define FA_GEMM3_CH 2 // K = 16 steps of weights (3 x 16 bytes per lane each) requested ahead
-#endif
+#define FA_GEMM3_CH 1 // K = 16 steps of weights (3 x 16 bytes per lane each) requested ahead (2: 84 us instead of 79 at 3v3 x 4096,
+#endif                // 157 instead of 145 at 5v5 -- the 12 more registers per step cost more than the deeper prefetch hides; 4: 123)
 typedef __bf16 fa_bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned fa_u32x4 __attribute__((ext_vector_type(4)));
 template <int K>
@@ -156,7 +156,7 @@ __device__ __forceinline__ void gemm_cb3(const float *arow, const fa_u32x4 *__re
                 acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc[r], 0, 0, 0);
                 acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[r], 0, 0, 0);
             }
-#ifndef FA_NO_SCHED_BARRIER
+#if !defined(FA_NO_SCHED_BARRIER) && !defined(FA_X3_NO_STEP_FENCE)
             // one K = 16 step at a time: left alone the scheduler hoists the LDS reads and the splits of many steps to the top
             // (the split's temporaries are 40 registers per row block) and spills
             __builtin_amdgcn_sched_barrier(0);
