@@ -4,16 +4,17 @@ import torch
 import emergent_multiagent_strategies_amd as fa
 from test_gpu_policy import _policies, _obs
 out={}
+det = len(sys.argv) > 1 and sys.argv[1] == "det"   # FixedCategorical.mode instead of a sample (no Gumbel noise)
 for G,A,E in ((3,3,4096),(5,5,4096)):
     pols, packed = _policies(fa, G, A, 1)
     eng = fa.BatchedFortAttack(E, G, A, 20); obs=_obs(E,G+A,E)
-    for _ in range(5): eng.policy_act(obs, packed[0], packed[1])
+    for _ in range(5): eng.policy_act(obs, packed[0], packed[1], deterministic=det)
     torch.cuda.synchronize()
     best=1e9
     for rep in range(3):
         a,b=torch.cuda.Event(enable_timing=True),torch.cuda.Event(enable_timing=True)
         a.record()
-        for _ in range(50): eng.policy_act(obs, packed[0], packed[1])
+        for _ in range(50): eng.policy_act(obs, packed[0], packed[1], deterministic=det)
         b.record(); torch.cuda.synchronize(); best=min(best,a.elapsed_time(b)*20)
     out["%dv%d"%(G,A)]=round(best,2)
-print(json.dumps({"lib": os.environ.get("FA_LIBRARY","product").split("/")[-1], **out}))
+print(json.dumps({"deterministic": det, "lib": os.environ.get("FA_LIBRARY","product").split("/")[-1], **out}))
