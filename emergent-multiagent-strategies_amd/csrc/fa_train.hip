@@ -36,7 +36,9 @@
 // weights requested four 16-byte steps ahead per lane (fa_policy.hip: eight): with one accumulator tile per wave and the
 // backward's operands in flight the tile kernel is at its register limit, and the shorter chunk spills less
 // (A/B: 754 -> 710 us per fa_ppo_grad call, 0.191 -> 0.180 s per update)
+#ifndef FA_GEMM_CH
 #define FA_GEMM_CH 4
+#endif
 #include "fa_mfma.h"
 #define FA_PROBE_TRAIN_TU
 #include "fa_probe.h"
