@@ -13,6 +13,7 @@ hard-wired to 5v5); the env RNG is seeded per env (`seed + global env index`).
 import argparse
 import json
 import os
+import sys
 import time
 
 import torch
@@ -55,6 +56,7 @@ def get_args():
     p.add_argument("-l", "--attacker-ckpts", nargs="+", type=int, default=[220, 650, 1240, 1600, 2520])
     p.add_argument("--guard-load-dir", default=None, help="pretrained guard checkpoint file (--pretrained-guard)")
     p.add_argument("--no-graph", action="store_true", help="do not replay the per-step sequence from hipGraphs")
+    p.add_argument("--no-pin", action="store_true", help="several ranks: do not pin the process to its slice of the GPU-local cores")
     return p.parse_args()
 
 
@@ -67,6 +69,13 @@ def main():
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if world > 1 and not args.no_pin:
+        # every update ends in cross-rank exchanges: each rank's host thread stays on its own slice of its GPU's NUMA-local cores
+        from emergent_multiagent_strategies_amd import dist as fa_dist
+        box = [None] * world
+        dist.all_gather_object(box, (rank, fa_dist.gpu_local_cpulist(local_rank)[0]))
+        pin = fa_dist.pin_rank_to_gpu_local_cpus(local_rank, rank, world, [l for _, l in sorted(box)])
+        print("rank %d -> cuda:%d, pinned to %s cpus (%s)" % (rank, local_rank, pin.get("pinned_to"), pin.get("source")), file=sys.stderr, flush=True)
     torch.manual_seed(args.seed)                       # same initial policies on every rank
     E = args.num_processes
     eng = fa.BatchedFortAttack(E, args.num_guards, args.num_attackers, args.num_env_steps, base_seed=args.seed,
